@@ -1,0 +1,299 @@
+"""ctypes wrapper over oracle/libcpu_ref.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcpu_ref.so")
+
+RANK_PROXIMITY_BM25, RANK_BM25, RANK_NONE, RANK_WORDCOUNT, RANK_PROXIMITY = 0, 1, 2, 3, 4
+OP_TERM, OP_AND, OP_OR, OP_MAYBE, OP_ANDNOT, OP_PHRASE = 0, 1, 2, 3, 4, 5
+ALL_FIELDS = 0xFFFFFFFF
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "cpu_ref.c")
+    hdr = os.path.join(_HERE, "cpu_ref.h")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libcpu_ref.so"])
+    return _LIB_PATH
+
+
+class DictEntry(C.Structure):
+    _fields_ = [("wordid", C.c_uint64), ("doclist_off", C.c_uint64), ("doclist_len", C.c_uint64),
+                ("skiplist_off", C.c_uint64), ("docs", C.c_uint32), ("hits", C.c_uint32)]
+
+
+DICT_DTYPE = np.dtype([("wordid", "<u8"), ("doclist_off", "<u8"), ("doclist_len", "<u8"),
+                       ("skiplist_off", "<u8"), ("docs", "<u4"), ("hits", "<u4")])
+assert DICT_DTYPE.itemsize == C.sizeof(DictEntry)
+
+
+class _Index(C.Structure):
+    _fields_ = [("spd", C.c_void_p), ("spd_len", C.c_size_t), ("spp", C.c_void_p), ("spp_len", C.c_size_t),
+                ("spe", C.c_void_p), ("spe_len", C.c_size_t), ("dict", C.c_void_p), ("n_terms", C.c_uint32),
+                ("total_docs", C.c_int64), ("skiplist_block_size", C.c_int), ("inline_hits", C.c_int),
+                ("n_fields", C.c_int)]
+
+
+class _Node(C.Structure):
+    _fields_ = [("op", C.c_int), ("n_children", C.c_int), ("first_child", C.c_int), ("term_id", C.c_int32),
+                ("atom_pos", C.c_int), ("field_mask", C.c_uint32), ("boost", C.c_float), ("opt", C.c_int),
+                ("not_weighted", C.c_int)]
+
+
+class _Query(C.Structure):
+    _fields_ = [("nodes", C.POINTER(_Node)), ("n_nodes", C.c_int), ("children", C.POINTER(C.c_int)),
+                ("root", C.c_int), ("ranker", C.c_int), ("max_matches", C.c_int),
+                ("field_weights", C.POINTER(C.c_int32)), ("n_weights", C.c_int), ("index_weight", C.c_int),
+                ("plain_idf", C.c_int), ("normalized_tfidf", C.c_int), ("total_docs_override", C.c_int64),
+                ("local_docs", C.POINTER(C.c_int64)), ("cutoff", C.c_int)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("n", C.c_int), ("total_found", C.c_int64), ("rowid", C.POINTER(C.c_uint32)),
+                ("weight", C.POINTER(C.c_int32)), ("fetched_docs", C.c_int64), ("fetched_hits", C.c_int64),
+                ("skips", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_zip_u64.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_zip_u64.restype = C.c_int
+        L.orc_writer_new.argtypes = [C.c_int, C.c_int]
+        L.orc_writer_new.restype = C.c_void_p
+        L.orc_writer_free.argtypes = [C.c_void_p]
+        L.orc_writer_hit.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_writer_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_writer_finish.argtypes = [C.c_void_p]
+        for nm in ("spd", "spp", "spe", "dict"):
+            f = getattr(L, "orc_writer_" + nm)
+            f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+            f.restype = C.c_void_p
+        L.orc_search.argtypes = [C.POINTER(_Index), C.POINTER(_Query), C.POINTER(_Result)]
+        L.orc_search.restype = C.c_int
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_idf.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]
+        L.orc_idf.restype = C.c_float
+        L.orc_decode_doclist.argtypes = [C.POINTER(_Index), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_decode_doclist.restype = C.c_int
+        L.orc_decode_hits.argtypes = [C.POINTER(_Index), C.c_uint64, C.c_void_p, C.c_int]
+        L.orc_decode_hits.restype = C.c_int
+        L.orc_decode_skiplist.argtypes = [C.POINTER(_Index), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_decode_skiplist.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def zip_bytes(v: int) -> bytes:
+    buf = (C.c_uint8 * 16)()
+    n = lib().orc_zip_u64(buf, v)
+    return bytes(buf[:n])
+
+
+def hitpos(fld: int, pos: int, end: bool = False) -> int:
+    return (fld << 24) | ((1 if end else 0) << 23) | (pos & 0x7FFFFF)
+
+
+@dataclass
+class Index:
+    """A segment in the reference's on-disk layout (byte arrays + flat term table)."""
+    spd: np.ndarray
+    spp: np.ndarray
+    spe: np.ndarray
+    dict: np.ndarray  # DICT_DTYPE, indexed by term id
+    total_docs: int
+    skiplist_block_size: int = 128
+    inline_hits: int = 1
+    n_fields: int = 2
+
+    def c_struct(self) -> _Index:
+        s = _Index()
+        s.spd, s.spd_len = self.spd.ctypes.data, self.spd.size
+        s.spp, s.spp_len = self.spp.ctypes.data, self.spp.size
+        s.spe, s.spe_len = self.spe.ctypes.data, self.spe.size
+        s.dict, s.n_terms = self.dict.ctypes.data, len(self.dict)
+        s.total_docs = self.total_docs
+        s.skiplist_block_size = self.skiplist_block_size
+        s.inline_hits = self.inline_hits
+        s.n_fields = self.n_fields
+        return s
+
+    def decode_doclist(self, term_id: int):
+        n = int(self.dict[term_id]["docs"])
+        rowid = np.zeros(n, np.uint32)
+        fields = np.zeros(n, np.uint32)
+        hits = np.zeros(n, np.uint32)
+        hp = np.zeros(n, np.uint64)
+        s = self.c_struct()
+        got = lib().orc_decode_doclist(C.byref(s), term_id, rowid.ctypes.data, fields.ctypes.data,
+                                       hits.ctypes.data, hp.ctypes.data)
+        assert got == n, (got, n)
+        return rowid, fields, hits, hp
+
+    def decode_hits(self, hitpos64: int) -> List[int]:
+        s = self.c_struct()
+        out = np.zeros(4096, np.uint32)
+        n = lib().orc_decode_hits(C.byref(s), int(hitpos64), out.ctypes.data, out.size)
+        return [int(x) for x in out[:n]]
+
+    def decode_skiplist(self, term_id: int):
+        s = self.c_struct()
+        cap = int(self.dict[term_id]["docs"]) // self.skiplist_block_size + 2
+        b = np.zeros(cap, np.uint32)
+        o = np.zeros(cap, np.uint64)
+        h = np.zeros(cap, np.uint64)
+        n = lib().orc_decode_skiplist(C.byref(s), term_id, b.ctypes.data, o.ctypes.data, h.ctypes.data, cap)
+        return b[:n], o[:n], h[:n]
+
+
+def build_index(wordid: np.ndarray, rowid: np.ndarray, hitp: np.ndarray, total_docs: int,
+                skiplist_block_size: int = 128, inline_hits: int = 1, n_fields: int = 2,
+                n_terms: Optional[int] = None) -> Index:
+    """Run the CSphHitBuilder restatement over hits sorted by (wordid, rowid, hitpos).
+
+    wordid values are 1-based term ids + 1 (0 is the flush marker); the returned term
+    table is indexed by (wordid - 1) and has n_terms rows (absent words: docs = 0).
+    """
+    L = lib()
+    wordid = np.ascontiguousarray(wordid, np.uint64)
+    rowid = np.ascontiguousarray(rowid, np.uint32)
+    hitp = np.ascontiguousarray(hitp, np.uint32)
+    assert wordid.size == rowid.size == hitp.size
+    assert (wordid > 0).all()
+    w = L.orc_writer_new(skiplist_block_size, inline_hits)
+    try:
+        L.orc_writer_hits(w, wordid.ctypes.data, rowid.ctypes.data, hitp.ctypes.data, wordid.size)
+        L.orc_writer_finish(w)
+        n = C.c_size_t()
+        bufs = {}
+        for nm in ("spd", "spp", "spe"):
+            p = getattr(L, "orc_writer_" + nm)(w, C.byref(n))
+            # 64 bytes of zero padding: device loaders may over-read a little past the end
+            a = np.zeros(n.value + 64, np.uint8)
+            C.memmove(a.ctypes.data, p, n.value)
+            bufs[nm] = a[: n.value]
+        p = L.orc_writer_dict(w, C.byref(n))
+        d = np.zeros(n.value, DICT_DTYPE)
+        if n.value:
+            C.memmove(d.ctypes.data, p, n.value * DICT_DTYPE.itemsize)
+    finally:
+        L.orc_writer_free(w)
+    nt = int(n_terms if n_terms is not None else (int(wordid.max()) if wordid.size else 0))
+    table = np.zeros(nt, DICT_DTYPE)
+    for e in d:
+        table[int(e["wordid"]) - 1] = e
+    return Index(bufs["spd"], bufs["spp"], bufs["spe"], table, total_docs, skiplist_block_size, inline_hits, n_fields)
+
+
+# ---------------------------------------------------------------- query trees
+@dataclass
+class QNode:
+    op: int
+    children: List["QNode"] = field(default_factory=list)
+    term_id: int = -1
+    atom_pos: int = 0
+    field_mask: int = ALL_FIELDS
+    boost: float = 1.0
+
+
+def term(term_id: int, atom_pos: int, field_mask: int = ALL_FIELDS, boost: float = 1.0) -> QNode:
+    return QNode(OP_TERM, [], term_id, atom_pos, field_mask, boost)
+
+
+def op(kind: int, *children: QNode, field_mask: int = ALL_FIELDS) -> QNode:
+    return QNode(kind, list(children), field_mask=field_mask)
+
+
+@dataclass
+class Result:
+    rowid: np.ndarray
+    weight: np.ndarray
+    total_found: int
+    fetched_docs: int = 0
+    fetched_hits: int = 0
+    skips: int = 0
+
+
+class FlatQuery:
+    """Flattened query kept alive for repeated orc_search calls (cpu_baseline timing)."""
+
+    def __init__(self, root: QNode, ranker: int = RANK_BM25, max_matches: int = 1000,
+                 field_weights: Optional[Sequence[int]] = None, index_weight: int = 1,
+                 plain_idf: bool = False, normalized_tfidf: bool = True, total_docs_override: int = 0,
+                 local_docs: Optional[dict] = None, cutoff: int = 0):
+        nodes: List[QNode] = []
+
+        def walk(n: QNode) -> int:
+            i = len(nodes)
+            nodes.append(n)
+            n._kids = [walk(c) for c in n.children]  # type: ignore[attr-defined]
+            return i
+
+        walk(root)
+        self.nodes = (_Node * len(nodes))()
+        kids: List[int] = []
+        for i, n in enumerate(nodes):
+            cn = self.nodes[i]
+            cn.op, cn.n_children, cn.first_child = n.op, len(n._kids), len(kids)  # type: ignore[attr-defined]
+            kids.extend(n._kids)  # type: ignore[attr-defined]
+            cn.term_id, cn.atom_pos, cn.field_mask, cn.boost = n.term_id, n.atom_pos, n.field_mask, n.boost
+        self.children = (C.c_int * max(1, len(kids)))(*kids)
+        q = _Query()
+        q.nodes, q.n_nodes = self.nodes, len(nodes)
+        q.children = self.children
+        q.root, q.ranker, q.max_matches = 0, ranker, max_matches
+        if field_weights is not None:
+            self.fw = (C.c_int32 * len(field_weights))(*field_weights)
+            q.field_weights, q.n_weights = self.fw, len(field_weights)
+        q.index_weight = index_weight
+        q.plain_idf, q.normalized_tfidf = int(plain_idf), int(normalized_tfidf)
+        q.total_docs_override = total_docs_override
+        if local_docs:
+            arr = [-1] * len(nodes)
+            for i, n in enumerate(nodes):
+                if n.op == OP_TERM and n.term_id in local_docs:
+                    arr[i] = int(local_docs[n.term_id])
+            self.ld = (C.c_int64 * len(nodes))(*arr)
+            q.local_docs = self.ld
+        q.cutoff = cutoff
+        self.q = q
+        self.K = max_matches
+
+    def run(self, index: Index, cidx: Optional[_Index] = None) -> Result:
+        s = cidx if cidx is not None else index.c_struct()
+        rowid = np.zeros(self.K, np.uint32)
+        weight = np.zeros(self.K, np.int32)
+        r = _Result()
+        r.rowid = rowid.ctypes.data_as(C.POINTER(C.c_uint32))
+        r.weight = weight.ctypes.data_as(C.POINTER(C.c_int32))
+        rc = lib().orc_search(C.byref(s), C.byref(self.q), C.byref(r))
+        if rc != 0:
+            raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+        return Result(rowid[: r.n].copy(), weight[: r.n].copy(), int(r.total_found), int(r.fetched_docs),
+                      int(r.fetched_hits), int(r.skips))
+
+
+def search(index: Index, root: QNode, **kw) -> Result:
+    return FlatQuery(root, **kw).run(index)
+
+
+def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool = True, n_qwords: int = 1,
+        boost: float = 1.0) -> float:
+    return float(lib().orc_idf(term_docs, total_docs, int(plain), int(normalized), n_qwords, boost))

@@ -1,0 +1,80 @@
+"""Test helpers: a tiny text -> hits pipeline so that the reference's own test corpora
+(test/test_019, test_037, test_322, gtests_rtstuff.cpp) can be turned into postings.
+
+Only what those corpora need: lower-casing, [a-z0-9_] + Cyrillic words, single CJK
+characters as 1-grams, min_word_len with position-preserving overshort skips
+(overshort_step=1), 1-based in-field positions, field-end marker on a field's last hit.
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+_TOKEN = re.compile(r"[a-z0-9_а-я]+|[㐀-龿]")
+
+
+def tokenize(text: str, min_word_len: int = 1) -> List[Tuple[str, int]]:
+    """-> [(token, position)], positions 1-based; overshort ASCII words keep their slot."""
+    out = []
+    pos = 0
+    for m in _TOKEN.finditer(text.lower()):
+        t = m.group(0)
+        pos += 1
+        if len(t) < min_word_len and t.isascii():
+            continue
+        out.append((t, pos))
+    return out
+
+
+def make_hits(docs: Sequence[Sequence[str]], min_word_len: int = 1):
+    """docs[rowid] = [field0 text, field1 text, ...] -> (wordid, rowid, hitpos) arrays sorted
+    by (wordid, rowid, hitpos), plus the vocabulary {token: term_id} (wordid = term_id + 1)."""
+    vocab: Dict[str, int] = {}
+    raw = []
+    for rowid, fields in enumerate(docs):
+        for f, text in enumerate(fields):
+            toks = tokenize(text, min_word_len)
+            for i, (t, pos) in enumerate(toks):
+                raw.append((t, rowid, f, pos, i == len(toks) - 1))
+    for t in sorted({r[0] for r in raw}):
+        vocab[t] = len(vocab)
+    hits = sorted((vocab[t] + 1, rowid, (f << 24) | pos, end) for t, rowid, f, pos, end in raw)
+    wordid = np.array([h[0] for h in hits], np.uint64)
+    rowid = np.array([h[1] for h in hits], np.uint32)
+    hitpos = np.array([h[2] | ((1 << 23) if h[3] else 0) for h in hits], np.uint32)
+    return wordid, rowid, hitpos, vocab
+
+
+def mini_index(orc, docs, min_word_len: int = 1, skiplist_block_size: int = 128, inline_hits: int = 1):
+    wordid, rowid, hitpos, vocab = make_hits(docs, min_word_len)
+    n_fields = max(len(d) for d in docs)
+    idx = orc.build_index(wordid, rowid, hitpos, total_docs=len(docs), skiplist_block_size=skiplist_block_size,
+                          inline_hits=inline_hits, n_fields=n_fields, n_terms=len(vocab))
+    return idx, vocab
+
+
+def synth_postings(rng: np.random.Generator, n_docs: int, probs: Sequence[float], n_fields: int = 2,
+                   max_pos: int = 1024, title_frac: float = 0.1, end_markers: bool = False):
+    """Small random corpus for parity tests: term t appears in a doc with probability probs[t];
+    tf = 1 + min(254, geometric(0.5)); hits spread over fields (field 0 w.p. title_frac)."""
+    W, R, H = [], [], []
+    for t, p in enumerate(probs):
+        mask = rng.random(n_docs) < p
+        rows = np.nonzero(mask)[0].astype(np.uint32)
+        for r in rows:
+            tf = 1 + min(254, int(rng.geometric(0.5)) - 1)
+            f = (rng.random(tf) >= title_frac).astype(np.uint32) if n_fields > 1 else np.zeros(tf, np.uint32)
+            if n_fields > 2:
+                f = rng.integers(0, n_fields, tf).astype(np.uint32)
+            pos = rng.integers(1, max_pos + 1, tf).astype(np.uint32)
+            hp = np.unique((f << 24) | pos)
+            if end_markers and rng.random() < 0.2:
+                hp[-1] |= 1 << 23
+            W.append(np.full(hp.size, t + 1, np.uint64))
+            R.append(np.full(hp.size, r, np.uint32))
+            H.append(hp.astype(np.uint32))
+    if not W:
+        return np.zeros(0, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+    return np.concatenate(W), np.concatenate(R), np.concatenate(H)
