@@ -1,0 +1,215 @@
+/*
+ * mrk.h -- C-ABI of the MI355X-native match -> rank -> top-K path ("mrk").
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Each entry point names the reference interface it stands in for
+ * (paths relative to the Manticore 3.6.1 tree, src/...).
+ *
+ *   mrk_segment_create   <- what DiskIndexQwordSetup_c binds per index: .spd/.spp/.spe
+ *                           readers + skiplist_block_size + the dictionary lookup result
+ *                           CSphDictEntry (sphinx.cpp:326-354, 12953-13080; sphinx.h:542-552)
+ *   mrk_query (tree)     <- XQNode_t / XQKeyword_t as handed to sphCreateRanker
+ *                           (sphinxquery.h:134-286; sphinxsearch.cpp:4167)
+ *   mrk_batch_submit     <- sphCreateRanker + the MatchExtended loop
+ *                           (sphinxsearch.cpp:4167-4380; sphinx.cpp:12190-12269):
+ *                           ExtNode_i::Create, IDF setup, GetMatches() until exhausted
+ *   mrk_result           <- what the caller reads back from ISphMatchSorter:
+ *                           Flatten() order + GetTotalCount() (sphinxsort.h:39-133,
+ *                           sphinxsort.cpp:627-641, 724) and CSphQueryStats (sphinx.h:2697-2705)
+ *   mrk_topk_merge       <- CSphMatchQueue::MoveTo across chunks / shards
+ *                           (sphinxsort.cpp:681-710; sphinxrt.cpp:5945-5981)
+ *   mrk_idf              <- the IDF block of sphCreateRanker (sphinxsearch.cpp:4317-4361)
+ *
+ * Threading: a mrk_ctx owns one HIP device + stream; a mrk_batch is used by one thread
+ * at a time; different batches may be driven from different threads.  All HIP calls are
+ * made on the calling thread: a host that runs rankers on small coroutine stacks
+ * (coroutine.cpp:47) must call from a regular thread.
+ *
+ * Errors: every function returns MRK_OK (0) or a negative code; mrk_last_error() gives
+ * the message for the calling thread (the reference's convention: no exceptions, error
+ * string on the side -- sphinxsearch.cpp:4377-4378).
+ */
+#ifndef MRK_H
+#define MRK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRK_OK 0
+#define MRK_E_INVAL (-1)       /* bad argument */
+#define MRK_E_UNSUPPORTED (-2) /* query shape / ranker the device path does not cover (yet) */
+#define MRK_E_HIP (-3)         /* HIP runtime failure */
+#define MRK_E_NOMEM (-4)
+#define MRK_E_FORMAT (-5)      /* malformed index bytes */
+
+#define MRK_INVALID_ROWID 0xFFFFFFFFu
+#define MRK_MAX_AND_TERMS 8    /* device N-way AND width */
+#define MRK_MAX_K 1024         /* device top-K capacity (max_matches default is 1000) */
+#define MRK_ALL_FIELDS 0xFFFFFFFFu
+
+/* ESphRankMode order (sphinx.h) */
+enum {
+  MRK_RANK_PROXIMITY_BM25 = 0,
+  MRK_RANK_BM25 = 1,
+  MRK_RANK_NONE = 2,
+  MRK_RANK_WORDCOUNT = 3,
+  MRK_RANK_PROXIMITY = 4
+};
+
+/* XQOperator_e subset (sphinxquery.h) */
+enum { MRK_OP_TERM = 0, MRK_OP_AND = 1, MRK_OP_OR = 2, MRK_OP_MAYBE = 3, MRK_OP_ANDNOT = 4, MRK_OP_PHRASE = 5 };
+
+enum { MRK_HITFMT_PLAIN = 0, MRK_HITFMT_INLINE = 1 }; /* ESphHitFormat */
+
+typedef struct mrk_ctx mrk_ctx;
+typedef struct mrk_segment mrk_segment;
+typedef struct mrk_batch mrk_batch;
+
+/* CSphDictEntry (sphinx.h:542-552): result of the dictionary lookup for one keyword */
+typedef struct {
+  uint64_t wordid;       /* m_uWordID (informational) */
+  uint64_t doclist_off;  /* m_iDoclistOffset into .spd */
+  uint64_t doclist_len;  /* m_iDoclistLength, bytes incl. the 0 terminator */
+  uint64_t skiplist_off; /* m_iSkiplistOffset into .spe (valid iff docs > skiplist_block_size) */
+  uint32_t docs;         /* m_iDocs */
+  uint32_t hits;         /* m_iHits */
+} mrk_dict_entry;
+
+/* One index segment (plain index / RT disk chunk) in the reference's v62 byte format */
+typedef struct {
+  const uint8_t* spd; /* doclists  (host memory; copied to HBM) */
+  uint64_t spd_len;
+  const uint8_t* spp; /* hitlists */
+  uint64_t spp_len;
+  const uint8_t* spe; /* skiplists */
+  uint64_t spe_len;
+  const mrk_dict_entry* dict; /* flat term table indexed by term id (stands in for .spi) */
+  uint32_t n_terms;
+  uint64_t total_docs;          /* m_iTotalDocuments */
+  uint32_t skiplist_block_size; /* index setting; 32 (default) or 128 */
+  uint32_t hit_format;          /* MRK_HITFMT_* */
+  uint32_t n_fields;            /* schema full-text fields (<= 32 on the device path) */
+  uint32_t rowid_base;          /* global docid = rowid_base + rowid for shard merges */
+} mrk_segment_desc;
+
+/* XQNode_t flattened: nodes[] + children[] (indices into nodes[]) */
+typedef struct {
+  int32_t op;          /* MRK_OP_* */
+  int32_t n_children;
+  int32_t first_child; /* offset into children[] */
+  int32_t term_id;     /* leaf: dictionary slot; < 0 = keyword not in the dictionary */
+  int32_t atom_pos;    /* XQKeyword_t::m_iAtomPos */
+  uint32_t field_mask; /* XQLimitSpec_t::m_dFieldMask, low dword */
+  float boost;         /* XQKeyword_t::m_fBoost */
+  int32_t opt;         /* XQNode_t::m_iOpArg */
+  int32_t not_weighted;
+} mrk_node;
+
+/* CSphQuery fields that reach the ranker + the query tree */
+typedef struct {
+  const mrk_node* nodes;
+  int32_t n_nodes;
+  const int32_t* children;
+  int32_t root;
+  int32_t ranker;               /* MRK_RANK_* (CSphQuery::m_eRanker) */
+  int32_t max_matches;          /* K (CSphQuery::m_iMaxMatches) */
+  const int32_t* field_weights; /* CSphQueryContext::m_dWeights, NULL => 1 per field */
+  int32_t n_weights;
+  int32_t index_weight;         /* MatchExtended iIndexWeight, 0 => 1 */
+  int32_t plain_idf;            /* CSphQuery::m_bPlainIDF */
+  int32_t normalized_tfidf;     /* CSphQuery::m_bNormalizedTFIDF */
+  int64_t total_docs_override;  /* CSphQueryContext::m_iTotalDocs (local_df), <= 0: segment's */
+  const int64_t* local_docs;    /* per node: m_pLocalDocs override of term docs, < 0 none; or NULL */
+  int32_t cutoff;               /* CSphQuery::m_iCutoff; only 0 supported on device */
+} mrk_query;
+
+typedef struct {
+  int32_t n;              /* matches returned, best first (<= max_matches) */
+  int64_t total_found;    /* ISphMatchSorter::GetTotalCount() */
+  const uint32_t* rowid;  /* n entries, valid until the batch is resubmitted/destroyed */
+  const int32_t* weight;
+  int32_t status;         /* MRK_OK or MRK_E_UNSUPPORTED for this query */
+} mrk_result;
+
+typedef struct {
+  float scan_ms;          /* decode+intersect+score kernel, HIP-event time on the batch stream */
+  float merge_ms;         /* top-K merge kernel */
+  uint64_t algo_bytes;    /* sum over queries of doclist bytes of their terms (reference format) */
+  uint64_t n_items;       /* work items (workgroups) launched by the scan kernel */
+} mrk_batch_stats;
+
+const char* mrk_last_error(void);
+
+int mrk_ctx_create(int device, mrk_ctx** out);
+void mrk_ctx_destroy(mrk_ctx* ctx);
+/* tunables: "item_bytes" (work-item size target) ; returns MRK_E_INVAL for unknown keys */
+int mrk_ctx_set(mrk_ctx* ctx, const char* key, int64_t value);
+
+int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* desc, mrk_segment** out);
+void mrk_segment_destroy(mrk_segment* seg);
+/* device bytes held, and the reference-format doclist bytes of one term */
+uint64_t mrk_segment_device_bytes(const mrk_segment* seg);
+
+int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** out);
+void mrk_batch_destroy(mrk_batch* b);
+/* plan on host, copy descriptors, launch kernels, start the result copy; returns at once */
+int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n_queries);
+/* block until the results of the last submit are in host memory */
+int mrk_batch_wait(mrk_batch* b);
+int mrk_batch_result(mrk_batch* b, uint32_t q, mrk_result* out);
+int mrk_batch_stats_get(mrk_batch* b, mrk_batch_stats* out);
+/* device-resident partial top-K of the last submit, for shard merges without a host hop:
+   keys[q*MRK_MAX_K + i] = ((weight ^ 0x80000000) << 32) | ~(rowid_base + rowid), sorted
+   descending; counts[q]; totals[q].  Valid after mrk_batch_wait. */
+int mrk_batch_device_results(mrk_batch* b, const uint64_t** keys, const uint32_t** counts, const uint64_t** totals);
+
+/* merge n_lists sorted partial top-K lists per query (device pointers):
+   in_keys[(l*n_queries + q)*MRK_MAX_K + i], in_counts[l*n_queries + q] -> out_keys[q*MRK_MAX_K + i],
+   out_counts[q].  Order: weight desc, global docid asc. Synchronous on the ctx stream. */
+int mrk_topk_merge(mrk_ctx* ctx, const uint64_t* in_keys, const uint32_t* in_counts, uint32_t n_lists,
+                   uint32_t n_queries, uint32_t k, uint64_t* out_keys, uint32_t* out_counts);
+
+/* IDF exactly as sphCreateRanker computes it (host libm logf) */
+float mrk_idf(int64_t term_docs, int64_t total_docs, int plain_idf, int normalized, int n_qwords, float boost);
+
+/* ------------------------------------------------------------------------------------
+ * Host-side index construction (format writer + synthetic corpus); no GPU involved.
+ * Writer follows CSphHitBuilder (sphinx.cpp:8378-8719) byte for byte.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mrk_host_index mrk_host_index;
+
+/* hits sorted by (wordid, rowid, hitpos); wordid = term id + 1 */
+int mrk_index_from_hits(const uint64_t* wordid, const uint32_t* rowid, const uint32_t* hitpos, uint64_t n,
+                        uint32_t n_terms, uint32_t skiplist_block_size, uint32_t hit_format, mrk_host_index** out);
+
+typedef struct {
+  uint64_t seed;
+  uint64_t n_docs;          /* docs in this segment (rowids 0..n_docs-1) */
+  uint32_t shard;           /* mixed into the seed so shards are independent */
+  const double* term_prob;  /* document probability of each generated term */
+  uint32_t n_terms;
+  uint32_t n_fields;        /* hits fall into field 0 with prob title_frac, else uniformly in 1..n_fields-1 */
+  double title_frac;
+  uint32_t max_pos;         /* positions uniform in [1, max_pos] */
+  uint32_t skiplist_block_size;
+  uint32_t hit_format;
+  uint32_t end_markers;     /* set the field-end bit on a doc's last hit per field */
+  uint32_t n_threads;       /* 0 = hardware concurrency */
+} mrk_synth_params;
+
+int mrk_synth_generate(const mrk_synth_params* p, mrk_host_index** out);
+void mrk_host_index_free(mrk_host_index* h);
+/* buffers have 64 zero bytes of slack after *len */
+const uint8_t* mrk_host_index_spd(const mrk_host_index* h, uint64_t* len);
+const uint8_t* mrk_host_index_spp(const mrk_host_index* h, uint64_t* len);
+const uint8_t* mrk_host_index_spe(const mrk_host_index* h, uint64_t* len);
+const mrk_dict_entry* mrk_host_index_dict(const mrk_host_index* h, uint32_t* n_terms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRK_H */

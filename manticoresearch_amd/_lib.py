@@ -1,0 +1,128 @@
+"""ctypes binding of csrc/libmrk.so (the C-ABI declared in include/mrk.h).
+
+The HIP extension is the product path: if it is missing this module raises -- there is
+no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmrk.so")
+
+MRK_OK, MRK_E_INVAL, MRK_E_UNSUPPORTED, MRK_E_HIP, MRK_E_NOMEM, MRK_E_FORMAT = 0, -1, -2, -3, -4, -5
+MRK_MAX_K = 1024
+MRK_MAX_AND_TERMS = 8
+
+
+class MrkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mrk error {code}: {msg}")
+        self.code = code
+
+
+class DictEntry(C.Structure):
+    _fields_ = [("wordid", C.c_uint64), ("doclist_off", C.c_uint64), ("doclist_len", C.c_uint64),
+                ("skiplist_off", C.c_uint64), ("docs", C.c_uint32), ("hits", C.c_uint32)]
+
+
+class SegmentDesc(C.Structure):
+    _fields_ = [("spd", C.c_void_p), ("spd_len", C.c_uint64), ("spp", C.c_void_p), ("spp_len", C.c_uint64),
+                ("spe", C.c_void_p), ("spe_len", C.c_uint64), ("dict", C.c_void_p), ("n_terms", C.c_uint32),
+                ("total_docs", C.c_uint64), ("skiplist_block_size", C.c_uint32), ("hit_format", C.c_uint32),
+                ("n_fields", C.c_uint32), ("rowid_base", C.c_uint32)]
+
+
+class Node(C.Structure):
+    _fields_ = [("op", C.c_int32), ("n_children", C.c_int32), ("first_child", C.c_int32), ("term_id", C.c_int32),
+                ("atom_pos", C.c_int32), ("field_mask", C.c_uint32), ("boost", C.c_float), ("opt", C.c_int32),
+                ("not_weighted", C.c_int32)]
+
+
+class Query(C.Structure):
+    _fields_ = [("nodes", C.POINTER(Node)), ("n_nodes", C.c_int32), ("children", C.POINTER(C.c_int32)),
+                ("root", C.c_int32), ("ranker", C.c_int32), ("max_matches", C.c_int32),
+                ("field_weights", C.POINTER(C.c_int32)), ("n_weights", C.c_int32), ("index_weight", C.c_int32),
+                ("plain_idf", C.c_int32), ("normalized_tfidf", C.c_int32), ("total_docs_override", C.c_int64),
+                ("local_docs", C.POINTER(C.c_int64)), ("cutoff", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n", C.c_int32), ("total_found", C.c_int64), ("rowid", C.POINTER(C.c_uint32)),
+                ("weight", C.POINTER(C.c_int32)), ("status", C.c_int32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("scan_ms", C.c_float), ("merge_ms", C.c_float), ("algo_bytes", C.c_uint64), ("n_items", C.c_uint64)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_docs", C.c_uint64), ("shard", C.c_uint32), ("term_prob", C.POINTER(C.c_double)),
+                ("n_terms", C.c_uint32), ("n_fields", C.c_uint32), ("title_frac", C.c_double), ("max_pos", C.c_uint32),
+                ("skiplist_block_size", C.c_uint32), ("hit_format", C.c_uint32), ("end_markers", C.c_uint32),
+                ("n_threads", C.c_uint32)]
+
+
+# every symbol include/mrk.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("mrk_last_error", C.c_char_p, []),
+    ("mrk_ctx_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("mrk_ctx_destroy", None, [C.c_void_p]),
+    ("mrk_ctx_set", C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    ("mrk_segment_create", C.c_int, [C.c_void_p, C.POINTER(SegmentDesc), C.POINTER(C.c_void_p)]),
+    ("mrk_segment_destroy", None, [C.c_void_p]),
+    ("mrk_segment_device_bytes", C.c_uint64, [C.c_void_p]),
+    ("mrk_batch_create", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mrk_batch_destroy", None, [C.c_void_p]),
+    ("mrk_batch_submit", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Query), C.c_uint32]),
+    ("mrk_batch_wait", C.c_int, [C.c_void_p]),
+    ("mrk_batch_result", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Result)]),
+    ("mrk_batch_stats_get", C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
+    ("mrk_batch_device_results", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("mrk_topk_merge", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("mrk_idf", C.c_float, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]),
+    ("mrk_index_from_hits", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mrk_synth_generate", C.c_int, [C.POINTER(SynthParams), C.POINTER(C.c_void_p)]),
+    ("mrk_host_index_free", None, [C.c_void_p]),
+    ("mrk_host_index_spd", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("mrk_host_index_spp", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("mrk_host_index_spe", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("mrk_host_index_dict", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32)]),
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile libmrk.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("mrk_kernels.hip", "mrk_host.cpp", "mrk_writer.cpp", "mrk_dev.h")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mrk.h"))
+    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "libmrk.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the HIP extension is the only execution path; there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != MRK_OK:
+        raise MrkError(rc, lib().mrk_last_error().decode(errors="replace"))

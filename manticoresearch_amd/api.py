@@ -1,0 +1,323 @@
+"""Host-side Python mirror of the reference's interface for this path.
+
+Names follow the reference (Manticore 3.6.1): an index *segment* (plain index / RT disk
+chunk) holds doclists (.spd), hitlists (.spp) and skiplists (.spe); a query is an
+``XQNode`` tree of keywords (``XQKeyword``) plus the ``CSphQuery`` knobs that reach the
+ranker (ranker mode, max_matches, field_weights, idf flags, local_df); results are what an
+``ISphMatchSorter`` hands back: matches best-first + total_found.
+
+Everything here is thin plumbing over the C-ABI (include/mrk.h); the work happens in the
+HIP kernels of csrc/mrk_kernels.hip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import MrkError, check, lib
+
+# ESphRankMode / XQOperator_e subsets (include/mrk.h)
+SPH_RANK_PROXIMITY_BM25, SPH_RANK_BM25, SPH_RANK_NONE, SPH_RANK_WORDCOUNT, SPH_RANK_PROXIMITY = 0, 1, 2, 3, 4
+SPH_QUERY_TERM, SPH_QUERY_AND, SPH_QUERY_OR, SPH_QUERY_MAYBE, SPH_QUERY_ANDNOT, SPH_QUERY_PHRASE = 0, 1, 2, 3, 4, 5
+SPH_HIT_FORMAT_PLAIN, SPH_HIT_FORMAT_INLINE = 0, 1
+ALL_FIELDS = 0xFFFFFFFF
+
+DICT_DTYPE = np.dtype([("wordid", "<u8"), ("doclist_off", "<u8"), ("doclist_len", "<u8"),
+                       ("skiplist_off", "<u8"), ("docs", "<u4"), ("hits", "<u4")])
+assert DICT_DTYPE.itemsize == C.sizeof(_lib.DictEntry)
+
+
+# --------------------------------------------------------------------------- host index
+@dataclass
+class HostIndex:
+    """One segment's bytes in host memory, in the reference's on-disk layout."""
+    spd: np.ndarray
+    spp: np.ndarray
+    spe: np.ndarray
+    dict: np.ndarray  # DICT_DTYPE, indexed by term id
+    total_docs: int
+    skiplist_block_size: int = 128
+    hit_format: int = SPH_HIT_FORMAT_INLINE
+    n_fields: int = 2
+
+    @property
+    def doclist_bytes(self) -> int:
+        return int(self.dict["doclist_len"].sum())
+
+
+def _take_host_index(h: int, total_docs: int, skiplist_block_size: int, hit_format: int, n_fields: int) -> HostIndex:
+    L = lib()
+    try:
+        n = C.c_uint64()
+        out = {}
+        for nm in ("spd", "spp", "spe"):
+            p = getattr(L, "mrk_host_index_" + nm)(h, C.byref(n))
+            a = np.empty(n.value + 64, np.uint8)  # keep the 64 slack bytes the writer provides
+            C.memmove(a.ctypes.data, p, n.value + 64)
+            out[nm] = a[: n.value]
+        nt = C.c_uint32()
+        p = L.mrk_host_index_dict(h, C.byref(nt))
+        d = np.zeros(nt.value, DICT_DTYPE)
+        if nt.value:
+            C.memmove(d.ctypes.data, p, nt.value * DICT_DTYPE.itemsize)
+    finally:
+        L.mrk_host_index_free(h)
+    return HostIndex(out["spd"], out["spp"], out["spe"], d, total_docs, skiplist_block_size, hit_format, n_fields)
+
+
+def index_from_hits(wordid: np.ndarray, rowid: np.ndarray, hitpos: np.ndarray, n_terms: int, total_docs: int,
+                    skiplist_block_size: int = 128, hit_format: int = SPH_HIT_FORMAT_INLINE, n_fields: int = 2) -> HostIndex:
+    """Encode explicit hits (sorted by wordid, rowid, hitpos; wordid = term id + 1)."""
+    wordid = np.ascontiguousarray(wordid, np.uint64)
+    rowid = np.ascontiguousarray(rowid, np.uint32)
+    hitpos = np.ascontiguousarray(hitpos, np.uint32)
+    h = C.c_void_p()
+    check(lib().mrk_index_from_hits(wordid.ctypes.data, rowid.ctypes.data, hitpos.ctypes.data, wordid.size, n_terms,
+                                    skiplist_block_size, hit_format, C.byref(h)))
+    return _take_host_index(h, total_docs, skiplist_block_size, hit_format, n_fields)
+
+
+def synth_index(n_docs: int, term_prob: Sequence[float], seed: int = 0x5EED0001, shard: int = 0, n_fields: int = 2,
+                title_frac: float = 0.1, max_pos: int = 1024, skiplist_block_size: int = 128,
+                hit_format: int = SPH_HIT_FORMAT_INLINE, end_markers: bool = False, n_threads: int = 0) -> HostIndex:
+    """Deterministic synthetic postings for the given per-term document probabilities."""
+    probs = (C.c_double * len(term_prob))(*[float(x) for x in term_prob])
+    p = _lib.SynthParams(seed, n_docs, shard, probs, len(term_prob), n_fields, title_frac, max_pos,
+                         skiplist_block_size, hit_format, int(end_markers), n_threads)
+    h = C.c_void_p()
+    check(lib().mrk_synth_generate(C.byref(p), C.byref(h)))
+    return _take_host_index(h, n_docs, skiplist_block_size, hit_format, n_fields)
+
+
+# --------------------------------------------------------------------------- query tree
+@dataclass
+class XQKeyword:
+    term_id: int              # dictionary slot of m_sWord (< 0: not in the dictionary)
+    atom_pos: int             # m_iAtomPos
+    boost: float = 1.0        # m_fBoost
+
+
+@dataclass
+class XQNode:
+    op: int = SPH_QUERY_AND
+    children: List["XQNode"] = field(default_factory=list)
+    word: Optional[XQKeyword] = None
+    field_mask: int = ALL_FIELDS   # m_dSpec.m_dFieldMask (low dword)
+    opt: int = 0                   # m_iOpArg
+
+    @staticmethod
+    def keyword(term_id: int, atom_pos: int, field_mask: int = ALL_FIELDS, boost: float = 1.0) -> "XQNode":
+        return XQNode(SPH_QUERY_TERM, [], XQKeyword(term_id, atom_pos, boost), field_mask)
+
+    @staticmethod
+    def AND(*kids: "XQNode") -> "XQNode":
+        return XQNode(SPH_QUERY_AND, list(kids))
+
+
+@dataclass
+class Query:
+    """CSphQuery fields that reach the ranker, plus the parsed tree."""
+    root: XQNode
+    ranker: int = SPH_RANK_PROXIMITY_BM25
+    max_matches: int = 1000
+    field_weights: Optional[Sequence[int]] = None
+    index_weight: int = 1
+    plain_idf: bool = False
+    normalized_tfidf: bool = True
+    total_docs: int = 0                       # local_df: m_iTotalDocs override
+    local_docs: Optional[Dict[int, int]] = None  # local_df: term id -> global docs
+    cutoff: int = 0
+
+
+class _CQueries:
+    """Flattened C structs for a list of queries (kept alive while a batch runs)."""
+
+    def __init__(self, queries: Sequence[Query]):
+        self.keep = []
+        self.arr = (_lib.Query * max(1, len(queries)))()
+        for qi, q in enumerate(queries):
+            nodes: List[XQNode] = []
+            kids_of: List[List[int]] = []
+
+            def walk(n: XQNode) -> int:
+                i = len(nodes)
+                nodes.append(n)
+                kids_of.append([])
+                kids_of[i] = [walk(c) for c in n.children]
+                return i
+
+            walk(q.root)
+            cn = (_lib.Node * len(nodes))()
+            flat: List[int] = []
+            for i, n in enumerate(nodes):
+                cn[i].op, cn[i].n_children, cn[i].first_child = n.op, len(kids_of[i]), len(flat)
+                flat.extend(kids_of[i])
+                cn[i].field_mask, cn[i].opt = n.field_mask, n.opt
+                if n.word is not None:
+                    cn[i].term_id, cn[i].atom_pos, cn[i].boost = n.word.term_id, n.word.atom_pos, n.word.boost
+                else:
+                    cn[i].term_id, cn[i].boost = -1, 1.0
+            ch = (C.c_int32 * max(1, len(flat)))(*flat)
+            c = self.arr[qi]
+            c.nodes, c.n_nodes, c.children, c.root = cn, len(nodes), ch, 0
+            c.ranker, c.max_matches = q.ranker, q.max_matches
+            if q.field_weights is not None:
+                fw = (C.c_int32 * len(q.field_weights))(*q.field_weights)
+                c.field_weights, c.n_weights = fw, len(q.field_weights)
+                self.keep.append(fw)
+            c.index_weight = q.index_weight
+            c.plain_idf, c.normalized_tfidf = int(q.plain_idf), int(q.normalized_tfidf)
+            c.total_docs_override = q.total_docs
+            if q.local_docs:
+                ld = (C.c_int64 * len(nodes))(*[
+                    int(q.local_docs.get(n.word.term_id, -1)) if n.word is not None else -1 for n in nodes])
+                c.local_docs = ld
+                self.keep.append(ld)
+            c.cutoff = q.cutoff
+            self.keep += [cn, ch]
+
+
+@dataclass
+class Matches:
+    """What the sorter hands back for one query: Flatten() order + GetTotalCount()."""
+    rowid: np.ndarray
+    weight: np.ndarray
+    total_found: int
+    status: int = 0
+
+
+# --------------------------------------------------------------------------- device objects
+class Context:
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        check(lib().mrk_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def set(self, key: str, value: int) -> None:
+        check(lib().mrk_ctx_set(self._h, key.encode(), value))
+
+    def close(self) -> None:
+        if self._h:
+            lib().mrk_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Segment:
+    """A HostIndex made resident in HBM (+ the device block index built from its skiplists)."""
+
+    def __init__(self, ctx: Context, hi: HostIndex, rowid_base: int = 0):
+        self.ctx = ctx
+        self.host = hi
+        d = _lib.SegmentDesc()
+        d.spd, d.spd_len = hi.spd.ctypes.data, hi.spd.size
+        d.spp, d.spp_len = hi.spp.ctypes.data, hi.spp.size
+        d.spe, d.spe_len = hi.spe.ctypes.data, hi.spe.size
+        d.dict, d.n_terms = hi.dict.ctypes.data, len(hi.dict)
+        d.total_docs = hi.total_docs
+        d.skiplist_block_size, d.hit_format, d.n_fields = hi.skiplist_block_size, hi.hit_format, hi.n_fields
+        d.rowid_base = rowid_base
+        self._h = C.c_void_p()
+        check(lib().mrk_segment_create(ctx._h, C.byref(d), C.byref(self._h)))
+
+    @property
+    def device_bytes(self) -> int:
+        return int(lib().mrk_segment_device_bytes(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            lib().mrk_segment_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """Submits batches of queries against a segment; one in flight at a time."""
+
+    def __init__(self, ctx: Context, max_queries: int):
+        self.ctx = ctx
+        self.max_queries = max_queries
+        self._h = C.c_void_p()
+        check(lib().mrk_batch_create(ctx._h, max_queries, C.byref(self._h)))
+        self._cq = None
+        self._n = 0
+
+    def submit(self, seg: Segment, queries: Sequence[Query]) -> None:
+        self._cq = _CQueries(queries)
+        self._n = len(queries)
+        check(lib().mrk_batch_submit(self._h, seg._h, self._cq.arr, self._n))
+
+    def submit_prepared(self, seg: Segment, cq: "_CQueries", n: int) -> None:
+        """Re-submit already flattened queries (benchmarks: no Python flattening in the loop)."""
+        self._cq, self._n = cq, n
+        check(lib().mrk_batch_submit(self._h, seg._h, cq.arr, n))
+
+    def wait(self) -> None:
+        check(lib().mrk_batch_wait(self._h))
+
+    def results(self) -> List[Matches]:
+        out = []
+        r = _lib.Result()
+        for i in range(self._n):
+            check(lib().mrk_batch_result(self._h, i, C.byref(r)))
+            n = r.n
+            rowid = np.ctypeslib.as_array(r.rowid, (max(n, 1),))[:n].copy()
+            weight = np.ctypeslib.as_array(r.weight, (max(n, 1),))[:n].copy()
+            out.append(Matches(rowid, weight, int(r.total_found), int(r.status)))
+        return out
+
+    def stats(self) -> dict:
+        s = _lib.BatchStats()
+        check(lib().mrk_batch_stats_get(self._h, C.byref(s)))
+        return {"scan_ms": s.scan_ms, "merge_ms": s.merge_ms, "algo_bytes": int(s.algo_bytes), "n_items": int(s.n_items)}
+
+    def device_results(self):
+        """(keys_ptr, counts_ptr, totals_ptr) of the last finished submit, HBM addresses."""
+        k, c, t = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib().mrk_batch_device_results(self._h, C.byref(k), C.byref(c), C.byref(t)))
+        return k.value, c.value, t.value
+
+    def search(self, seg: Segment, queries: Sequence[Query]) -> List[Matches]:
+        self.submit(seg, queries)
+        self.wait()
+        return self.results()
+
+    def close(self) -> None:
+        if self._h:
+            lib().mrk_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prepare(queries: Sequence[Query]) -> _CQueries:
+    return _CQueries(queries)
+
+
+def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool = True, n_qwords: int = 1,
+        boost: float = 1.0) -> float:
+    return float(lib().mrk_idf(term_docs, total_docs, int(plain), int(normalized), n_qwords, boost))
+
+
+__all__ = ["SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
+           "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE",
+           "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Matches", "Context",
+           "Segment", "Batch", "prepare", "idf", "MrkError"]

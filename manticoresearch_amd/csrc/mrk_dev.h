@@ -1,0 +1,98 @@
+// mrk_dev.h -- plain structs shared by the host planner and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/mrk.h"
+
+namespace mrk {
+
+constexpr int DEVBLK = 128;      // docs per device block (= 1..4 skiplist blocks)
+constexpr int WAVES = 4;         // waves per workgroup
+constexpr int WG = 64 * WAVES;   // threads per workgroup
+constexpr int T0_BLOCKS = WAVES; // driver-term blocks per tile (one per wave)
+constexpr int TILE = T0_BLOCKS * DEVBLK;
+constexpr int SLOTS = 16;        // other-term blocks decoded per pass
+constexpr int KCAP = MRK_MAX_K;  // top-K capacity
+constexpr int CAND = 2 * KCAP;   // candidate buffer (keys) per workgroup
+// worst-case doclist entry: 5 (rowid delta) + 5 (hits) + 5 (fieldmask) + 10 (hitlist offset delta)
+constexpr int MAX_DOC_BYTES = 25;
+constexpr int STAGE_BYTES = ((DEVBLK * MAX_DOC_BYTES + 1 + 15 + 15) / 16) * 16; // 3232
+
+// Device-resident segment (all pointers are HBM)
+struct DevSegment {
+  const uint8_t* spd;
+  const uint8_t* spp;
+  const uint32_t* blk_base; // per device block: SkiplistEntry_t::m_tBaseRowIDPlus1
+  const uint64_t* blk_off;  // absolute .spd offset of the block's first doclist entry
+  const uint64_t* blk_hit;  // SkiplistEntry_t::m_iBaseHitlistPos
+  uint64_t spd_len;
+  uint64_t spp_len;
+  uint32_t rowid_base;
+  uint32_t inline_hits;
+};
+
+struct DevTerm {
+  uint32_t blk_first; // index of the term's first block in blk_*[]
+  uint32_t nblocks;
+  uint32_t docs;
+  uint32_t queried32; // queried-fields mask (low dword)
+  float idf;
+  uint32_t qpos;      // atom position
+  uint64_t spd_end;   // doclist_off + doclist_len
+};
+
+struct DevQuery {
+  uint32_t n_terms; // terms sorted ascending by docs (ExtMultiAnd_T node order); [0] drives
+  uint32_t ranker;
+  uint32_t k;
+  uint32_t n_weights;
+  uint32_t index_weight;
+  uint32_t item_first;
+  uint32_t n_items;
+  uint32_t pad;
+  int32_t weights[32];
+  DevTerm t[MRK_MAX_AND_TERMS];
+};
+
+struct DevItem {
+  uint32_t query;
+  uint32_t blk_begin; // driver-term block range [begin, end)
+  uint32_t blk_end;
+  uint32_t pad;
+};
+
+// candidate key: bigger = better under MatchRelevanceLt_fn (weight desc, rowid asc)
+__host__ __device__ inline uint64_t make_key(int32_t weight, uint32_t rowid) {
+  return ((uint64_t)((uint32_t)weight ^ 0x80000000u) << 32) | (uint32_t)(~rowid);
+}
+__host__ __device__ inline int32_t key_weight(uint64_t k) { return (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); }
+__host__ __device__ inline uint32_t key_rowid(uint64_t k) { return ~(uint32_t)k; }
+
+struct ScanArgs {
+  DevSegment seg;
+  const DevQuery* queries;
+  const DevItem* items;
+  uint64_t* item_cand; // [n_items][KCAP]
+  uint32_t* item_cnt;  // [n_items]
+  uint64_t* q_total;   // [n_queries]
+  uint64_t* q_tau;     // [n_queries] running K-th best key (lower bound), atomicMax
+  uint32_t n_items;
+};
+
+struct MergeArgs {
+  const uint64_t* in_keys;  // lists of <= KCAP keys
+  const uint32_t* in_cnt;
+  const uint32_t* list_first; // per query: first list index   (NULL => strided layout below)
+  const uint32_t* list_n;     // per query: number of lists
+  uint32_t n_lists;           // strided layout: list l of query q is at l*n_queries + q
+  uint32_t n_queries;
+  const uint32_t* k_per_query; // NULL => k
+  uint32_t k;
+  uint64_t* out_keys;          // [n_queries][KCAP], sorted descending
+  uint32_t* out_cnt;
+};
+
+void launch_scan(const ScanArgs& a, void* stream);
+void launch_merge(const MergeArgs& a, void* stream);
+
+} // namespace mrk

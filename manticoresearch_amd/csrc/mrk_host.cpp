@@ -1,0 +1,704 @@
+// mrk_host.cpp -- host side of the C-ABI in include/mrk.h: device context, segment ingest
+// (reference-format bytes -> HBM + device block index), query planning (term order, IDF,
+// work items) and batch submission.  Compiled with hipcc; the kernels live in
+// mrk_kernels.hip.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mrk_dev.h"
+
+using namespace mrk;
+
+// ----------------------------------------------------------------------------------------
+// errors
+// ----------------------------------------------------------------------------------------
+static thread_local char g_err[512];
+
+extern "C" const char* mrk_last_error(void) { return g_err; }
+
+int mrk_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return mrk_fail(MRK_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// ----------------------------------------------------------------------------------------
+// objects
+// ----------------------------------------------------------------------------------------
+struct mrk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t item_bytes = 128 << 10; // target doclist bytes per work item
+};
+
+struct HostTerm {
+  uint64_t doclist_off = 0, doclist_len = 0;
+  uint32_t blk_first = 0, nblocks = 0, docs = 0, hits = 0;
+};
+
+struct mrk_segment {
+  mrk_ctx* ctx = nullptr;
+  DevSegment dev{};
+  std::vector<HostTerm> terms;
+  uint64_t total_docs = 0;
+  uint32_t n_fields = 0;
+  uint64_t device_bytes = 0;
+  void* d_spd = nullptr;
+  void* d_spp = nullptr;
+  void* d_blk_base = nullptr;
+  void* d_blk_off = nullptr;
+  void* d_blk_hit = nullptr;
+};
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return MRK_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 4 + 64;
+    HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return MRK_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+template <typename T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return MRK_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 4 + 64;
+    HIP_TRY(hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault));
+    cap = want;
+    return MRK_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct mrk_batch {
+  mrk_ctx* ctx = nullptr;
+  uint32_t max_queries = 0;
+  uint32_t n_queries = 0; // of the last submit
+  bool in_flight = false;
+  uint32_t rowid_base = 0; // of the segment of the last submit
+  // host (pinned) staging
+  PinBuf<DevQuery> h_queries;
+  PinBuf<DevItem> h_items;
+  PinBuf<uint32_t> h_list_first, h_list_n, h_kq;
+  PinBuf<uint64_t> h_keys;   // [max_queries][KCAP]
+  PinBuf<uint32_t> h_cnt;    // [max_queries]
+  PinBuf<uint64_t> h_total;  // [max_queries]
+  // device
+  DevBuf<DevQuery> d_queries;
+  DevBuf<DevItem> d_items;
+  DevBuf<uint64_t> d_item_cand;
+  DevBuf<uint32_t> d_item_cnt;
+  DevBuf<uint64_t> d_q_total, d_q_tau;
+  DevBuf<uint32_t> d_list_first, d_list_n, d_kq;
+  DevBuf<uint64_t> d_out_keys;
+  DevBuf<uint32_t> d_out_cnt;
+  // decoded results
+  std::vector<uint32_t> rowid;
+  std::vector<int32_t> weight;
+  std::vector<int32_t> status;
+  bool decoded = false;
+  hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_merge1 = nullptr;
+  mrk_batch_stats stats{};
+};
+
+// ----------------------------------------------------------------------------------------
+// ctx
+// ----------------------------------------------------------------------------------------
+extern "C" int mrk_ctx_create(int device, mrk_ctx** out) {
+  if (!out) return mrk_fail(MRK_E_INVAL, "mrk_ctx_create: out is NULL");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return mrk_fail(MRK_E_INVAL, "mrk_ctx_create: device %d of %d", device, n);
+  HIP_TRY(hipSetDevice(device));
+  mrk_ctx* c = new (std::nothrow) mrk_ctx();
+  if (!c) return mrk_fail(MRK_E_NOMEM, "out of memory");
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return mrk_fail(MRK_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return MRK_OK;
+}
+
+extern "C" void mrk_ctx_destroy(mrk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
+  if (!c || !key) return mrk_fail(MRK_E_INVAL, "mrk_ctx_set: NULL argument");
+  if (!strcmp(key, "item_bytes")) {
+    if (value < 4096) return mrk_fail(MRK_E_INVAL, "item_bytes must be >= 4096");
+    c->item_bytes = value;
+    return MRK_OK;
+  }
+  return mrk_fail(MRK_E_INVAL, "mrk_ctx_set: unknown key '%s'", key);
+}
+
+// ----------------------------------------------------------------------------------------
+// segment ingest
+// ----------------------------------------------------------------------------------------
+static inline uint64_t unzip64(const uint8_t*& p, const uint8_t* end, bool& ok) {
+  // SPH_VARINT_DECODE (fileio.cpp:31-45), bounds-checked
+  uint64_t res = 0;
+  for (;;) {
+    if (p >= end) {
+      ok = false;
+      return 0;
+    }
+    uint32_t b = *p++;
+    res = (res << 7) + (b & 0x7f);
+    if (!(b & 0x80)) break;
+  }
+  return res;
+}
+
+extern "C" void mrk_segment_destroy(mrk_segment* s) {
+  if (!s) return;
+  if (s->ctx) (void)hipSetDevice(s->ctx->device);
+  if (s->d_spd) (void)hipFree(s->d_spd);
+  if (s->d_spp) (void)hipFree(s->d_spp);
+  if (s->d_blk_base) (void)hipFree(s->d_blk_base);
+  if (s->d_blk_off) (void)hipFree(s->d_blk_off);
+  if (s->d_blk_hit) (void)hipFree(s->d_blk_hit);
+  delete s;
+}
+
+static int upload(void** dptr, const void* src, size_t bytes, size_t pad, hipStream_t st) {
+  HIP_TRY(hipMalloc(dptr, bytes + pad));
+  HIP_TRY(hipMemsetAsync((char*)*dptr + bytes, 0, pad, st));
+  if (bytes) HIP_TRY(hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, st));
+  return MRK_OK;
+}
+
+extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_segment** out) {
+  if (!ctx || !d || !out) return mrk_fail(MRK_E_INVAL, "mrk_segment_create: NULL argument");
+  if (!d->spd || !d->spd_len) return mrk_fail(MRK_E_INVAL, "mrk_segment_create: empty .spd");
+  const uint32_t sb = d->skiplist_block_size;
+  if (sb == 0 || (sb & (sb - 1)) || sb > (uint32_t)DEVBLK)
+    return mrk_fail(MRK_E_UNSUPPORTED, "skiplist_block_size %u: device path needs a power of two <= %d", sb, DEVBLK);
+  if (d->n_fields > 32) return mrk_fail(MRK_E_UNSUPPORTED, "%u fields: device path covers <= 32", d->n_fields);
+  if (d->hit_format != MRK_HITFMT_INLINE && d->hit_format != MRK_HITFMT_PLAIN)
+    return mrk_fail(MRK_E_INVAL, "bad hit_format %u", d->hit_format);
+  HIP_TRY(hipSetDevice(ctx->device));
+
+  mrk_segment* s = new (std::nothrow) mrk_segment();
+  if (!s) return mrk_fail(MRK_E_NOMEM, "out of memory");
+  s->ctx = ctx;
+  s->total_docs = d->total_docs;
+  s->n_fields = d->n_fields;
+  s->terms.resize(d->n_terms);
+
+  // device block index: every (DEVBLK / skiplist_block_size)-th SkiplistEntry_t, rebuilt the way
+  // DiskIndexQwordSetup_c::Setup does per query (sphinx.cpp:13056-13073) -- once, at load time.
+  // The writer emits ceil(docs/block) snapshots (sphinx.cpp:8447-8453), all of which are used.
+  const uint32_t step = (uint32_t)DEVBLK / sb;
+  std::vector<uint32_t> blk_base;
+  std::vector<uint64_t> blk_off, blk_hit;
+  for (uint32_t t = 0; t < d->n_terms; ++t) {
+    const mrk_dict_entry& e = d->dict[t];
+    HostTerm& h = s->terms[t];
+    h.docs = e.docs;
+    h.hits = e.hits;
+    h.doclist_off = e.doclist_off;
+    h.doclist_len = e.doclist_len;
+    h.blk_first = (uint32_t)blk_base.size();
+    if (!e.docs) continue;
+    if (e.doclist_off == 0 || e.doclist_off + e.doclist_len > d->spd_len) {
+      delete s;
+      return mrk_fail(MRK_E_FORMAT, "term %u: doclist [%llu,+%llu) outside .spd (%llu bytes)", t,
+                      (unsigned long long)e.doclist_off, (unsigned long long)e.doclist_len,
+                      (unsigned long long)d->spd_len);
+    }
+    h.nblocks = (e.docs + DEVBLK - 1) / DEVBLK;
+    uint32_t base = 0;
+    uint64_t off = e.doclist_off, hit = 0;
+    blk_base.push_back(base);
+    blk_off.push_back(off);
+    blk_hit.push_back(hit);
+    if (e.docs > sb) {
+      const uint32_t n_snap = (e.docs + sb - 1) / sb; // entry 0 is implicit
+      if (!d->spe || e.skiplist_off == 0 || e.skiplist_off >= d->spe_len) {
+        delete s;
+        return mrk_fail(MRK_E_FORMAT, "term %u: skiplist offset %llu outside .spe", t, (unsigned long long)e.skiplist_off);
+      }
+      const uint8_t* p = d->spe + e.skiplist_off;
+      const uint8_t* end = d->spe + d->spe_len;
+      bool ok = true;
+      for (uint32_t i = 1; i < n_snap; ++i) {
+        base += sb + (uint32_t)unzip64(p, end, ok);
+        off += 4ull * sb + unzip64(p, end, ok);
+        hit += unzip64(p, end, ok);
+        if (!ok) {
+          delete s;
+          return mrk_fail(MRK_E_FORMAT, "term %u: truncated skiplist", t);
+        }
+        if (i % step == 0) {
+          if (off >= e.doclist_off + e.doclist_len) {
+            delete s;
+            return mrk_fail(MRK_E_FORMAT, "term %u: skiplist entry %u points outside the doclist", t, i);
+          }
+          blk_base.push_back(base);
+          blk_off.push_back(off);
+          blk_hit.push_back(hit);
+        }
+      }
+    }
+    if (blk_base.size() - h.blk_first != h.nblocks) {
+      delete s;
+      return mrk_fail(MRK_E_FORMAT, "term %u: %u docs need %u blocks, skiplist gave %zu", t, e.docs, h.nblocks,
+                      blk_base.size() - h.blk_first);
+    }
+  }
+
+  int rc;
+  const size_t nb = blk_base.size();
+  if ((rc = upload(&s->d_spd, d->spd, d->spd_len, 64, ctx->stream)) != MRK_OK ||
+      (rc = upload(&s->d_spp, d->spp, d->spp ? d->spp_len : 0, 64, ctx->stream)) != MRK_OK ||
+      (rc = upload(&s->d_blk_base, blk_base.data(), nb * 4, 64, ctx->stream)) != MRK_OK ||
+      (rc = upload(&s->d_blk_off, blk_off.data(), nb * 8, 64, ctx->stream)) != MRK_OK ||
+      (rc = upload(&s->d_blk_hit, blk_hit.data(), nb * 8, 64, ctx->stream)) != MRK_OK) {
+    mrk_segment_destroy(s);
+    return rc;
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    mrk_segment_destroy(s);
+    return mrk_fail(MRK_E_HIP, "segment upload: %s", hipGetErrorString(e));
+  }
+  s->device_bytes = d->spd_len + (d->spp ? d->spp_len : 0) + nb * 20 + 5 * 64;
+  s->dev.spd = (const uint8_t*)s->d_spd;
+  s->dev.spp = (const uint8_t*)s->d_spp;
+  s->dev.blk_base = (const uint32_t*)s->d_blk_base;
+  s->dev.blk_off = (const uint64_t*)s->d_blk_off;
+  s->dev.blk_hit = (const uint64_t*)s->d_blk_hit;
+  s->dev.spd_len = d->spd_len;
+  s->dev.spp_len = d->spp ? d->spp_len : 0;
+  s->dev.rowid_base = d->rowid_base;
+  s->dev.inline_hits = d->hit_format == MRK_HITFMT_INLINE ? 1u : 0u;
+  *out = s;
+  return MRK_OK;
+}
+
+extern "C" uint64_t mrk_segment_device_bytes(const mrk_segment* s) { return s ? s->device_bytes : 0; }
+
+// ----------------------------------------------------------------------------------------
+// IDF  (sphCreateRanker, sphinxsearch.cpp:4317-4361) -- host libm logf like the reference
+// ----------------------------------------------------------------------------------------
+extern "C" float mrk_idf(int64_t term_docs, int64_t total_docs, int plain_idf, int normalized, int n_qwords, float boost) {
+  float idf = 0.0f;
+  if (term_docs) {
+    const int64_t total_clamped = std::max(total_docs, term_docs);
+    const float log_total = logf(float(1 + total_clamped));
+    if (!plain_idf)
+      idf = logf(float(total_clamped - term_docs + 1) / float(term_docs)) / (2 * log_total);
+    else
+      idf = logf(float(total_clamped) / float(term_docs)) / (2 * log_total);
+  }
+  if (normalized) idf /= n_qwords;
+  return idf * boost;
+}
+
+// ----------------------------------------------------------------------------------------
+// planner: mrk_query -> DevQuery + work items
+// ----------------------------------------------------------------------------------------
+struct PlanTerm {
+  int32_t term_id;
+  int32_t node;
+  int docs;
+  float boost, idf;
+  uint32_t queried32;
+  int atom_pos;
+  bool weighted_first; // first node of its word in GetQwords order gets the IDF, later dupes get 0
+};
+
+// returns MRK_OK, or MRK_E_UNSUPPORTED / MRK_E_INVAL with the message set
+static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, DevQuery& dq,
+                      std::vector<DevItem>& items, uint32_t qi, uint64_t& algo_bytes) {
+  memset(&dq, 0, sizeof dq);
+  dq.item_first = (uint32_t)items.size();
+  if (!q.nodes || q.n_nodes <= 0 || q.root < 0 || q.root >= q.n_nodes) return mrk_fail(MRK_E_INVAL, "query %u: bad tree", qi);
+  if (q.max_matches <= 0 || q.max_matches > MRK_MAX_K)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: max_matches %d outside 1..%d", qi, q.max_matches, MRK_MAX_K);
+  if (q.cutoff > 0) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: cutoff is order-dependent; not on the device path", qi);
+  const mrk_node& root = q.nodes[q.root];
+
+  std::vector<PlanTerm> terms;
+  auto add_leaf = [&](int32_t ni) -> int {
+    const mrk_node& n = q.nodes[ni];
+    if (n.op != MRK_OP_TERM) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: only AND over plain keywords is on the device path", qi);
+    PlanTerm t{};
+    t.term_id = n.term_id;
+    t.node = ni;
+    t.docs = (n.term_id >= 0 && (uint32_t)n.term_id < seg->terms.size()) ? (int)seg->terms[n.term_id].docs : 0;
+    t.boost = n.boost;
+    t.queried32 = n.field_mask;
+    t.atom_pos = n.atom_pos;
+    terms.push_back(t);
+    return MRK_OK;
+  };
+  bool single_word = false;
+  if (root.op == MRK_OP_TERM) {
+    single_word = true;
+    int rc = add_leaf(q.root);
+    if (rc) return rc;
+  } else if (root.op == MRK_OP_AND) {
+    if (root.n_children < 1 || root.n_children > MRK_MAX_AND_TERMS)
+      return mrk_fail(MRK_E_UNSUPPORTED, "query %u: AND of %d keywords (device path: 1..%d)", qi, root.n_children, MRK_MAX_AND_TERMS);
+    for (int i = 0; i < root.n_children; ++i) {
+      int32_t ci = q.children[root.first_child + i];
+      if (ci < 0 || ci >= q.n_nodes) return mrk_fail(MRK_E_INVAL, "query %u: child index out of range", qi);
+      int rc = add_leaf(ci);
+      if (rc) return rc;
+    }
+  } else
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, root.op);
+
+  uint32_t ranker;
+  switch (q.ranker) {
+    case MRK_RANK_NONE: ranker = MRK_RANK_NONE; break;
+    case MRK_RANK_BM25: ranker = MRK_RANK_BM25; break;
+    case MRK_RANK_PROXIMITY_BM25:
+      // a single keyword is ranked by ExtRanker_WeightSum_c<BM25> (sphinxsearch.cpp:4195-4196)
+      if (!single_word) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity_bm25 over several keywords needs the hit path", qi);
+      ranker = MRK_RANK_BM25;
+      break;
+    default: return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker %d not on the device path", qi, q.ranker);
+  }
+
+  // ExtMultiAnd_T sorts its nodes by ascending docs with sphSort (searchnode.cpp:2791); for
+  // query-sized arrays that is the insertion sort of sphinxstd.h:853-869, which moves an element
+  // left past every element that is not less than it: equal keys end in reverse arrival order.
+  const int n = (int)terms.size();
+  std::vector<int> ord(n);
+  for (int i = 0; i < n; ++i) ord[i] = i;
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0; --j) {
+      if (terms[ord[j - 1]].docs < terms[ord[j]].docs) break;
+      std::swap(ord[j], ord[j - 1]);
+    }
+
+  // distinct words in GetQwords order (= sorted node order, searchnode.cpp:3276-3286)
+  std::vector<int> words;
+  for (int i = 0; i < n; ++i) {
+    PlanTerm& t = terms[ord[i]];
+    bool seen = false;
+    for (int w : words) seen |= terms[w].term_id == t.term_id;
+    t.weighted_first = !seen;
+    if (!seen) words.push_back(ord[i]);
+  }
+  const int64_t total_docs = q.total_docs_override > 0 ? q.total_docs_override : (int64_t)seg->total_docs;
+  for (int w : words) {
+    PlanTerm& t = terms[w];
+    int64_t term_docs = t.docs;
+    if (q.local_docs && q.local_docs[t.node] >= 0) term_docs = q.local_docs[t.node];
+    t.idf = mrk_idf(term_docs, total_docs, q.plain_idf, q.normalized_tfidf, (int)words.size(), t.boost);
+  }
+
+  dq.n_terms = (uint32_t)n;
+  dq.ranker = ranker;
+  dq.k = (uint32_t)q.max_matches;
+  dq.n_weights = seg->n_fields;
+  dq.index_weight = (uint32_t)(q.index_weight ? q.index_weight : 1);
+  for (uint32_t f = 0; f < 32; ++f)
+    dq.weights[f] = (q.field_weights && (int)f < q.n_weights) ? q.field_weights[f] : 1; // BindWeights default
+  uint64_t bytes = 0;
+  bool empty = false;
+  for (int i = 0; i < n; ++i) {
+    const PlanTerm& t = terms[ord[i]];
+    DevTerm& dt = dq.t[i];
+    if (!t.docs) {
+      empty = true; // a keyword without postings: AND matches nothing (searchnode.cpp:2922)
+      continue;
+    }
+    const HostTerm& h = seg->terms[t.term_id];
+    dt.blk_first = h.blk_first;
+    dt.nblocks = h.nblocks;
+    dt.docs = h.docs;
+    dt.queried32 = t.queried32;
+    dt.idf = t.weighted_first ? t.idf : 0.0f;
+    dt.qpos = (uint32_t)t.atom_pos;
+    dt.spd_end = h.doclist_off + h.doclist_len;
+    bytes += h.doclist_len;
+  }
+  if (empty) {
+    dq.n_items = 0;
+    return MRK_OK;
+  }
+  algo_bytes += bytes;
+
+  // work items: contiguous ranges of driver-term blocks, ~item_bytes of doclist each
+  const uint32_t nb0 = dq.t[0].nblocks;
+  const double per_block = (double)bytes / (double)nb0;
+  uint64_t bpi = (uint64_t)((double)item_bytes / per_block);
+  bpi = std::max<uint64_t>(T0_BLOCKS, (bpi / T0_BLOCKS) * T0_BLOCKS);
+  for (uint64_t b = 0; b < nb0; b += bpi) {
+    DevItem it{};
+    it.query = qi;
+    it.blk_begin = (uint32_t)b;
+    it.blk_end = (uint32_t)std::min<uint64_t>(nb0, b + bpi);
+    items.push_back(it);
+  }
+  dq.n_items = (uint32_t)items.size() - dq.item_first;
+  return MRK_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// batch
+// ----------------------------------------------------------------------------------------
+extern "C" void mrk_batch_destroy(mrk_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  if (b->in_flight) (void)hipStreamSynchronize(b->ctx->stream);
+  b->h_queries.release();
+  b->h_items.release();
+  b->h_list_first.release();
+  b->h_list_n.release();
+  b->h_kq.release();
+  b->h_keys.release();
+  b->h_cnt.release();
+  b->h_total.release();
+  b->d_queries.release();
+  b->d_items.release();
+  b->d_item_cand.release();
+  b->d_item_cnt.release();
+  b->d_q_total.release();
+  b->d_q_tau.release();
+  b->d_list_first.release();
+  b->d_list_n.release();
+  b->d_kq.release();
+  b->d_out_keys.release();
+  b->d_out_cnt.release();
+  if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
+  if (b->ev_scan1) (void)hipEventDestroy(b->ev_scan1);
+  if (b->ev_merge1) (void)hipEventDestroy(b->ev_merge1);
+  delete b;
+}
+
+extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** out) {
+  if (!ctx || !out || !max_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_create: bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  mrk_batch* b = new (std::nothrow) mrk_batch();
+  if (!b) return mrk_fail(MRK_E_NOMEM, "out of memory");
+  b->ctx = ctx;
+  b->max_queries = max_queries;
+  int rc = MRK_OK;
+  const size_t nq = max_queries;
+  if ((rc = b->h_queries.reserve(nq)) || (rc = b->h_list_first.reserve(nq)) || (rc = b->h_list_n.reserve(nq)) ||
+      (rc = b->h_kq.reserve(nq)) || (rc = b->h_keys.reserve(nq * KCAP)) || (rc = b->h_cnt.reserve(nq)) ||
+      (rc = b->h_total.reserve(nq)) || (rc = b->d_queries.reserve(nq)) || (rc = b->d_q_total.reserve(nq)) ||
+      (rc = b->d_q_tau.reserve(nq)) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
+      (rc = b->d_kq.reserve(nq)) || (rc = b->d_out_keys.reserve(nq * KCAP)) || (rc = b->d_out_cnt.reserve(nq))) {
+    mrk_batch_destroy(b);
+    return rc;
+  }
+  hipError_t e1 = hipEventCreate(&b->ev_scan0), e2 = hipEventCreate(&b->ev_scan1), e3 = hipEventCreate(&b->ev_merge1);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    mrk_batch_destroy(b);
+    return mrk_fail(MRK_E_HIP, "hipEventCreate failed");
+  }
+  b->rowid.resize(nq * KCAP);
+  b->weight.resize(nq * KCAP);
+  b->status.assign(nq, MRK_OK);
+  *out = b;
+  return MRK_OK;
+}
+
+extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n) {
+  if (!b || !seg || (!queries && n)) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: NULL argument");
+  if (n > b->max_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: %u queries > batch capacity %u", n, b->max_queries);
+  if (seg->ctx != b->ctx) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: segment and batch belong to different contexts");
+  HIP_TRY(hipSetDevice(b->ctx->device));
+  hipStream_t st = b->ctx->stream;
+  if (b->in_flight) HIP_TRY(hipStreamSynchronize(st)); // pinned staging is about to be rewritten
+  b->in_flight = false;
+  b->decoded = false;
+  b->n_queries = n;
+  b->rowid_base = seg->dev.rowid_base;
+  b->stats = mrk_batch_stats{};
+  if (!n) return MRK_OK;
+
+  // ---- plan
+  std::vector<DevItem> items;
+  items.reserve(n * 4);
+  uint64_t algo_bytes = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    int rc = plan_query(seg, queries[i], b->ctx->item_bytes, b->h_queries.p[i], items, i, algo_bytes);
+    b->status[i] = rc;
+    if (rc == MRK_E_INVAL) return rc;
+    if (rc != MRK_OK) { // unsupported: reported per query, runs no device work
+      items.resize(b->h_queries.p[i].item_first);
+      b->h_queries.p[i].n_items = 0;
+    }
+    b->h_list_first.p[i] = b->h_queries.p[i].item_first;
+    b->h_list_n.p[i] = b->h_queries.p[i].n_items;
+    b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;
+  }
+  const size_t n_items = items.size();
+  b->stats.algo_bytes = algo_bytes;
+  b->stats.n_items = n_items;
+  int rc;
+  if ((rc = b->h_items.reserve(n_items + 1)) || (rc = b->d_items.reserve(n_items + 1)) ||
+      (rc = b->d_item_cand.reserve((n_items + 1) * KCAP)) || (rc = b->d_item_cnt.reserve(n_items + 1)))
+    return rc;
+  if (n_items) memcpy(b->h_items.p, items.data(), n_items * sizeof(DevItem));
+
+  // ---- copy descriptors, launch
+  HIP_TRY(hipMemcpyAsync(b->d_queries.p, b->h_queries.p, n * sizeof(DevQuery), hipMemcpyHostToDevice, st));
+  if (n_items) HIP_TRY(hipMemcpyAsync(b->d_items.p, b->h_items.p, n_items * sizeof(DevItem), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(b->d_list_first.p, b->h_list_first.p, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(b->d_list_n.p, b->h_list_n.p, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(b->d_kq.p, b->h_kq.p, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(b->d_q_total.p, 0, n * 8, st));
+  HIP_TRY(hipMemsetAsync(b->d_q_tau.p, 0, n * 8, st));
+
+  ScanArgs sa{};
+  sa.seg = seg->dev;
+  sa.queries = b->d_queries.p;
+  sa.items = b->d_items.p;
+  sa.item_cand = b->d_item_cand.p;
+  sa.item_cnt = b->d_item_cnt.p;
+  sa.q_total = b->d_q_total.p;
+  sa.q_tau = b->d_q_tau.p;
+  sa.n_items = (uint32_t)n_items;
+  HIP_TRY(hipEventRecord(b->ev_scan0, st));
+  launch_scan(sa, st);
+  HIP_TRY(hipEventRecord(b->ev_scan1, st));
+
+  MergeArgs ma{};
+  ma.in_keys = b->d_item_cand.p;
+  ma.in_cnt = b->d_item_cnt.p;
+  ma.list_first = b->d_list_first.p;
+  ma.list_n = b->d_list_n.p;
+  ma.n_lists = 0;
+  ma.n_queries = n;
+  ma.k_per_query = b->d_kq.p;
+  ma.k = KCAP;
+  ma.out_keys = b->d_out_keys.p;
+  ma.out_cnt = b->d_out_cnt.p;
+  launch_merge(ma, st);
+  HIP_TRY(hipEventRecord(b->ev_merge1, st));
+  HIP_TRY(hipGetLastError());
+
+  // ---- results to pinned host memory
+  HIP_TRY(hipMemcpyAsync(b->h_cnt.p, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_total.p, b->d_q_total.p, n * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_keys.p, b->d_out_keys.p, (size_t)n * KCAP * 8, hipMemcpyDeviceToHost, st));
+  b->in_flight = true;
+  return MRK_OK;
+}
+
+extern "C" int mrk_batch_wait(mrk_batch* b) {
+  if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_wait: NULL batch");
+  if (!b->in_flight) return MRK_OK;
+  HIP_TRY(hipSetDevice(b->ctx->device));
+  HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  b->in_flight = false;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, b->ev_scan0, b->ev_scan1) == hipSuccess) b->stats.scan_ms = ms;
+  if (hipEventElapsedTime(&ms, b->ev_scan1, b->ev_merge1) == hipSuccess) b->stats.merge_ms = ms;
+  return MRK_OK;
+}
+
+extern "C" int mrk_batch_result(mrk_batch* b, uint32_t q, mrk_result* out) {
+  if (!b || !out) return mrk_fail(MRK_E_INVAL, "mrk_batch_result: NULL argument");
+  if (b->in_flight) return mrk_fail(MRK_E_INVAL, "mrk_batch_result: call mrk_batch_wait first");
+  if (q >= b->n_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_result: query %u of %u", q, b->n_queries);
+  if (!b->decoded) {
+    for (uint32_t i = 0; i < b->n_queries; ++i) {
+      const uint32_t cnt = b->status[i] == MRK_OK ? std::min<uint32_t>(b->h_cnt.p[i], KCAP) : 0;
+      const uint64_t* keys = b->h_keys.p + (size_t)i * KCAP;
+      const uint32_t rb = b->rowid_base; // report segment-local rowids, as the reference's sorter holds them
+      for (uint32_t j = 0; j < cnt; ++j) {
+        b->rowid[(size_t)i * KCAP + j] = key_rowid(keys[j]) - rb;
+        b->weight[(size_t)i * KCAP + j] = key_weight(keys[j]);
+      }
+    }
+    b->decoded = true;
+  }
+  out->status = b->status[q];
+  out->n = b->status[q] == MRK_OK ? (int32_t)std::min<uint32_t>(b->h_cnt.p[q], KCAP) : 0;
+  out->total_found = b->status[q] == MRK_OK ? (int64_t)b->h_total.p[q] : 0;
+  out->rowid = b->rowid.data() + (size_t)q * KCAP;
+  out->weight = b->weight.data() + (size_t)q * KCAP;
+  return MRK_OK;
+}
+
+extern "C" int mrk_batch_stats_get(mrk_batch* b, mrk_batch_stats* out) {
+  if (!b || !out) return mrk_fail(MRK_E_INVAL, "mrk_batch_stats_get: NULL argument");
+  *out = b->stats;
+  return MRK_OK;
+}
+
+extern "C" int mrk_batch_device_results(mrk_batch* b, const uint64_t** keys, const uint32_t** counts, const uint64_t** totals) {
+  if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_device_results: NULL batch");
+  if (b->in_flight) return mrk_fail(MRK_E_INVAL, "mrk_batch_device_results: call mrk_batch_wait first");
+  if (keys) *keys = b->d_out_keys.p;
+  if (counts) *counts = b->d_out_cnt.p;
+  if (totals) *totals = b->d_q_total.p;
+  return MRK_OK;
+}
+
+extern "C" int mrk_topk_merge(mrk_ctx* ctx, const uint64_t* in_keys, const uint32_t* in_counts, uint32_t n_lists,
+                              uint32_t n_queries, uint32_t k, uint64_t* out_keys, uint32_t* out_counts) {
+  if (!ctx || !in_keys || !in_counts || !out_keys || !out_counts) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge: NULL argument");
+  if (k == 0 || k > MRK_MAX_K) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge: k %u outside 1..%d", k, MRK_MAX_K);
+  HIP_TRY(hipSetDevice(ctx->device));
+  MergeArgs ma{};
+  ma.in_keys = in_keys;
+  ma.in_cnt = in_counts;
+  ma.list_first = nullptr;
+  ma.list_n = nullptr;
+  ma.n_lists = n_lists;
+  ma.n_queries = n_queries;
+  ma.k_per_query = nullptr;
+  ma.k = k;
+  ma.out_keys = out_keys;
+  ma.out_cnt = out_counts;
+  launch_merge(ma, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MRK_OK;
+}

@@ -1,0 +1,271 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle on the same index bytes.
+
+Bit-exact bar: identical rowid lists (order included), identical int weights, identical
+total_found.  Run on the GPU box: python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+from helpers import make_hits, mini_index, synth_postings
+from test_oracle_golden import T019, T019_IDS, T037, T322
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import manticoresearch_amd as m
+
+    ctx = m.Context(0)
+    batch = m.Batch(ctx, 256)
+    yield m, ctx, batch
+    batch.close()
+    ctx.close()
+
+
+def orc_index_of(orc, hi):
+    return orc.Index(hi.spd, hi.spp, hi.spe, hi.dict.view(orc.DICT_DTYPE), hi.total_docs, hi.skiplist_block_size,
+                     hi.hit_format, hi.n_fields)
+
+
+def to_orc(orc, q):
+    def conv(n):
+        if n.word is not None:
+            return orc.term(n.word.term_id, n.word.atom_pos, n.field_mask, n.word.boost)
+        return orc.op(n.op, *[conv(c) for c in n.children], field_mask=n.field_mask)
+
+    return orc.FlatQuery(conv(q.root), ranker=q.ranker, max_matches=q.max_matches, field_weights=q.field_weights,
+                         index_weight=q.index_weight, plain_idf=q.plain_idf, normalized_tfidf=q.normalized_tfidf,
+                         total_docs_override=q.total_docs, local_docs=q.local_docs)
+
+
+def check_batch(orc, dev, hi, queries, rowid_base=0):
+    m, ctx, batch = dev
+    seg = m.Segment(ctx, hi, rowid_base=rowid_base)
+    oi = orc_index_of(orc, hi)
+    try:
+        for i in range(0, len(queries), batch.max_queries):
+            chunk = queries[i:i + batch.max_queries]
+            got = batch.search(seg, chunk)
+            for q, g in zip(chunk, got):
+                want = to_orc(orc, q).run(oi)
+                assert g.status == 0
+                assert g.total_found == want.total_found, (g.total_found, want.total_found)
+                assert len(g.rowid) == len(want.rowid)
+                assert (g.rowid == want.rowid).all(), (g.rowid[:10], want.rowid[:10])
+                assert (g.weight == want.weight).all(), (g.weight[:10], want.weight[:10])
+    finally:
+        seg.close()
+
+
+def kw(m, t, pos, mask=0xFFFFFFFF, boost=1.0):
+    return m.XQNode.keyword(t, pos, mask, boost)
+
+
+# ------------------------------------------------------------------ reference corpora
+def test_reference_corpora_single_and_and(orc, dev):
+    m = dev[0]
+    for docs, mwl in ((T019, 2), (T037, 1), (T322, 1)):
+        W, R, H, v = make_hits(docs, mwl)
+        nf = max(len(d) for d in docs)
+        hi = m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(docs), n_fields=nf)
+        qs = []
+        for t in range(len(v)):
+            for rk in (m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_PROXIMITY_BM25):
+                qs.append(m.Query(kw(m, t, 1), ranker=rk))
+                qs.append(m.Query(kw(m, t, 1, mask=0b01), ranker=rk))
+        ids = list(range(len(v)))
+        for a in ids[:12]:
+            for b in ids[:12]:
+                if a != b:
+                    qs.append(m.Query(m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), ranker=m.SPH_RANK_BM25))
+        check_batch(orc, dev, hi, qs)
+
+
+def test_golden_weights_on_device(dev):
+    """Reference goldens straight from the device path (no oracle in the loop)."""
+    m, ctx, batch = dev
+    W, R, H, v = make_hits(T037)
+    seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(T037)))
+    r = batch.search(seg, [m.Query(kw(m, v["test"], 1, mask=0b01), ranker=m.SPH_RANK_BM25)])[0]
+    assert list(r.rowid) == [1] and list(r.weight) == [1800]  # test_037: "@title test" bm25 -> 2:1800
+    seg.close()
+    W, R, H, v = make_hits(T019, 2)
+    seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(T019)))
+    r = batch.search(seg, [m.Query(kw(m, v["77"], 1))])[0]
+    assert [T019_IDS[i] for i in r.rowid] == [777] and list(r.weight) == [1803]  # test_019: "77" -> 777:1803
+    seg.close()
+    docs = [["If I were a cat...", "We are the greatest cat"]]
+    W, R, H, v = make_hits(docs)
+    seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=1))
+    r = batch.search(seg, [m.Query(kw(m, v["cat"], 1, mask=0b01))])[0]
+    assert list(r.weight) == [1500]  # gtests_rtstuff.cpp RTN.WeightBoundary
+    seg.close()
+
+
+# ------------------------------------------------------------------ random corpora
+PROBS = [0.5, 0.3, 0.12, 0.05, 0.02, 0.006, 0.002, 0.0007, 0.9, 0.3, 0.0001]
+
+
+@pytest.mark.parametrize("block,fmt", [(128, 1), (32, 1), (128, 0), (64, 1)])
+def test_random_corpus_and_queries(orc, dev, block, fmt):
+    m = dev[0]
+    rng = np.random.default_rng(1234 + block + fmt)
+    n_docs = 60000
+    W, R, H = synth_postings(rng, n_docs, PROBS, n_fields=3, end_markers=True)
+    nt = len(PROBS) + 1  # last term has no postings
+    hi = m.index_from_hits(W, R, H, n_terms=nt, total_docs=n_docs, skiplist_block_size=block, hit_format=fmt, n_fields=3)
+    qs = []
+    for t in range(nt):
+        qs.append(m.Query(kw(m, t, 1), ranker=m.SPH_RANK_BM25))
+        qs.append(m.Query(kw(m, t, 1, mask=0b010), ranker=m.SPH_RANK_BM25, max_matches=10))
+    for _ in range(150):
+        k = int(rng.integers(2, 5))
+        ts = rng.choice(nt, size=k, replace=False)
+        masks = [0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)) for _ in ts]
+        root = m.XQNode.AND(*[kw(m, int(t), i + 1, mk) for i, (t, mk) in enumerate(zip(ts, masks))])
+        qs.append(m.Query(root, ranker=int(rng.choice([m.SPH_RANK_BM25, m.SPH_RANK_NONE])),
+                          max_matches=int(rng.choice([1, 7, 100, 1000, 1024])),
+                          field_weights=[int(x) for x in rng.integers(-3, 12, 3)] if rng.random() < 0.5 else None,
+                          index_weight=int(rng.choice([1, 1, 3])), plain_idf=bool(rng.random() < 0.2),
+                          normalized_tfidf=bool(rng.random() < 0.8)))
+    # 8-way AND, a missing keyword, equal doc counts (terms 1 and 9 have the same probability)
+    qs.append(m.Query(m.XQNode.AND(*[kw(m, t, t + 1) for t in (8, 0, 1, 9, 2, 3, 4, 5)]), ranker=m.SPH_RANK_BM25))
+    qs.append(m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, nt - 1, 2)), ranker=m.SPH_RANK_BM25))
+    qs.append(m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, -1, 2)), ranker=m.SPH_RANK_BM25))
+    qs.append(m.Query(m.XQNode.AND(kw(m, 1, 1), kw(m, 9, 2), kw(m, 0, 3)), ranker=m.SPH_RANK_BM25))
+    # local_df overrides (global IDF inputs for sharded search)
+    qs.append(m.Query(m.XQNode.AND(kw(m, 2, 1), kw(m, 3, 2)), ranker=m.SPH_RANK_BM25, total_docs=10 * n_docs,
+                      local_docs={2: 70000, 3: 31000}))
+    check_batch(orc, dev, hi, qs)
+
+
+def test_tiny_and_ragged_lists(orc, dev):
+    """docs counts around the block edges: 1, block-1, block, block+1, 2*block, 2*block+1 ..."""
+    m = dev[0]
+    sizes = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 1000]
+    rng = np.random.default_rng(5)
+    n_docs = 5000
+    W, R, H = [], [], []
+    for t, n in enumerate(sizes):
+        rows = np.sort(rng.choice(n_docs, size=n, replace=False)).astype(np.uint32)
+        for r in rows:
+            tf = int(rng.integers(1, 4))
+            hp = np.unique(((rng.integers(0, 2, tf).astype(np.uint32)) << 24) | rng.integers(1, 50, tf).astype(np.uint32))
+            W += [t + 1] * len(hp)
+            R += [r] * len(hp)
+            H += list(hp)
+    for block in (32, 128):
+        hi = m.index_from_hits(np.array(W, np.uint64), np.array(R, np.uint32), np.array(H, np.uint32),
+                               n_terms=len(sizes), total_docs=n_docs, skiplist_block_size=block)
+        qs = [m.Query(kw(m, t, 1), ranker=m.SPH_RANK_BM25) for t in range(len(sizes))]
+        for a in range(len(sizes)):
+            for b in (len(sizes) - 1, len(sizes) - 2, 9):
+                if a != b:
+                    qs.append(m.Query(m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), ranker=m.SPH_RANK_BM25))
+        check_batch(orc, dev, hi, qs)
+
+
+def test_wide_rowid_gaps_and_first_rowid_zero(orc, dev):
+    """5-byte rowid deltas (gaps >= 2^28), rowid 0 present, rowids near 2^32."""
+    m = dev[0]
+    rows_a = np.array([0, 1, 5, 1 << 28, (1 << 28) + 3, (1 << 31) + 7, 0xFFFFFFF0, 0xFFFFFFFE], np.uint32)
+    rows_b = np.array([0, 5, 9, (1 << 28) + 3, (1 << 31) + 7, 0xFFFFFFFE], np.uint32)
+    W = np.concatenate([np.full(len(rows_a), 1), np.full(len(rows_b), 2)]).astype(np.uint64)
+    R = np.concatenate([rows_a, rows_b])
+    H = np.full(len(R), (1 << 24) | 3, np.uint32)
+    hi = m.index_from_hits(W, R, H, n_terms=2, total_docs=0xFFFFFFFF)
+    qs = [m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25), m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_BM25)]
+    check_batch(orc, dev, hi, qs)
+
+
+def test_long_entries_slow_path(orc, dev):
+    """Entries longer than the 8-byte fast window: huge tf, full 32-bit field masks, big hitlist offsets."""
+    m = dev[0]
+    rng = np.random.default_rng(11)
+    W, R, H = [], [], []
+    for r in range(0, 2000, 3):
+        fields = rng.choice(32, size=int(rng.integers(1, 20)), replace=False)
+        hp = np.unique(np.concatenate([(np.uint32(f) << 24) | rng.integers(1, 300, int(rng.integers(1, 60))).astype(np.uint32)
+                                       for f in fields]))
+        W += [1] * len(hp)
+        R += [r] * len(hp)
+        H += list(hp)
+    for r in range(0, 2000, 2):
+        W.append(2), R.append(r), H.append((31 << 24) | 1000)
+    hi = m.index_from_hits(np.array(W, np.uint64), np.array(R, np.uint32), np.array(H, np.uint32), n_terms=2,
+                           total_docs=2000, n_fields=32)
+    fw = [int(x) for x in rng.integers(-5, 50, 32)]
+    qs = [m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25, field_weights=fw),
+          m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_BM25, field_weights=fw),
+          m.Query(m.XQNode.AND(kw(m, 0, 1, 1 << 31), kw(m, 1, 2)), ranker=m.SPH_RANK_BM25)]
+    check_batch(orc, dev, hi, qs)
+
+
+def test_unsupported_shapes_fail_loudly(dev):
+    m, ctx, batch = dev
+    hi = m.synth_index(1000, [0.5, 0.5], seed=1)
+    seg = m.Segment(ctx, hi)
+    q_or = m.Query(m.XQNode(m.SPH_QUERY_OR, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
+    q_big = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25, max_matches=5000)
+    q_ok = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25)
+    r = batch.search(seg, [q_or, q_ok, q_big])
+    assert r[0].status == -2 and r[2].status == -2 and r[1].status == 0 and r[1].total_found > 0
+    seg.close()
+
+
+def test_synth_medium_and_merge_across_shards(orc, dev):
+    """Bigger lists (many work items per query) and the shard merge entry point."""
+    import ctypes as C
+    m, ctx, batch = dev
+    from manticoresearch_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+
+    def dmalloc(n):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(n)) == 0
+        return p
+
+    probs = [0.3, 0.2, 0.05, 0.01, 0.001]
+    n_docs = 400000
+    ctx.set("item_bytes", 16 << 10)  # many items per query
+    his = [m.synth_index(n_docs, probs, seed=42, shard=s) for s in range(2)]
+    qs = [m.Query(m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), ranker=m.SPH_RANK_BM25, total_docs=2 * n_docs,
+                  local_docs={t: int(his[0].dict[t]["docs"]) + int(his[1].dict[t]["docs"]) for t in (a, b)})
+          for a in range(5) for b in range(5) if a != b]
+    nq = len(qs)
+    for s in range(2):
+        check_batch(orc, dev, his[s], qs, rowid_base=s * n_docs)
+    # merged result == oracle top-K of the union with global rowids
+    K = 1000
+    in_keys, in_cnt = dmalloc(2 * nq * 1024 * 8), dmalloc(2 * nq * 4)
+    out_keys, out_cnt = dmalloc(nq * 1024 * 8), dmalloc(nq * 4)
+    want = []
+    for s in range(2):
+        seg = m.Segment(ctx, his[s], rowid_base=s * n_docs)
+        batch.search(seg, qs)
+        kp, cp, _ = batch.device_results()
+        assert hip.hipMemcpy(C.c_void_p(in_keys.value + s * nq * 1024 * 8), C.c_void_p(kp), C.c_size_t(nq * 1024 * 8), 3) == 0
+        assert hip.hipMemcpy(C.c_void_p(in_cnt.value + s * nq * 4), C.c_void_p(cp), C.c_size_t(nq * 4), 3) == 0
+        seg.close()
+        oi = orc_index_of(orc, his[s])
+        want.append([to_orc(orc, q).run(oi) for q in qs])
+    _lib.check(_lib.lib().mrk_topk_merge(ctx._h, in_keys, in_cnt, 2, nq, K, out_keys, out_cnt))
+    ok = np.zeros((nq, 1024), np.uint64)
+    oc = np.zeros(nq, np.uint32)
+    assert hip.hipMemcpy(C.c_void_p(ok.ctypes.data), out_keys, C.c_size_t(ok.nbytes), 2) == 0
+    assert hip.hipMemcpy(C.c_void_p(oc.ctypes.data), out_cnt, C.c_size_t(oc.nbytes), 2) == 0
+    for p in (in_keys, in_cnt, out_keys, out_cnt):
+        hip.hipFree(p)
+    for qi in range(nq):
+        allm = []
+        for s in range(2):
+            w = want[s][qi]
+            allm += [(-int(wt), int(r) + s * n_docs) for r, wt in zip(w.rowid, w.weight)]
+        allm.sort()  # weight desc, global docid asc
+        allm = allm[:K]
+        ks = [int(k) for k in ok[qi][:oc[qi]]]
+        gw = [((k >> 32) ^ 0x80000000) - (1 << 32) if ((k >> 32) ^ 0x80000000) >= (1 << 31) else ((k >> 32) ^ 0x80000000) for k in ks]
+        gr = [(~k) & 0xFFFFFFFF for k in ks]
+        assert [(-w, r) for w, r in zip(gw, gr)] == allm
+    ctx.set("item_bytes", 128 << 10)

@@ -1,0 +1,76 @@
+"""CPU tests: the product's format writer / synthetic generator (libmrk.so host code)
+against the oracle's CSphHitBuilder restatement and reader. No GPU calls."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import make_hits, synth_postings
+from test_oracle_golden import T019, T322
+
+
+def test_lib_exports_every_declared_symbol():
+    import re, os
+    from manticoresearch_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(os.path.dirname(_lib._HERE), "include", "mrk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mrk_[a-z_0-9]+)\s*\(", hdr))
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for n in declared:
+        assert hasattr(L, n)
+
+
+@pytest.mark.parametrize("block", [32, 128])
+@pytest.mark.parametrize("inline", [1, 0])
+def test_writer_bytes_match_oracle_writer(orc, block, inline):
+    import manticoresearch_amd as m
+    rng = np.random.default_rng(7)
+    W, R, H = synth_postings(rng, 3000, [0.5, 0.2, 0.05, 0.01, 0.9], end_markers=True)
+    a = orc.build_index(W, R, H, total_docs=3000, skiplist_block_size=block, inline_hits=inline, n_terms=5)
+    b = m.index_from_hits(W, R, H, n_terms=5, total_docs=3000, skiplist_block_size=block, hit_format=inline)
+    assert bytes(a.spd) == bytes(b.spd)
+    assert bytes(a.spp) == bytes(b.spp)
+    assert bytes(a.spe) == bytes(b.spe)
+    for f in ("doclist_off", "doclist_len", "docs", "hits"):
+        assert (a.dict[f] == b.dict[f]).all(), f
+    big = a.dict["docs"] > block
+    assert (a.dict["skiplist_off"][big] == b.dict["skiplist_off"][big]).all()
+
+
+@pytest.mark.parametrize("docs", [T019, T322])
+def test_writer_bytes_match_on_reference_corpora(orc, docs):
+    import manticoresearch_amd as m
+    W, R, H, vocab = make_hits(docs, min_word_len=2)
+    a = orc.build_index(W, R, H, total_docs=len(docs), n_terms=len(vocab))
+    b = m.index_from_hits(W, R, H, n_terms=len(vocab), total_docs=len(docs))
+    assert bytes(a.spd) == bytes(b.spd) and bytes(a.spp) == bytes(b.spp) and bytes(a.spe) == bytes(b.spe)
+
+
+def test_synth_index_decodes_with_oracle_reader(orc):
+    import manticoresearch_amd as m
+    probs = [0.3, 0.05, 0.002, 0.6]
+    hi = m.synth_index(20000, probs, seed=123, skiplist_block_size=32, end_markers=True, n_threads=2)
+    oi = orc.Index(hi.spd, hi.spp, hi.spe, hi.dict.view(orc.DICT_DTYPE), hi.total_docs, 32, 1, 2)
+    for t, p in enumerate(probs):
+        rowid, fields, hits, hp = oi.decode_doclist(t)
+        n = len(rowid)
+        assert n == hi.dict[t]["docs"]
+        assert abs(n - p * 20000) < 6 * np.sqrt(p * 20000) + 5
+        assert (np.diff(rowid.astype(np.int64)) > 0).all() and rowid[-1] < 20000
+        assert hits.sum() == hi.dict[t]["hits"]
+        for i in range(0, n, max(1, n // 50)):
+            hl = oi.decode_hits(hp[i])
+            assert len(hl) == hits[i] and hl == sorted(hl)
+            mask = 0
+            for h in hl:
+                mask |= 1 << (h >> 24)
+            assert mask == fields[i]
+        b, o, hb = oi.decode_skiplist(t)
+        if n > 32:
+            assert len(b) == n // 32 and b[0] == 0
+            assert (rowid[32::32][: len(b) - 1] >= b[1:]).all()
+    # determinism
+    hi2 = m.synth_index(20000, probs, seed=123, skiplist_block_size=32, end_markers=True, n_threads=1)
+    assert bytes(hi.spd) == bytes(hi2.spd) and bytes(hi.spp) == bytes(hi2.spp)
