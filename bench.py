@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the match -> rank -> top-K path on MI355X.
+
+Workload (BASELINE.json metric): 2-term AND, SPH_RANK_BM25, top-1000 over a synthetic Zipf
+corpus (default 100 M docs), queries stratified into common x common / selective x common /
+selective x selective thirds.  A "step" = one pass over the whole query set: one batch
+(kernel launch) per stratum.  Index segments are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--docs D] [--queries Q]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the corpus is split into N
+rowid-range shards (strong scaling: total docs fixed), every rank scans its shard, partial
+top-K lists are all-gathered over RCCL and merged on device, total_found is all-reduced.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+VOCAB = 1 << 20
+AVG_TERMS_PER_DOC = 64.0
+COMMON = (0.03, 0.3)       # document-probability band of "common" terms
+SELECTIVE = (1e-4, 3e-3)   # ... of "selective" terms
+QUERY_SEED = 0x5EED0002
+CORPUS_SEED = 0x5EED0001
+
+
+def zipf_c() -> float:
+    """C such that sum_r min(0.5, C/r) over r = 1..VOCAB equals AVG_TERMS_PER_DOC (s = 1)."""
+    lo, hi = 0.1, 50.0
+    r = np.arange(1, VOCAB + 1, dtype=np.float64)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if np.minimum(0.5, mid / r).sum() < AVG_TERMS_PER_DOC:
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
+def rank_band(c: float, band) -> tuple:
+    """Zipf ranks whose document probability C/r lies inside the band."""
+    return int(math.ceil(c / band[1])), int(math.floor(c / band[0]))
+
+
+def make_queries(c: float, q_per_stratum: int):
+    """-> (ranks of the terms to materialise, {stratum: [(term_idx_a, term_idx_b), ...]})."""
+    rng = np.random.default_rng(QUERY_SEED)
+    cr, sr = rank_band(c, COMMON), rank_band(c, SELECTIVE)
+    pairs = {"cc": [], "sc": [], "ss": []}
+    for _ in range(q_per_stratum):
+        a, b = rng.integers(cr[0], cr[1] + 1, 2)
+        while a == b:
+            b = rng.integers(cr[0], cr[1] + 1)
+        pairs["cc"].append((int(a), int(b)))
+        pairs["sc"].append((int(rng.integers(sr[0], sr[1] + 1)), int(rng.integers(cr[0], cr[1] + 1))))
+        a, b = rng.integers(sr[0], sr[1] + 1, 2)
+        while a == b:
+            b = rng.integers(sr[0], sr[1] + 1)
+        pairs["ss"].append((int(a), int(b)))
+    ranks = sorted({r for v in pairs.values() for p in v for r in p})
+    idx = {r: i for i, r in enumerate(ranks)}
+    return ranks, {k: [(idx[a], idx[b]) for a, b in v] for k, v in pairs.items()}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--docs", type=int, default=100_000_000, help="documents in the whole corpus")
+    ap.add_argument("--queries", type=int, default=256, help="queries per stratum per step")
+    ap.add_argument("--item-bytes", type=int, default=0)
+    ap.add_argument("--skiplist-block", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the oracle timing sample")
+    ap.add_argument("--latency-samples", type=int, default=96)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+
+    import manticoresearch_amd as m
+    from manticoresearch_amd import dist as mdist
+
+    t_setup = time.time()
+    c = zipf_c()
+    ranks, strata = make_queries(c, args.queries)
+    probs = [min(0.5, c / r) for r in ranks]
+    shard_docs = args.docs // world
+    hi = m.synth_index(shard_docs, probs, seed=CORPUS_SEED, shard=rank, skiplist_block_size=args.skiplist_block)
+    t_gen = time.time() - t_setup
+
+    ctx = m.Context(local_rank)
+    if args.item_bytes:
+        ctx.set("item_bytes", args.item_bytes)
+    seg = m.Segment(ctx, hi, rowid_base=rank * shard_docs)
+    batch = m.Batch(ctx, args.queries)
+
+    # global DF / N so that every shard ranks with the same IDF (local_df, sphinxrt.cpp:6501-6521)
+    local_docs = hi.dict["docs"].astype(np.int64)
+    if world > 1:
+        global_docs, total_docs = mdist.global_df(local_docs, shard_docs, local_rank)
+    else:
+        global_docs, total_docs = local_docs, shard_docs
+
+    kw = m.XQNode.keyword
+    K = 1000
+
+    def mkq(a, b):
+        return m.Query(m.XQNode.AND(kw(a, 1), kw(b, 2)), ranker=m.SPH_RANK_BM25, max_matches=K, total_docs=int(total_docs),
+                       local_docs={a: int(global_docs[a]), b: int(global_docs[b])})
+
+    names = ["cc", "sc", "ss"]
+    prepared = {s: m.prepare([mkq(a, b) for a, b in strata[s]]) for s in names}
+    nq = args.queries
+    merger = mdist.ShardMerger(ctx, batch, nq, K, world, local_rank) if world > 1 else None
+
+    per = {s: {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0} for s in names}
+
+    def step(record: bool) -> None:
+        for s in names:
+            batch.submit_prepared(seg, prepared[s], nq)
+            batch.wait()
+            if merger is not None:
+                merger.merge()
+            if record:
+                st = batch.stats()
+                per[s]["scan_ms"] += st["scan_ms"]
+                per[s]["merge_ms"] += st["merge_ms"]
+                per[s]["algo_bytes"] = st["algo_bytes"]
+                per[s]["n_items"] = st["n_items"]
+                per[s]["n"] += 1
+
+    def sync() -> None:
+        batch.wait()
+        if world > 1:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # output bytes of the cc stratum: 8 B per returned match
+    batch.submit_prepared(seg, prepared["cc"], nq)
+    batch.wait()
+    res_cc = batch.results()
+    out_bytes = sum(8 * len(r.rowid) for r in res_cc)
+
+    # single-query latency (batch of one), p50 over a stratified sample
+    lat = []
+    if rank == 0 and world == 1 and args.latency_samples > 0:
+        sample = []
+        per_s = max(1, args.latency_samples // 3)
+        for s in names:
+            sample += [mkq(a, b) for a, b in strata[s][:per_s]]
+        singles = [m.prepare([q]) for q in sample]
+        for cq in singles[:3]:
+            batch.submit_prepared(seg, cq, 1)
+            batch.wait()
+        for cq in singles:
+            t1 = time.perf_counter()
+            batch.submit_prepared(seg, cq, 1)
+            batch.wait()
+            lat.append((time.perf_counter() - t1) * 1e3)
+
+    total_queries = 3 * nq * args.steps
+    qps = total_queries / elapsed
+    cc = per["cc"]
+    scan_ms = cc["scan_ms"] / max(1, cc["n"])
+    algo = cc["algo_bytes"] + out_bytes
+    achieved = algo / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic = None
+    tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr_path):
+        try:
+            tj = json.load(open(tr_path))
+            if tj.get("docs") == args.docs and tj.get("queries") == nq and tj.get("skiplist_block") == args.skiplist_block:
+                traffic = tj.get("traffic_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "queries/sec, 2-term AND BM25 top-1000 (p50 latency in p50_latency_ms)",
+        "value": round(qps, 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u8 postings -> u32 rowids, f32 BM25, i32 weights",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.docs // 1_000_000}M docs (Zipf s=1, V=2^20, {AVG_TERMS_PER_DOC:.0f} terms/doc), 2-term AND, "
+                        f"SPH_RANK_BM25, top-{K}, {3 * nq} queries/step in 3 strata (cc/sc/ss), "
+                        f"skiplist_block_size={args.skiplist_block}, inline hits",
+            "docs": args.docs,
+            "shards": world,
+            "queries_per_step": 3 * nq,
+            "k": K,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "kernel": "scan_kernel (common x common stratum launch)",
+            "algo_bytes_per_launch": int(algo),
+            "launch_ms": round(scan_ms, 4),
+        },
+        "strata": {
+            s: {"scan_ms": round(per[s]["scan_ms"] / max(1, per[s]["n"]), 4),
+                "merge_ms": round(per[s]["merge_ms"] / max(1, per[s]["n"]), 4),
+                "algo_MB": round(per[s]["algo_bytes"] / 1e6, 2), "items": per[s].get("n_items", 0)} for s in names},
+        "p50_latency_ms": round(float(np.percentile(lat, 50)), 4) if lat else None,
+        "p95_latency_ms": round(float(np.percentile(lat, 95)), 4) if lat else None,
+        "setup_s": {"generate": round(t_gen, 1), "index_MB": round((hi.spd.size + hi.spp.size + hi.spe.size) / 1e6, 1)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(hi, strata, total_docs, K, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    batch.close()
+    seg.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(hi, strata, total_docs, K, budget_s: float) -> dict:
+    """The oracle (kind "port") on this box's host cores over a bounded, stratified sample of the
+    SAME queries and index bytes: one independent query per thread, the reference's own
+    parallelism model (searchd.cpp:5654).  Test infrastructure used as the reported baseline only."""
+    from oracle import oracle as orc
+
+    oi = orc.Index(hi.spd, hi.spp, hi.spe, hi.dict.view(orc.DICT_DTYPE), hi.total_docs, hi.skiplist_block_size,
+                   hi.hit_format, hi.n_fields)
+    cidx = oi.c_struct()
+
+    def fq(a, b):
+        return orc.FlatQuery(orc.op(orc.OP_AND, orc.term(a, 1), orc.term(b, 2)), ranker=orc.RANK_BM25, max_matches=K,
+                             total_docs_override=int(total_docs))
+
+    names = ["cc", "sc", "ss"]
+    # single-thread pass: interleave strata so that the sample keeps the workload's mix
+    sample, t_single = [], []
+    t_begin = time.perf_counter()
+    i = 0
+    while time.perf_counter() - t_begin < budget_s * 0.4 and i < len(strata["cc"]):
+        for s in names:
+            q = fq(*strata[s][i])
+            t1 = time.perf_counter()
+            q.run(oi, cidx)
+            t_single.append(time.perf_counter() - t1)
+            sample.append(q)
+        i += 1
+    cores = os.cpu_count() or 1
+    # all-core pass: every thread runs the whole sample once
+    def worker():
+        for q in sample:
+            q.run(oi, cidx)
+
+    th = [threading.Thread(target=worker) for _ in range(cores)]
+    t1 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t1
+    return {
+        "value": round(cores * len(sample) / wall, 3),
+        "unit": "queries/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{len(sample)} queries ({len(sample) // 3} per stratum, same index bytes), run once by each of {cores} "
+                  f"threads; single-thread {len(sample) / sum(t_single):.3f} q/s, p50 {np.percentile(t_single, 50) * 1e3:.1f} ms",
+        "single_thread_qps": round(len(sample) / sum(t_single), 3),
+    }
+
+
+if __name__ == "__main__":
+    main()

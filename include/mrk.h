@@ -167,6 +167,10 @@ int mrk_batch_stats_get(mrk_batch* b, mrk_batch_stats* out);
    descending; counts[q]; totals[q].  Valid after mrk_batch_wait. */
 int mrk_batch_device_results(mrk_batch* b, const uint64_t** keys, const uint32_t** counts, const uint64_t** totals);
 
+/* copy those three arrays into caller-owned device buffers (e.g. tensors handed to RCCL);
+   any pointer may be NULL; synchronous */
+int mrk_batch_export_device(mrk_batch* b, uint64_t* keys_dst, uint32_t* counts_dst, uint64_t* totals_dst);
+
 /* merge n_lists sorted partial top-K lists per query (device pointers):
    in_keys[(l*n_queries + q)*MRK_MAX_K + i], in_counts[l*n_queries + q] -> out_keys[q*MRK_MAX_K + i],
    out_counts[q].  Order: weight desc, global docid asc. Synchronous on the ctx stream. */

@@ -82,6 +82,7 @@ SYMBOLS = [
     ("mrk_batch_result", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Result)]),
     ("mrk_batch_stats_get", C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     ("mrk_batch_device_results", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("mrk_batch_export_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mrk_topk_merge", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mrk_idf", C.c_float, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]),
     ("mrk_index_from_hits", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),

@@ -49,24 +49,39 @@ class HostIndex:
         return int(self.dict["doclist_len"].sum())
 
 
-def _take_host_index(h: int, total_docs: int, skiplist_block_size: int, hit_format: int, n_fields: int) -> HostIndex:
+class _HostIndexOwner:
+    """Keeps the C++ mrk_host_index alive while numpy views its buffers (no copy of GBs)."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mrk_host_index_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _take_host_index(h, total_docs: int, skiplist_block_size: int, hit_format: int, n_fields: int) -> HostIndex:
     L = lib()
-    try:
-        n = C.c_uint64()
-        out = {}
-        for nm in ("spd", "spp", "spe"):
-            p = getattr(L, "mrk_host_index_" + nm)(h, C.byref(n))
-            a = np.empty(n.value + 64, np.uint8)  # keep the 64 slack bytes the writer provides
-            C.memmove(a.ctypes.data, p, n.value + 64)
-            out[nm] = a[: n.value]
-        nt = C.c_uint32()
-        p = L.mrk_host_index_dict(h, C.byref(nt))
-        d = np.zeros(nt.value, DICT_DTYPE)
-        if nt.value:
-            C.memmove(d.ctypes.data, p, nt.value * DICT_DTYPE.itemsize)
-    finally:
-        L.mrk_host_index_free(h)
-    return HostIndex(out["spd"], out["spp"], out["spe"], d, total_docs, skiplist_block_size, hit_format, n_fields)
+    owner = _HostIndexOwner(h)
+    n = C.c_uint64()
+    out = {}
+    for nm in ("spd", "spp", "spe"):
+        p = getattr(L, "mrk_host_index_" + nm)(h, C.byref(n))
+        buf = (C.c_uint8 * (n.value + 64)).from_address(p)  # the writer leaves 64 zero bytes of slack
+        a = np.frombuffer(buf, dtype=np.uint8)
+        out[nm] = a[: n.value]
+    nt = C.c_uint32()
+    p = L.mrk_host_index_dict(h, C.byref(nt))
+    d = np.zeros(nt.value, DICT_DTYPE)
+    if nt.value:
+        C.memmove(d.ctypes.data, p, nt.value * DICT_DTYPE.itemsize)
+    hi = HostIndex(out["spd"], out["spp"], out["spe"], d, total_docs, skiplist_block_size, hit_format, n_fields)
+    hi._owner = owner
+    return hi
 
 
 def index_from_hits(wordid: np.ndarray, rowid: np.ndarray, hitpos: np.ndarray, n_terms: int, total_docs: int,

@@ -681,6 +681,19 @@ extern "C" int mrk_batch_device_results(mrk_batch* b, const uint64_t** keys, con
   return MRK_OK;
 }
 
+extern "C" int mrk_batch_export_device(mrk_batch* b, uint64_t* keys_dst, uint32_t* counts_dst, uint64_t* totals_dst) {
+  if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_export_device: NULL batch");
+  HIP_TRY(hipSetDevice(b->ctx->device));
+  hipStream_t st = b->ctx->stream;
+  const size_t n = b->n_queries;
+  if (keys_dst) HIP_TRY(hipMemcpyAsync(keys_dst, b->d_out_keys.p, n * KCAP * 8, hipMemcpyDeviceToDevice, st));
+  if (counts_dst) HIP_TRY(hipMemcpyAsync(counts_dst, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToDevice, st));
+  if (totals_dst) HIP_TRY(hipMemcpyAsync(totals_dst, b->d_q_total.p, n * 8, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  b->in_flight = false;
+  return MRK_OK;
+}
+
 extern "C" int mrk_topk_merge(mrk_ctx* ctx, const uint64_t* in_keys, const uint32_t* in_counts, uint32_t n_lists,
                               uint32_t n_queries, uint32_t k, uint64_t* out_keys, uint32_t* out_counts) {
   if (!ctx || !in_keys || !in_counts || !out_keys || !out_counts) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge: NULL argument");

@@ -18,10 +18,13 @@
 // hitlists first.
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <stdio.h>
 #include <new>
 #include <thread>
 #include <vector>
@@ -32,10 +35,40 @@ int mrk_fail(int code, const char* fmt, ...);
 
 namespace {
 
-inline void put_vlb(std::vector<uint8_t>& out, uint64_t v) {
+// append-only byte run with amortised growth and unchecked writes after ensure()
+struct Bytes {
+  uint8_t* p = nullptr;
+  size_t n = 0, cap = 0;
+  Bytes() = default;
+  Bytes(const Bytes&) = delete;
+  Bytes& operator=(const Bytes&) = delete;
+  ~Bytes() { free(p); }
+  void ensure(size_t extra) {
+    if (n + extra <= cap) return;
+    size_t nc = cap ? cap * 2 : 4096;
+    while (nc < n + extra) nc *= 2;
+    p = (uint8_t*)realloc(p, nc);
+    cap = nc;
+  }
+  size_t size() const { return n; }
+  const uint8_t* data() const { return p; }
+  void clear() { n = 0; }
+  void release() {
+    free(p);
+    p = nullptr;
+    n = cap = 0;
+  }
+};
+
+inline void put_vlb(Bytes& out, uint64_t v) {
+  out.ensure(10);
+  if (v < 128) {
+    out.p[out.n++] = (uint8_t)v;
+    return;
+  }
   int n = 1;
   for (uint64_t t = v >> 7; t; t >>= 7) ++n;
-  for (int i = n - 1; i >= 0; --i) out.push_back((uint8_t)(((v >> (7 * i)) & 0x7f) | (i ? 0x80 : 0)));
+  for (int i = n - 1; i >= 0; --i) out.p[out.n++] = (uint8_t)(((v >> (7 * i)) & 0x7f) | (i ? 0x80 : 0));
 }
 
 // postings of one word: docs in rowid order, each with its (deduplicated, sorted) hit positions
@@ -46,7 +79,7 @@ struct WordPostings {
 };
 
 struct WordBytes {
-  std::vector<uint8_t> spd, spp, spe;
+  Bytes spd, spp, spe;
   std::vector<uint32_t> spp_doc_off; // local .spp offset of each multi-hit doc's hitlist
   uint32_t docs = 0, n_hits = 0;
 };
@@ -57,6 +90,7 @@ void encode_hitlists(const WordPostings& w, bool inline_fmt, WordBytes& o) {
   o.spp_doc_off.assign(nd, 0);
   o.docs = (uint32_t)nd;
   o.n_hits = (uint32_t)w.hits.size();
+  o.spp.ensure(w.hits.size() * 2 + nd + 16);
   for (size_t d = 0; d < nd; ++d) {
     const uint32_t hb = w.hit_begin[d], he = w.hit_begin[d + 1];
     o.spp_doc_off[d] = (uint32_t)o.spp.size();
@@ -76,6 +110,7 @@ void encode_doclist(const WordPostings& w, bool inline_fmt, uint32_t block, uint
   uint64_t last_hit_pos = 0; // m_iLastHitlistPos: resets to 0 per word (sphinx.cpp:8612)
   uint32_t snap_base = 0;
   uint64_t snap_off = 0, snap_hit = 0;
+  o.spd.ensure(nd * 6 + 16);
   for (size_t d = 0; d < nd; ++d) {
     if ((d & (block - 1)) == 0 && d) { // snapshot 0 is implicit
       const uint32_t bp1 = last_rowid + 1u;
@@ -119,42 +154,40 @@ void encode_doclist(const WordPostings& w, bool inline_fmt, uint32_t block, uint
 } // namespace
 
 struct mrk_host_index {
-  std::vector<uint8_t> spd, spp, spe;
+  uint8_t *spd = nullptr, *spp = nullptr, *spe = nullptr; // malloc'd, 64 zero bytes of slack each
+  uint64_t spd_len = 0, spp_len = 0, spe_len = 0;
   std::vector<mrk_dict_entry> dict;
+  ~mrk_host_index() {
+    free(spd);
+    free(spp);
+    free(spe);
+  }
 };
 
 namespace {
 
+template <typename F>
+void parallel_for(size_t n, uint32_t n_threads, F fn);
+
 // concatenates per-word runs; spd runs must already carry absolute .spp offsets
-int assemble(std::vector<WordBytes>& wb, const std::vector<uint64_t>& spp_base, uint32_t block, mrk_host_index** out) {
+int assemble(std::vector<WordBytes>& wb, const std::vector<uint64_t>& spp_base, uint32_t block, uint32_t n_threads,
+             mrk_host_index** out) {
   mrk_host_index* h = new (std::nothrow) mrk_host_index();
   if (!h) return mrk_fail(MRK_E_NOMEM, "out of memory");
   const size_t nt = wb.size();
-  uint64_t spd_len = 1, spp_len = 1, spe_len = 1;
-  for (size_t t = 0; t < nt; ++t) {
-    if (!wb[t].docs) continue;
-    spd_len += wb[t].spd.size();
-    spp_len += wb[t].spp.size();
-    spe_len += wb[t].spe.size();
-  }
-  h->spd.assign(spd_len + 64, 0);
-  h->spp.assign(spp_len + 64, 0);
-  h->spe.assign(spe_len + 64, 0);
-  h->spd[0] = h->spp[0] = h->spe[0] = 1;
-  h->dict.assign(nt, mrk_dict_entry{});
+  std::vector<uint64_t> od(nt), op(nt), oe(nt);
   uint64_t pd = 1, pp = 1, pe = 1;
+  h->dict.assign(nt, mrk_dict_entry{});
   for (size_t t = 0; t < nt; ++t) {
-    WordBytes& w = wb[t];
+    const WordBytes& w = wb[t];
     mrk_dict_entry& e = h->dict[t];
     e.wordid = t + 1;
+    od[t] = pd, op[t] = pp, oe[t] = pe;
     if (!w.docs) continue;
     if (pp != spp_base[t]) {
       delete h;
       return mrk_fail(MRK_E_FORMAT, "internal: hitlist base mismatch for word %zu", t);
     }
-    memcpy(h->spd.data() + pd, w.spd.data(), w.spd.size());
-    memcpy(h->spp.data() + pp, w.spp.data(), w.spp.size());
-    memcpy(h->spe.data() + pe, w.spe.data(), w.spe.size());
     e.doclist_off = pd;
     e.doclist_len = w.spd.size();
     e.skiplist_off = w.docs > block ? pe : 0;
@@ -163,10 +196,29 @@ int assemble(std::vector<WordBytes>& wb, const std::vector<uint64_t>& spp_base, 
     pd += w.spd.size();
     pp += w.spp.size();
     pe += w.spe.size();
-    std::vector<uint8_t>().swap(w.spd);
-    std::vector<uint8_t>().swap(w.spp);
-    std::vector<uint8_t>().swap(w.spe);
   }
+  h->spd_len = pd, h->spp_len = pp, h->spe_len = pe;
+  h->spd = (uint8_t*)malloc(pd + 64);
+  h->spp = (uint8_t*)malloc(pp + 64);
+  h->spe = (uint8_t*)malloc(pe + 64);
+  if (!h->spd || !h->spp || !h->spe) {
+    delete h;
+    return mrk_fail(MRK_E_NOMEM, "out of memory assembling the index");
+  }
+  h->spd[0] = h->spp[0] = h->spe[0] = 1; // dummy first byte (sphinx.cpp:8404-8409)
+  memset(h->spd + pd, 0, 64);
+  memset(h->spp + pp, 0, 64);
+  memset(h->spe + pe, 0, 64);
+  parallel_for(nt, n_threads, [&](size_t t) { // parallel copy = parallel first touch of the big buffers
+    WordBytes& w = wb[t];
+    if (!w.docs) return;
+    memcpy(h->spd + od[t], w.spd.data(), w.spd.size());
+    memcpy(h->spp + op[t], w.spp.data(), w.spp.size());
+    memcpy(h->spe + oe[t], w.spe.data(), w.spe.size());
+    w.spd.release();
+    w.spp.release();
+    w.spe.release();
+  });
   *out = h;
   return MRK_OK;
 }
@@ -192,13 +244,18 @@ void parallel_for(size_t n, uint32_t n_threads, F fn) {
   for (auto& x : th) x.join();
 }
 
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool timing_on() { return getenv("MRK_TIMING") != nullptr; }
+
 int build(std::vector<WordPostings>& words, uint32_t block, uint32_t hit_format, uint32_t n_threads, mrk_host_index** out) {
   if (!out) return mrk_fail(MRK_E_INVAL, "out is NULL");
+  const double t0 = now_s();
   if (block == 0 || (block & (block - 1))) return mrk_fail(MRK_E_INVAL, "skiplist_block_size %u is not a power of two", block);
   const bool inline_fmt = hit_format == MRK_HITFMT_INLINE;
   const size_t nt = words.size();
   std::vector<WordBytes> wb(nt);
   parallel_for(nt, n_threads, [&](size_t t) { encode_hitlists(words[t], inline_fmt, wb[t]); });
+  const double t1 = now_s();
   std::vector<uint64_t> spp_base(nt);
   uint64_t pp = 1;
   for (size_t t = 0; t < nt; ++t) {
@@ -211,7 +268,10 @@ int build(std::vector<WordPostings>& words, uint32_t block, uint32_t hit_format,
     std::vector<uint32_t>().swap(words[t].hits);
     std::vector<uint32_t>().swap(words[t].hit_begin);
   });
-  return assemble(wb, spp_base, block, out);
+  const double t2 = now_s();
+  int rc = assemble(wb, spp_base, block, n_threads, out);
+  if (timing_on()) fprintf(stderr, "[mrk] encode hitlists %.2fs, doclists %.2fs, assemble %.2fs\n", t1 - t0, t2 - t1, now_s() - t2);
+  return rc;
 }
 
 inline uint64_t splitmix64(uint64_t& s) {
@@ -273,6 +333,7 @@ extern "C" int mrk_synth_generate(const mrk_synth_params* p, mrk_host_index** ou
     return mrk_fail(MRK_E_INVAL, "mrk_synth_generate: bad n_fields/max_pos");
   for (uint32_t t = 0; t < p->n_terms; ++t)
     if (!(p->term_prob[t] > 0.0 && p->term_prob[t] <= 1.0)) return mrk_fail(MRK_E_INVAL, "term_prob[%u] outside (0,1]", t);
+  const double tg0 = now_s();
   std::vector<WordPostings> words(p->n_terms);
   const uint64_t title_thr = (uint64_t)(p->title_frac * 18446744073709551615.0);
   parallel_for(p->n_terms, p->n_threads, [&](size_t t) {
@@ -304,8 +365,13 @@ extern "C" int mrk_synth_generate(const mrk_synth_params* p, mrk_host_index** ou
         const uint32_t pos = 1 + (uint32_t)((a & 0xFFFFF) * (uint64_t)p->max_pos >> 20);
         tmp[n++] = (f << 24) | pos;
       }
-      std::sort(tmp, tmp + n);
-      n = (uint32_t)(std::unique(tmp, tmp + n) - tmp);
+      if (n > 1) {
+        if (n == 2) {
+          if (tmp[0] > tmp[1]) std::swap(tmp[0], tmp[1]);
+        } else
+          std::sort(tmp, tmp + n);
+        n = (uint32_t)(std::unique(tmp, tmp + n) - tmp);
+      }
       if (p->end_markers) // mark each field's last hit of this word in this doc
         for (uint32_t i = 0; i < n; ++i)
           if (i + 1 == n || (tmp[i + 1] >> 24) != (tmp[i] >> 24)) tmp[i] |= 1u << 23;
@@ -316,21 +382,22 @@ extern "C" int mrk_synth_generate(const mrk_synth_params* p, mrk_host_index** ou
     }
     w.hit_begin.push_back((uint32_t)w.hits.size());
   });
+  if (timing_on()) fprintf(stderr, "[mrk] sample postings %.2fs\n", now_s() - tg0);
   return build(words, p->skiplist_block_size, p->hit_format, p->n_threads, out);
 }
 
 extern "C" void mrk_host_index_free(mrk_host_index* h) { delete h; }
 extern "C" const uint8_t* mrk_host_index_spd(const mrk_host_index* h, uint64_t* len) {
-  if (len) *len = h->spd.size() - 64;
-  return h->spd.data();
+  if (len) *len = h->spd_len;
+  return h->spd;
 }
 extern "C" const uint8_t* mrk_host_index_spp(const mrk_host_index* h, uint64_t* len) {
-  if (len) *len = h->spp.size() - 64;
-  return h->spp.data();
+  if (len) *len = h->spp_len;
+  return h->spp;
 }
 extern "C" const uint8_t* mrk_host_index_spe(const mrk_host_index* h, uint64_t* len) {
-  if (len) *len = h->spe.size() - 64;
-  return h->spe.data();
+  if (len) *len = h->spe_len;
+  return h->spe;
 }
 extern "C" const mrk_dict_entry* mrk_host_index_dict(const mrk_host_index* h, uint32_t* n_terms) {
   if (n_terms) *n_terms = (uint32_t)h->dict.size();
