@@ -86,6 +86,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the oracle timing sample")
     ap.add_argument("--latency-samples", type=int, default=96)
+    ap.add_argument("--strata", default="cc,sc,ss", help="subset of strata to run (profiling aid; the metric uses all three)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,12 +134,12 @@ def main() -> None:
         return m.Query(m.XQNode.AND(kw(a, 1), kw(b, 2)), ranker=m.SPH_RANK_BM25, max_matches=K, total_docs=int(total_docs),
                        local_docs={a: int(global_docs[a]), b: int(global_docs[b])})
 
-    names = ["cc", "sc", "ss"]
+    names = [x for x in ["cc", "sc", "ss"] if x in args.strata.split(",")]
     prepared = {s: m.prepare([mkq(a, b) for a, b in strata[s]]) for s in names}
     nq = args.queries
     merger = mdist.ShardMerger(ctx, batch, nq, K, world, local_rank) if world > 1 else None
 
-    per = {s: {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0} for s in names}
+    per = {s: {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0} for s in ["cc", "sc", "ss"]}
 
     def step(record: bool) -> None:
         for s in names:
@@ -179,6 +180,10 @@ def main() -> None:
         elapsed = float(t.item())
 
     # output bytes of the cc stratum: 8 B per returned match
+    if "cc" not in names:
+        names_backup = names
+        prepared["cc"] = m.prepare([mkq(a, b) for a, b in strata["cc"]])
+        per.setdefault("cc", {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0})
     batch.submit_prepared(seg, prepared["cc"], nq)
     batch.wait()
     res_cc = batch.results()
@@ -201,7 +206,7 @@ def main() -> None:
             batch.wait()
             lat.append((time.perf_counter() - t1) * 1e3)
 
-    total_queries = 3 * nq * args.steps
+    total_queries = len(names) * nq * args.steps
     qps = total_queries / elapsed
     cc = per["cc"]
     scan_ms = cc["scan_ms"] / max(1, cc["n"])
@@ -254,6 +259,7 @@ def main() -> None:
             s: {"scan_ms": round(per[s]["scan_ms"] / max(1, per[s]["n"]), 4),
                 "merge_ms": round(per[s]["merge_ms"] / max(1, per[s]["n"]), 4),
                 "algo_MB": round(per[s]["algo_bytes"] / 1e6, 2), "items": per[s].get("n_items", 0)} for s in names},
+        "strata_run": names,
         "p50_latency_ms": round(float(np.percentile(lat, 50)), 4) if lat else None,
         "p95_latency_ms": round(float(np.percentile(lat, 95)), 4) if lat else None,
         "setup_s": {"generate": round(t_gen, 1), "index_MB": round((hi.spd.size + hi.spp.size + hi.spe.size) / 1e6, 1)},

@@ -1,17 +1,20 @@
 // mrk_kernels.hip -- gfx950 (MI355X, wave64) kernels of the match -> rank -> top-K path.
 //
-// scan_kernel  : one workgroup per work item = (query, range of driver-term blocks).
-//                VLB doclist blocks are pulled from HBM 16 B/lane, staged in LDS, split
-//                into entries with wave-wide terminator-bit prefix sums, decoded one
-//                entry per lane, intersected N-way (driver docs probe the other terms'
-//                decoded blocks), scored (fp32 BM25 in reference op order, int weight)
-//                and filtered into a per-workgroup top-K buffer in LDS.
+// scan_kernel  : one workgroup per work item = (query, range of driver-term blocks); each of
+//                its 4 waves owns a contiguous run of driver blocks and works on its own:
+//                it streams the driver term's VLB doclist blocks and, for every other term,
+//                the blocks its driver docs can fall into (2-stream merge when the lists
+//                are dense, skiplist-style jumps when they are not), decodes them in LDS
+//                (terminator-bit prefix sums split the byte stream into entries, one entry
+//                per lane), probes, scores in fp32 in the reference's op order and pushes
+//                candidates above the running threshold into the workgroup's top-K buffer.
+//                Waves only meet at one barrier per driver block (buffer compaction).
 // merge_kernel : one workgroup per query: top-K of the candidates the scan produced
 //                (or of per-shard partial top-K lists), sorted best-first.
 //
 // What each piece restates (reference file:line, Manticore 3.6.1 src/):
 //   decode_block      DiskIndexQword_c::ReadNext         sphinx.cpp:511-549
-//   block lookup      DiskIndexQword_c::HintRowID        sphinx.cpp:407-451
+//   block seek        DiskIndexQword_c::HintRowID        sphinx.cpp:407-451
 //   intersection      ExtMultiAnd_T::AdvanceQwords       searchnode.cpp:2865-2889
 //   field filter      NodeInfo_t::FitsFields             searchnode.cpp:2727-2747
 //   tfidf             ExtMultiAnd_T::GetTFIDF            searchnode.cpp:2821-2832
@@ -24,40 +27,58 @@
 
 namespace mrk {
 
-constexpr int RNG_CAP = 512; // other-term block bases cached in LDS per tile
 constexpr uint32_t NOBLK = 0xFFFFFFFFu;
+constexpr uint32_t INF_ROWID = 0xFFFFFFFFu;
+constexpr int CHUNK = 63; // usable block-index entries per 64-lane metadata chunk (one spare for "next")
+
+struct __align__(16) WaveLds {
+  uint8_t stage[STAGE_BYTES + 16];
+  uint32_t tj_rowid[DEVBLK];
+  uint32_t tj_tf[DEVBLK];
+  uint32_t tj_fields[DEVBLK];
+  uint16_t docstart[DEVBLK + 8];
+};
 
 struct __align__(16) Smem {
-  uint8_t stage[WAVES][STAGE_BYTES + 16];
+  WaveLds w[WAVES];
   uint64_t cand[CAND];
-  uint32_t t0_rowid[TILE];
-  float t0_acc[TILE];
-  uint32_t t0_fields[TILE];
-  uint32_t blk_of[TILE];
-  uint32_t need_list[TILE];
-  uint32_t tj_rowid[SLOTS][DEVBLK];
-  uint32_t tj_tf[SLOTS][DEVBLK];
-  uint32_t tj_fields[SLOTS][DEVBLK];
-  uint32_t rng_base[RNG_CAP];
-  uint16_t need_idx[TILE];
-  uint16_t docstart[WAVES][DEVBLK + 8];
   int32_t weights[32];
   uint32_t wave_cnt[2 * WAVES];
   uint32_t cand_n;
-  uint32_t rng_lo, rng_hi;
   uint64_t tau;
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// ---- wave-wide primitives on DPP (row_shr within rows of 16, then row_bcast15 / row_bcast31)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-  const uint32_t lane = lane_id();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if (lane >= (uint32_t)d) v += t;
-  }
+  v += dpp_u32<0x111, 0xf>(0, v); // row_shr:1
+  v += dpp_u32<0x112, 0xf>(0, v); // row_shr:2
+  v += dpp_u32<0x114, 0xf>(0, v); // row_shr:4
+  v += dpp_u32<0x118, 0xf>(0, v); // row_shr:8
+  v += dpp_u32<0x142, 0xa>(0, v); // row_bcast:15 -> rows 1,3
+  v += dpp_u32<0x143, 0xc>(0, v); // row_bcast:31 -> rows 2,3
   return v;
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+  v = min(v, dpp_u32<0x111, 0xf>(0xFFFFFFFFu, v));
+  v = min(v, dpp_u32<0x112, 0xf>(0xFFFFFFFFu, v));
+  v = min(v, dpp_u32<0x114, 0xf>(0xFFFFFFFFu, v));
+  v = min(v, dpp_u32<0x118, 0xf>(0xFFFFFFFFu, v));
+  v = min(v, dpp_u32<0x142, 0xa>(0xFFFFFFFFu, v));
+  v = min(v, dpp_u32<0x143, 0xc>(0xFFFFFFFFu, v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, uint32_t l) {
+  return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
 }
 
 // LDS hand-off between lanes of ONE wave: make earlier ds_writes visible and keep the
@@ -79,23 +100,68 @@ __device__ __forceinline__ float term_tfidf(uint32_t tf, float idf) {
   return q * idf;
 }
 
+// ---- block metadata: 64 consecutive entries of a term's block index, one per lane
+struct Chunk {
+  uint32_t first; // block index (within the term) held by lane 0
+  uint32_t bp1;   // SkiplistEntry_t::m_tBaseRowIDPlus1 of block first+lane (INF past the end)
+  uint64_t off;   // .spd offset of block first+lane (doclist end past the end)
+};
+
+__device__ __forceinline__ void load_chunk(Chunk& c, const DevSegment& seg, const DevTerm& T, uint32_t first) {
+  const uint32_t i = first + lane_id();
+  c.first = first;
+  if (i < T.nblocks) {
+    c.bp1 = seg.blk_base[T.blk_first + i];
+    c.off = seg.blk_off[T.blk_first + i];
+  } else {
+    c.bp1 = INF_ROWID;
+    c.off = T.spd_end;
+  }
+}
+
+struct BlkMeta {
+  uint64_t p0, p1; // byte range in .spd
+  uint32_t base;   // decoder rowid before the block's first entry (sphinx.cpp:447)
+  uint32_t nd;     // entries in the block
+};
+
+// i = index into the chunk (wave-uniform, < CHUNK)
+__device__ __forceinline__ BlkMeta chunk_meta(const Chunk& c, const DevTerm& T, uint32_t i) {
+  BlkMeta m;
+  m.p0 = rdlane64(c.off, i);
+  m.p1 = rdlane64(c.off, i + 1);
+  m.base = rdlane(c.bp1, i) - 1u;
+  const uint32_t left = T.docs - (c.first + i) * DEVBLK;
+  m.nd = left < (uint32_t)DEVBLK ? left : (uint32_t)DEVBLK;
+  return m;
+}
+
+// first 1 KiB of a block's byte run, 16 B per lane, straight into registers (issued early, used late)
+__device__ __forceinline__ uint4 issue_strip(const uint8_t* __restrict__ spd, const BlkMeta& m) {
+  const uint64_t a = m.p0 & ~15ull;
+  const uint64_t span = m.p1 > a ? m.p1 - a : 0;
+  const uint32_t my = lane_id() * 16;
+  uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+  if ((uint64_t)my < span) v = *reinterpret_cast<const uint4*>(spd + a + my);
+  return v;
+}
+
 struct Dec {
   uint32_t rowid[2], tf[2], fields[2];
   bool ok[2];
 };
 
 // One wave decodes one device block (<= 128 doclist entries): lane l returns entries l and l+64.
-__device__ void decode_block(const DevSegment& seg, const DevTerm& T, uint32_t b, uint32_t nd, uint8_t* stage,
-                             uint16_t* docstart, Dec& out) {
+__device__ void decode_block(const uint8_t* __restrict__ spd, const bool inline_hits, const BlkMeta& m, uint4 first_strip,
+                             WaveLds& L, Dec& out) {
   const uint32_t lane = lane_id();
-  const uint32_t gb = T.blk_first + b;
-  const uint64_t p0 = seg.blk_off[gb];
-  const uint64_t p1 = (b + 1 < T.nblocks) ? seg.blk_off[gb + 1] : T.spd_end;
-  const uint32_t base = seg.blk_base[gb] - 1u; // decoder rowid before the block's first entry (sphinx.cpp:447)
-  const uint64_t a = p0 & ~15ull;
-  const uint32_t lead = (uint32_t)(p0 - a);
-  uint64_t span = p1 > a ? p1 - a : 0;
+  uint8_t* stage = L.stage;
+  uint16_t* docstart = L.docstart;
+  const uint64_t a = m.p0 & ~15ull;
+  const uint32_t lead = (uint32_t)(m.p0 - a);
+  const uint64_t span = m.p1 > a ? m.p1 - a : 0;
   const uint32_t nbytes = span < (uint64_t)STAGE_BYTES ? (uint32_t)span : (uint32_t)STAGE_BYTES;
+  const uint32_t nd = m.nd;
 
   docstart[lane] = 0xFFFF;
   docstart[lane + 64] = 0xFFFF;
@@ -105,11 +171,12 @@ __device__ void decode_block(const DevSegment& seg, const DevTerm& T, uint32_t b
   uint32_t carry = 0;
   for (uint32_t off = 0; off < nbytes; off += 1024) {
     const uint32_t my = off + lane * 16;
-    uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
-    if (my < nbytes) {
-      v = *reinterpret_cast<const uint4*>(seg.spd + a + my);
-      *reinterpret_cast<uint4*>(stage + my) = v;
+    uint4 v = first_strip;
+    if (off) {
+      v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+      if (my < nbytes) v = *reinterpret_cast<const uint4*>(spd + a + my);
     }
+    if (my < nbytes) *reinterpret_cast<uint4*>(stage + my) = v;
     uint32_t t = term4(v.x) | (term4(v.y) << 4) | (term4(v.z) << 8) | (term4(v.w) << 12);
     if (my + 16 > nbytes) t = (my < nbytes) ? (t & ((1u << (nbytes - my)) - 1u)) : 0u;
     if (my < lead) t &= ~((1u << (lead - my)) - 1u);
@@ -117,21 +184,21 @@ __device__ void decode_block(const DevSegment& seg, const DevTerm& T, uint32_t b
     const uint32_t inc = wave_incl_scan(cnt);
     const uint32_t s = carry + inc - cnt; // index of my first varint
     // every doclist entry is exactly 4 varints (sphinx.cpp:8456-8490): entry e ends with varint 4e+3
-    uint32_t m = t;
+    uint32_t mm = t;
     const uint32_t r = (3u - s) & 3u;
-    for (uint32_t i = 0; i < r; ++i) m &= m - 1;
+    for (uint32_t i = 0; i < r; ++i) mm &= mm - 1;
     uint32_t idx = s + r;
-    while (m) {
-      const uint32_t pos = __builtin_ctz(m);
+    while (mm) {
+      const uint32_t pos = __builtin_ctz(mm);
       const uint32_t doc = (idx >> 2) + 1;
       if (doc < nd) docstart[doc] = (uint16_t)(my + pos + 1);
-      m &= m - 1;
-      m &= m - 1;
-      m &= m - 1;
-      m &= m - 1;
+      mm &= mm - 1;
+      mm &= mm - 1;
+      mm &= mm - 1;
+      mm &= mm - 1;
       idx += 4;
     }
-    carry += __shfl(inc, 63, 64);
+    carry += rdlane(inc, 63);
   }
   wave_lds_fence();
 
@@ -143,86 +210,110 @@ __device__ void decode_block(const DevSegment& seg, const DevTerm& T, uint32_t b
     bool ok = d < nd;
     uint32_t st = ok ? docstart[d] : 0xFFFFu;
     ok = ok && st != 0xFFFFu && st < nbytes;
-    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    uint32_t v0 = 0, v1 = 0, vf = 0;
+    bool lone = false; // inline format: hits == 1
+    bool fast = false;
+    uint64_t x = 0;
     if (ok) {
       const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
       const uint32_t wi = st >> 2, sh = st & 3u;
       const uint32_t w0 = s32[wi], w1 = s32[wi + 1], w2 = s32[wi + 2];
       const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
       const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-      uint64_t x = ((uint64_t)hi << 32) | lo;
-      const uint64_t tm = ~x & 0x8080808080808080ull;
-      if (__popcll(tm) >= 4) {
-        uint32_t vv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          uint32_t val = 0, bb;
-          do {
-            bb = (uint32_t)x & 0xffu;
-            x >>= 8;
-            val = (val << 7) | (bb & 0x7fu);
-          } while (bb & 0x80u);
-          vv[k] = val;
+      x = ((uint64_t)hi << 32) | lo;
+      // fast path: the entry fits bytes 0..6 of the window and no varint is longer than 2 bytes
+      const uint32_t T = (term4(lo) | (term4(hi) << 4)) & 0x7Fu;
+      const uint32_t T1 = T & (T - 1), T2 = T1 & (T1 - 1), T3 = T2 & (T2 - 1);
+      if (T3) {
+        const uint32_t e0 = __builtin_ctz(T), e1 = __builtin_ctz(T1), e2 = __builtin_ctz(T2), e3 = __builtin_ctz(T3);
+        const uint32_t C = ~T & ((2u << e3) - 1u); // continuation bytes inside the entry
+        if (!(C & (C >> 1))) {
+          fast = true;
+          const uint64_t xs = x << 8; // byte e-1 (or 0) lands at bits 0..7 of (xs >> 8e), byte e at 8..15
+          auto val2 = [&](uint32_t e) -> uint32_t {
+            const uint32_t w = (uint32_t)(xs >> (8 * e));
+            const uint32_t last = (w >> 8) & 0x7fu;
+            const uint32_t prev = (w & 0x80u) ? ((w & 0x7fu) << 7) : 0u;
+            return prev | last;
+          };
+          v0 = val2(e0);
+          v1 = val2(e1);
+          if (inline_hits) {
+            lone = v1 == 1;
+            vf = val2(lone ? e3 : e2);
+          } else {
+            // plain: delta, hitlist offset delta, fieldmask, hits
+            vf = val2(e2);
+            v1 = val2(e3);
+          }
         }
-        v0 = vv[0], v1 = vv[1], v2 = vv[2], v3 = vv[3];
+      }
+    }
+    if (ok && !fast) {
+      // general path (rare): byte loop out of LDS, any varint length
+      uint32_t pos = st;
+      const uint32_t lim = STAGE_BYTES + 15;
+      uint32_t vv[4];
+      for (int k = 0; k < 4; ++k) {
+        uint32_t val = 0, bb;
+        do {
+          bb = stage[pos < lim ? pos : lim];
+          ++pos;
+          val = (val << 7) | (bb & 0x7fu);
+        } while ((bb & 0x80u) && pos <= lim);
+        vv[k] = val;
+      }
+      v0 = vv[0];
+      if (inline_hits) {
+        v1 = vv[1];
+        lone = v1 == 1;
+        vf = lone ? vv[3] : vv[2];
       } else {
-        // long entry (rare): byte loop out of LDS
-        uint32_t pos = st;
-        const uint32_t lim = STAGE_BYTES + 15;
-        uint32_t vv[4];
-        for (int k = 0; k < 4; ++k) {
-          uint32_t val = 0, bb;
-          do {
-            bb = stage[pos < lim ? pos : lim];
-            ++pos;
-            val = (val << 7) | (bb & 0x7fu);
-          } while ((bb & 0x80u) && pos <= lim);
-          vv[k] = val;
-        }
-        v0 = vv[0], v1 = vv[1], v2 = vv[2], v3 = vv[3];
+        vf = vv[2];
+        v1 = vv[3];
       }
     }
     // ReadNext (sphinx.cpp:511-549)
-    uint32_t tf, fields;
-    if (seg.inline_hits) {
-      tf = v1;
-      if (tf == 1) { // lone hit inlined: v2 = position, v3 = field<<1 | end
-        const uint32_t f = (v3 >> 1) & 255u;
-        fields = f < 32 ? (1u << f) : 0u;
-      } else
-        fields = v2; // v3 = hitlist offset delta
-    } else { // plain: delta, hitlist offset delta, fieldmask, hits
-      fields = v2;
-      tf = v3;
-    }
+    uint32_t fields;
+    if (lone) { // lone hit inlined: vf = field<<1 | end
+      const uint32_t f = (vf >> 1) & 255u;
+      fields = f < 32 ? (1u << f) : 0u;
+    } else
+      fields = vf;
     delta[r] = ok ? v0 : 0u;
-    out.tf[r] = tf;
+    out.tf[r] = v1;
     out.fields[r] = fields;
     out.ok[r] = ok;
   }
   const uint32_t s0 = wave_incl_scan(delta[0]);
-  const uint32_t tot0 = __shfl(s0, 63, 64);
+  const uint32_t tot0 = rdlane(s0, 63);
   const uint32_t s1 = wave_incl_scan(delta[1]);
-  out.rowid[0] = base + s0;
-  out.rowid[1] = base + tot0 + s1;
+  out.rowid[0] = m.base + s0;
+  out.rowid[1] = m.base + tot0 + s1;
   wave_lds_fence(); // stage/docstart are reused by this wave's next block
 }
 
-// largest i in [0,n) with base[i] <= r, given base[0] <= r
-template <typename P>
-__device__ __forceinline__ uint32_t find_block(P base, uint32_t n, uint32_t r) {
-  uint32_t lo = 0, hi = n;
+// wave-cooperative search: largest i in [lo, n) with base[i] <= r, given base[lo] <= r.
+// 64-ary: every step probes 64 evenly spaced entries.
+__device__ uint32_t wave_find_block(const uint32_t* __restrict__ base, uint32_t lo, uint32_t n, uint32_t r) {
+  const uint32_t lane = lane_id();
+  uint32_t hi = n;
   while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (base[mid] <= r)
-      lo = mid;
-    else
-      hi = mid;
+    const uint32_t len = hi - lo;
+    const uint32_t stride = (len + 63) / 64;
+    const uint32_t idx = lo + lane * stride;
+    const bool le = idx < hi && base[idx] <= r;
+    const uint64_t bal = __ballot(le);
+    const uint32_t p = 63u - (uint32_t)__builtin_clzll(bal | 1ull); // lane 0 always qualifies
+    const uint32_t nlo = lo + p * stride;
+    const uint32_t nhi = nlo + stride < hi ? nlo + stride : hi;
+    lo = nlo;
+    hi = nhi;
   }
   return lo;
 }
 
-// bitonic sort of s.cand[0..CAND) descending, all WG threads
+// bitonic sort of c[0..CAND) descending, all WG threads
 __device__ void sort_cand_desc(uint64_t* c) {
   for (uint32_t k = 2; k <= (uint32_t)CAND; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -241,8 +332,8 @@ __device__ void sort_cand_desc(uint64_t* c) {
   }
 }
 
-// keep the best min(n, k) keys; returns new count; once k keys are held their worst one is a
-// valid lower bound of the query's final K-th best key: raise the shared threshold with it
+// keep the best min(n, k) keys; once k keys are held their worst one is a valid lower bound of
+// the query's final K-th best key: raise the shared threshold with it
 __device__ uint32_t compact_cand(Smem& s, uint32_t k, uint64_t* gtau) {
   __syncthreads();
   const uint32_t n = s.cand_n;
@@ -262,19 +353,19 @@ __device__ uint32_t compact_cand(Smem& s, uint32_t k, uint64_t* gtau) {
 }
 
 // exclusive positions of flags laid out as i = tid + r*WG; returns total
-__device__ __forceinline__ uint32_t block_scan2(Smem& s, bool f0, bool f1, uint32_t& pos0, uint32_t& pos1) {
+__device__ __forceinline__ uint32_t block_scan2(uint32_t* wave_cnt, bool f0, bool f1, uint32_t& pos0, uint32_t& pos1) {
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   const uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
   __syncthreads(); // wave_cnt reuse
   if (lane == 0) {
-    s.wave_cnt[wave] = __popcll(b0);
-    s.wave_cnt[WAVES + wave] = __popcll(b1);
+    wave_cnt[wave] = __popcll(b0);
+    wave_cnt[WAVES + wave] = __popcll(b1);
   }
   __syncthreads();
   uint32_t base0 = 0, base1 = 0, tot0 = 0, tot1 = 0;
 #pragma unroll
   for (uint32_t w = 0; w < (uint32_t)WAVES; ++w) {
-    const uint32_t c0 = s.wave_cnt[w], c1 = s.wave_cnt[WAVES + w];
+    const uint32_t c0 = wave_cnt[w], c1 = wave_cnt[WAVES + w];
     if (w < wave) base0 += c0, base1 += c1;
     tot0 += c0;
     tot1 += c1;
@@ -295,212 +386,178 @@ __global__ __launch_bounds__(WG) void scan_kernel(ScanArgs a) {
   const uint32_t nw = Q->n_weights < 32u ? Q->n_weights : 32u;
   const uint32_t index_weight = Q->index_weight;
   const DevTerm T0 = Q->t[0];
+  const uint8_t* __restrict__ spd = a.seg.spd;
+  const bool inline_hits = a.seg.inline_hits != 0;
+  WaveLds& L = s.w[wave];
   if (tid < 32) s.weights[tid] = Q->weights[tid];
   if (tid == 0) {
     s.cand_n = 0;
     s.tau = 0;
   }
-  uint32_t total = 0; // matches seen by this thread's slots
+  // this wave's run of driver blocks
+  const uint32_t nb = item.blk_end - item.blk_begin;
+  const uint32_t per = (nb + WAVES - 1) / WAVES;
+  const uint32_t wb0 = item.blk_begin + wave * per;
+  const uint32_t wb1 = wb0 + per < item.blk_end ? wb0 + per : item.blk_end;
+
+  uint32_t total = 0; // matches seen by this lane
+  Chunk c0;           // driver-term block index chunk
+  Chunk cj;           // other-term chunk (valid for term cj_term)
+  uint32_t cj_term = 0, slot_blk = NOBLK, slot_term = 0;
+  uint32_t kj = 0; // cursor into the other term's blocks (2-term queries: persists across driver blocks)
+  BlkMeta m0{};
+  uint4 strip0 = make_uint4(0, 0, 0, 0);
+  if (wb0 < wb1) {
+    load_chunk(c0, a.seg, T0, wb0);
+    m0 = chunk_meta(c0, T0, 0);
+    strip0 = issue_strip(spd, m0);
+  }
   __syncthreads();
 
-  for (uint32_t g = item.blk_begin; g < item.blk_end; g += T0_BLOCKS) {
-    // refresh the shared threshold (any value <= the true K-th best key is safe)
-    if (tid == 0) {
-      const uint64_t gt = __hip_atomic_load(a.q_tau + item.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (gt > s.tau) s.tau = gt;
-    }
-    // ---- driver term: one block per wave
-    Dec d;
-    d.ok[0] = d.ok[1] = false;
-    d.rowid[0] = d.rowid[1] = d.tf[0] = d.tf[1] = d.fields[0] = d.fields[1] = 0;
-    const uint32_t b = g + wave;
-    if (b < item.blk_end) {
-      const uint32_t left = T0.docs - b * DEVBLK;
-      decode_block(a.seg, T0, b, left < (uint32_t)DEVBLK ? left : (uint32_t)DEVBLK, s.stage[wave], s.docstart[wave], d);
-    }
-    // field filter (FitsFields) + compaction into the tile arrays
-    uint32_t mf[2];
-    bool live[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      mf[r] = d.fields[r] & T0.queried32;
-      live[r] = d.ok[r] && mf[r] != 0;
-    }
-    // tile order must be rowid order: wave w's entries l, l+64 sit at w*128 + l, w*128 + 64 + l;
-    // scan them as two sub-tiles per wave
-    uint32_t n0;
-    {
-      const uint64_t b0 = __ballot(live[0]), b1 = __ballot(live[1]);
-      __syncthreads();
-      if (lane == 0) {
-        s.wave_cnt[2 * wave] = __popcll(b0);
-        s.wave_cnt[2 * wave + 1] = __popcll(b1);
+  for (uint32_t it = 0; it < per; ++it) {
+    const uint32_t b = wb0 + it;
+    if (b < wb1) { // wave-uniform
+      if (lane == 0) { // refresh the shared threshold (any value <= the final K-th best key is safe)
+        const uint64_t gt = __hip_atomic_load(a.q_tau + item.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gt > s.tau) atomicMax((unsigned long long*)&s.tau, (unsigned long long)gt);
       }
-      __syncthreads();
-      uint32_t basew = 0, tot = 0;
-#pragma unroll
-      for (uint32_t w = 0; w < 2u * WAVES; ++w) {
-        const uint32_t c = s.wave_cnt[w];
-        if (w < 2 * wave) basew += c;
-        tot += c;
+      // ---- driver block b (strip already in flight); issue the next one before decoding
+      BlkMeta m_next{};
+      uint4 strip_next = make_uint4(0, 0, 0, 0);
+      if (b + 1 < wb1) {
+        if (b + 1 - c0.first >= (uint32_t)CHUNK) load_chunk(c0, a.seg, T0, b + 1);
+        m_next = chunk_meta(c0, T0, b + 1 - c0.first);
+        strip_next = issue_strip(spd, m_next);
       }
-      n0 = tot;
-      const uint64_t lt = (1ull << lane) - 1ull;
-      const uint32_t p0 = basew + __popcll(b0 & lt);
-      const uint32_t p1 = basew + __popcll(b0) + __popcll(b1 & lt);
-      if (live[0]) {
-        s.t0_rowid[p0] = d.rowid[0];
-        s.t0_acc[p0] = 0.0f + term_tfidf(d.tf[0], T0.idf);
-        s.t0_fields[p0] = mf[0];
-      }
-      if (live[1]) {
-        s.t0_rowid[p1] = d.rowid[1];
-        s.t0_acc[p1] = 0.0f + term_tfidf(d.tf[1], T0.idf);
-        s.t0_fields[p1] = mf[1];
-      }
-    }
-    __syncthreads();
+      Dec d;
+      decode_block(spd, inline_hits, m0, strip0, L, d);
+      m0 = m_next;
+      strip0 = strip_next;
 
-    // ---- the other terms, in ascending-docs order
-    for (uint32_t j = 1; j < nterms && n0 > 0; ++j) {
-      const DevTerm Tj = Q->t[j];
-      const uint32_t* __restrict__ gbase = a.seg.blk_base + Tj.blk_first;
-      if (tid == 0) s.rng_lo = find_block(gbase, Tj.nblocks, s.t0_rowid[0]);
-      if (tid == 64) s.rng_hi = find_block(gbase, Tj.nblocks, s.t0_rowid[n0 - 1]);
-      __syncthreads();
-      const uint32_t rlo = s.rng_lo, rn = s.rng_hi - rlo + 1;
-      const bool in_lds = rn <= (uint32_t)RNG_CAP;
-      if (in_lds)
-        for (uint32_t i = tid; i < rn; i += WG) s.rng_base[i] = gbase[rlo + i];
-      __syncthreads();
-      // block of every driver doc (HintRowID's FindSpan)
+      uint32_t fld[2];
+      float acc[2];
+      bool live[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const uint32_t i = tid + r * WG;
-        if (i < n0) {
-          const uint32_t rowid = s.t0_rowid[i];
-          s.blk_of[i] = rlo + (in_lds ? find_block(s.rng_base, rn, rowid) : find_block(gbase + rlo, rn, rowid));
+        fld[r] = d.fields[r] & T0.queried32; // FitsFields
+        live[r] = d.ok[r] && fld[r] != 0;
+        acc[r] = 0.0f + term_tfidf(d.tf[r], T0.idf);
+      }
+
+      // ---- the other terms, in ascending-docs order
+      for (uint32_t j = 1; j < nterms; ++j) {
+        if (!__ballot(live[0] || live[1])) break;
+        const DevTerm Tj = Q->t[j];
+        const uint32_t* __restrict__ gbase = a.seg.blk_base + Tj.blk_first;
+        bool done[2] = {!live[0], !live[1]};
+        bool hit[2] = {false, false};
+        if (cj_term != j) { // (re)bind the chunk/cursor to this term
+          cj_term = j;
+          kj = 0;
+          cj.first = NOBLK;
         }
-      }
-      __syncthreads();
-      // distinct blocks, in order
-      bool head[2];
+        for (;;) {
+          // smallest driver rowid still waiting for this term
+          const uint32_t r_min = wave_min(min(done[0] ? INF_ROWID : d.rowid[0], done[1] ? INF_ROWID : d.rowid[1]));
+          if (r_min == INF_ROWID) break;
+          // block of r_min: the last block whose base <= r_min (HintRowID's FindSpan), never behind the cursor
+          if (cj.first == NOBLK || kj < cj.first || kj - cj.first >= (uint32_t)CHUNK) load_chunk(cj, a.seg, Tj, kj);
+          {
+            const uint64_t le = __ballot(cj.bp1 <= r_min);
+            uint32_t p = le ? 63u - (uint32_t)__builtin_clzll(le) : 0u; // chunk entries are ascending
+            if (p >= (uint32_t)CHUNK) { // beyond this chunk: jump with a wave-wide search, then reload
+              kj = wave_find_block(gbase, cj.first + CHUNK - 1, Tj.nblocks, r_min);
+              load_chunk(cj, a.seg, Tj, kj);
+              p = 0;
+            }
+            const uint32_t k_new = cj.first + p;
+            if (k_new > kj) kj = k_new;
+          }
+          const uint32_t ci = kj - cj.first;
+          const uint32_t bp1_k = rdlane(cj.bp1, ci), bp1_n = rdlane(cj.bp1, ci + 1);
+          if (slot_blk != kj || slot_term != j) {
+            const BlkMeta mj = chunk_meta(cj, Tj, ci);
+            const uint4 sj = issue_strip(spd, mj);
+            Dec e;
+            decode_block(spd, inline_hits, mj, sj, L, e);
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const uint32_t i = tid + r * WG;
-        head[r] = i < n0 && (i == 0 || s.blk_of[i - 1] != s.blk_of[i]);
-      }
-      uint32_t hp0, hp1;
-      const uint32_t n_need = block_scan2(s, head[0], head[1], hp0, hp1);
-      {
-        // need_idx[i] = (#heads at or before i) - 1
-        const uint32_t i0 = tid, i1 = tid + WG;
-        if (i0 < n0) s.need_idx[i0] = (uint16_t)(hp0 + (head[0] ? 1 : 0) - 1);
-        if (i1 < n0) s.need_idx[i1] = (uint16_t)(hp1 + (head[1] ? 1 : 0) - 1);
-        if (head[0]) s.need_list[hp0] = s.blk_of[i0];
-        if (head[1]) s.need_list[hp1] = s.blk_of[i1];
-      }
-      __syncthreads();
-
-      for (uint32_t pass = 0; pass < n_need; pass += SLOTS) {
-        for (uint32_t sl = wave; sl < (uint32_t)SLOTS && pass + sl < n_need; sl += WAVES) {
-          const uint32_t bj = s.need_list[pass + sl];
-          const uint32_t left = Tj.docs - bj * DEVBLK;
-          Dec e;
-          decode_block(a.seg, Tj, bj, left < (uint32_t)DEVBLK ? left : (uint32_t)DEVBLK, s.stage[wave], s.docstart[wave], e);
+            for (int r = 0; r < 2; ++r) {
+              const uint32_t o = lane + 64 * r;
+              L.tj_rowid[o] = e.ok[r] ? e.rowid[r] : MRK_INVALID_ROWID;
+              L.tj_tf[o] = e.tf[r];
+              L.tj_fields[o] = e.fields[r];
+            }
+            slot_blk = kj;
+            slot_term = j;
+            wave_lds_fence();
+          }
+          // probe: driver docs that fall into [bp1_k, bp1_n)
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
-            const uint32_t o = lane + 64 * r;
-            s.tj_rowid[sl][o] = e.ok[r] ? e.rowid[r] : MRK_INVALID_ROWID;
-            s.tj_tf[sl][o] = e.tf[r];
-            s.tj_fields[sl][o] = e.fields[r];
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const uint32_t i = tid + r * WG;
-          if (i < n0) {
-            const uint32_t sl = (uint32_t)s.need_idx[i] - pass;
-            if (sl < (uint32_t)SLOTS) {
-              const uint32_t rowid = s.t0_rowid[i];
-              const uint32_t* arr = s.tj_rowid[sl];
+            if (!done[r] && d.rowid[r] >= bp1_k && d.rowid[r] < bp1_n) {
+              done[r] = true;
+              const uint32_t rowid = d.rowid[r];
               uint32_t pos = 0;
 #pragma unroll
               for (uint32_t step = DEVBLK / 2; step; step >>= 1)
-                if (arr[pos + step - 1] < rowid) pos += step;
-              bool hit = arr[pos] == rowid;
-              if (hit) {
-                const uint32_t f = s.tj_fields[sl][pos] & Tj.queried32;
+                if (L.tj_rowid[pos + step - 1] < rowid) pos += step;
+              if (L.tj_rowid[pos] == rowid) {
+                const uint32_t f = L.tj_fields[pos] & Tj.queried32;
                 if (f) {
-                  s.t0_acc[i] = s.t0_acc[i] + term_tfidf(s.tj_tf[sl][pos], Tj.idf);
-                  s.t0_fields[i] |= f;
-                } else
-                  hit = false;
+                  hit[r] = true;
+                  acc[r] = acc[r] + term_tfidf(L.tj_tf[pos], Tj.idf);
+                  fld[r] |= f;
+                }
               }
-              if (!hit) s.blk_of[i] = NOBLK;
             }
           }
-        }
-        __syncthreads();
-      }
-      // drop the docs term j rejected
-      {
-        uint32_t rr[2], ff[2];
-        float aa[2];
-        bool keep[2];
+          // docs below bp1_k cannot exist (blocks only move forward); guard against a stall anyway
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const uint32_t i = tid + r * WG;
-          keep[r] = i < n0 && s.blk_of[i] != NOBLK;
-          if (keep[r]) rr[r] = s.t0_rowid[i], aa[r] = s.t0_acc[i], ff[r] = s.t0_fields[i];
+          for (int r = 0; r < 2; ++r)
+            if (!done[r] && d.rowid[r] < bp1_k) done[r] = true;
         }
-        uint32_t q0, q1;
-        n0 = block_scan2(s, keep[0], keep[1], q0, q1);
-        if (keep[0]) s.t0_rowid[q0] = rr[0], s.t0_acc[q0] = aa[0], s.t0_fields[q0] = ff[0];
-        if (keep[1]) s.t0_rowid[q1] = rr[1], s.t0_acc[q1] = aa[1], s.t0_fields[q1] = ff[1];
-        __syncthreads();
+        live[0] = live[0] && hit[0];
+        live[1] = live[1] && hit[1];
       }
-    }
 
-    // ---- n0 matches: weight, threshold, candidates
-    if (s.cand_n > (uint32_t)(CAND - TILE)) compact_cand(s, K, a.q_tau + item.query);
-    const uint64_t tau = s.tau;
+      // ---- matches: weight, threshold, candidates
+      const uint64_t tau = s.tau;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const uint32_t i = tid + r * WG;
-      bool push = false;
-      uint64_t key = 0;
-      if (i < n0) {
-        ++total;
-        uint32_t weight;
-        if (ranker == MRK_RANK_NONE)
-          weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
-        else {
-          // ExtRanker_WeightSum_c<BM25>, sphinxsearch.cpp:1070, 1112-1129
-          const int32_t bm = (int32_t)((s.t0_acc[i] + 0.5f) * 1000.0f);
-          const uint32_t mask = s.t0_fields[i];
-          uint32_t rank = 0;
-          if (!mask)
-            rank = 1;
-          else
-            for (uint32_t f = 0; f < nw; ++f)
-              if (mask & (1u << f)) rank += (uint32_t)s.weights[f];
-          weight = (uint32_t)bm + rank * 1000u;
+      for (int r = 0; r < 2; ++r) {
+        bool push = false;
+        uint64_t key = 0;
+        if (live[r]) {
+          ++total;
+          uint32_t weight;
+          if (ranker == MRK_RANK_NONE)
+            weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
+          else {
+            // ExtRanker_WeightSum_c<BM25>, sphinxsearch.cpp:1070, 1112-1129
+            const int32_t bm = (int32_t)((acc[r] + 0.5f) * 1000.0f);
+            const uint32_t mask = fld[r];
+            uint32_t rank = 0;
+            if (!mask)
+              rank = 1;
+            else
+              for (uint32_t f = 0; f < nw; ++f)
+                if (mask & (1u << f)) rank += (uint32_t)s.weights[f];
+            weight = (uint32_t)bm + rank * 1000u;
+          }
+          weight *= index_weight; // MatchExtended, sphinx.cpp:12220
+          key = make_key((int32_t)weight, a.seg.rowid_base + d.rowid[r]);
+          push = key >= tau;
         }
-        weight *= index_weight; // MatchExtended, sphinx.cpp:12220
-        key = make_key((int32_t)weight, a.seg.rowid_base + s.t0_rowid[i]);
-        push = key >= tau;
-      }
-      const uint64_t bal = __ballot(push);
-      if (bal) {
-        uint32_t basep = 0;
-        if (lane == 0) basep = atomicAdd(&s.cand_n, (uint32_t)__popcll(bal));
-        basep = __shfl(basep, 0, 64);
-        if (push) s.cand[basep + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+        const uint64_t bal = __ballot(push);
+        if (bal) {
+          uint32_t basep = 0;
+          if (lane == 0) basep = atomicAdd(&s.cand_n, (uint32_t)__popcll(bal));
+          basep = rdlane(basep, 0);
+          if (push) s.cand[basep + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+        }
       }
     }
     __syncthreads();
+    if (s.cand_n > (uint32_t)(CAND - WAVES * DEVBLK)) compact_cand(s, K, a.q_tau + item.query);
   }
 
   // ---- item epilogue
@@ -512,7 +569,7 @@ __global__ __launch_bounds__(WG) void scan_kernel(ScanArgs a) {
     if (lane == 0 && t) atomicAdd((unsigned long long*)(a.q_total + item.query), (unsigned long long)t);
   }
   __syncthreads();
-  // publish candidates that can still make the query's top-K
+  // publish the candidates that can still make the query's top-K
   if (tid == 0) {
     const uint64_t gt = __hip_atomic_load(a.q_tau + item.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gt > s.tau) s.tau = gt;
@@ -527,7 +584,7 @@ __global__ __launch_bounds__(WG) void scan_kernel(ScanArgs a) {
       const uint32_t i = base_i + tid;
       const bool w = i < n && s.cand[i] >= tau;
       uint32_t p0, p1;
-      const uint32_t c = block_scan2(s, w, false, p0, p1);
+      const uint32_t c = block_scan2(s.wave_cnt, w, false, p0, p1);
       if (w) dst[written + p0] = s.cand[i];
       written += c;
     }
@@ -632,7 +689,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(MergeArgs a) {
         if (bal) {
           uint32_t basep = 0;
           if (lane == 0) basep = atomicAdd(&s.cand_n, (uint32_t)__popcll(bal));
-          basep = __shfl(basep, 0, 64);
+          basep = rdlane(basep, 0);
           if (push) s.cand[basep + __popcll(bal & ((1ull << lane) - 1ull))] = key;
         }
       }
