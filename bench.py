@@ -87,6 +87,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the oracle timing sample")
     ap.add_argument("--latency-samples", type=int, default=96)
     ap.add_argument("--strata", default="cc,sc,ss", help="subset of strata to run (profiling aid; the metric uses all three)")
+    ap.add_argument("--path", type=int, default=0, help="0 = packed doclists (default), 1 = VLB-direct")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +118,7 @@ def main() -> None:
     ctx = m.Context(local_rank)
     if args.item_bytes:
         ctx.set("item_bytes", args.item_bytes)
+    ctx.set("path", args.path)
     seg = m.Segment(ctx, hi, rowid_base=rank * shard_docs)
     batch = m.Batch(ctx, args.queries)
 
@@ -152,7 +154,10 @@ def main() -> None:
                 per[s]["scan_ms"] += st["scan_ms"]
                 per[s]["merge_ms"] += st["merge_ms"]
                 per[s]["algo_bytes"] = st["algo_bytes"]
+                per[s]["dev_bytes"] = st["dev_bytes"]
+                per[s]["packed"] = st["packed"]
                 per[s]["n_items"] = st["n_items"]
+                per[s]["n_cands"] = st["n_cands"]
                 per[s]["n"] += 1
 
     def sync() -> None:
@@ -210,7 +215,8 @@ def main() -> None:
     qps = total_queries / elapsed
     cc = per["cc"]
     scan_ms = cc["scan_ms"] / max(1, cc["n"])
-    algo = cc["algo_bytes"] + out_bytes
+    # algorithmic bytes = min(reference-format bytes, device-format bytes) + 8 B per result
+    algo = min(cc["algo_bytes"], cc.get("dev_bytes", cc["algo_bytes"])) + out_bytes
     achieved = algo / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -253,12 +259,15 @@ def main() -> None:
             "traffic": traffic,
             "kernel": "scan_kernel (common x common stratum launch)",
             "algo_bytes_per_launch": int(algo),
+            "ref_format_bytes_per_launch": int(cc["algo_bytes"]),
+            "device_format_bytes_per_launch": int(cc.get("dev_bytes", 0)),
+            "device_format": "packed 128-doc blocks (bit-packed rowid deltas + tf/field bytes)" if cc.get("packed") else "reference .spd VLB",
             "launch_ms": round(scan_ms, 4),
         },
         "strata": {
             s: {"scan_ms": round(per[s]["scan_ms"] / max(1, per[s]["n"]), 4),
                 "merge_ms": round(per[s]["merge_ms"] / max(1, per[s]["n"]), 4),
-                "algo_MB": round(per[s]["algo_bytes"] / 1e6, 2), "items": per[s].get("n_items", 0)} for s in names},
+                "algo_MB": round(per[s]["algo_bytes"] / 1e6, 2), "dev_MB": round(per[s].get("dev_bytes", 0) / 1e6, 2), "items": per[s].get("n_items", 0), "cands": per[s].get("n_cands", 0)} for s in names},
         "strata_run": names,
         "p50_latency_ms": round(float(np.percentile(lat, 50)), 4) if lat else None,
         "p95_latency_ms": round(float(np.percentile(lat, 95)), 4) if lat else None,

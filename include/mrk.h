@@ -140,13 +140,18 @@ typedef struct {
   float merge_ms;         /* top-K merge kernel */
   uint64_t algo_bytes;    /* sum over queries of doclist bytes of their terms (reference format) */
   uint64_t n_items;       /* work items (workgroups) launched by the scan kernel */
+  uint64_t dev_bytes;     /* the same sum over the format the kernel actually read (packed or .spd) */
+  uint32_t packed;        /* 1 = packed-doclist path, 0 = VLB-direct path */
+  uint64_t n_cands;       /* packed path: candidates that survived in-scan pruning (all queries) */
 } mrk_batch_stats;
 
 const char* mrk_last_error(void);
 
 int mrk_ctx_create(int device, mrk_ctx** out);
 void mrk_ctx_destroy(mrk_ctx* ctx);
-/* tunables: "item_bytes" (work-item size target) ; returns MRK_E_INVAL for unknown keys */
+/* tunables: "item_bytes" (work-item size target); "pack" (1 = build packed doclists at segment
+   load, default); "path" (0 = packed when present, 1 = VLB-direct, 2 = packed only);
+   returns MRK_E_INVAL for unknown keys */
 int mrk_ctx_set(mrk_ctx* ctx, const char* key, int64_t value);
 
 int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* desc, mrk_segment** out);

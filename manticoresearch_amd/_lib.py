@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmrk.so")
+LIB_PATH = os.environ.get("MRK_LIB_PATH") or os.path.join(CSRC, "libmrk.so")  # override: kernel experiments only
 
 MRK_OK, MRK_E_INVAL, MRK_E_UNSUPPORTED, MRK_E_HIP, MRK_E_NOMEM, MRK_E_FORMAT = 0, -1, -2, -3, -4, -5
 MRK_MAX_K = 1024
@@ -56,7 +56,8 @@ class Result(C.Structure):
 
 
 class BatchStats(C.Structure):
-    _fields_ = [("scan_ms", C.c_float), ("merge_ms", C.c_float), ("algo_bytes", C.c_uint64), ("n_items", C.c_uint64)]
+    _fields_ = [("scan_ms", C.c_float), ("merge_ms", C.c_float), ("algo_bytes", C.c_uint64), ("n_items", C.c_uint64),
+                ("dev_bytes", C.c_uint64), ("packed", C.c_uint32), ("n_cands", C.c_uint64)]
 
 
 class SynthParams(C.Structure):
@@ -97,7 +98,7 @@ SYMBOLS = [
 
 def build(force: bool = False) -> str:
     """Compile libmrk.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mrk_kernels.hip", "mrk_host.cpp", "mrk_writer.cpp", "mrk_dev.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mrk_kernels.hip", "mrk_scan_pk.hip", "mrk_kcommon.h", "mrk_host.cpp", "mrk_pack.cpp", "mrk_pack.h", "mrk_writer.cpp", "mrk_dev.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mrk.h"))
     stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:

@@ -29,7 +29,20 @@ struct DevSegment {
   uint64_t spp_len;
   uint32_t rowid_base;
   uint32_t inline_hits;
+  // packed doclists (lossless load-time transcode of .spd, see mrk_pack.cpp); NULL if absent
+  const uint32_t* pk_base;  // per block: first possible rowid (= last rowid of the previous block + 1)
+  const uint32_t* pk_doff;  // per block: word offset of its bit-packed deltas in pk_delta
+  const uint8_t* pk_w;      // per block: bits per delta (0..16), or PK_WIDE for 32-bit deltas
+  const uint32_t* pk_delta; // delta arena
+  const uint32_t* pk_attr;  // per block 64 words: tf[l] | tf[l+64]<<8 | fields[l]<<16 | fields[l+64]<<24
+  const uint64_t* pk_exc;   // tf exceptions (tf >= 255): rowid<<32 | tf, sorted per term
 };
+
+constexpr uint32_t PK_WIDE = 0xFFu;
+constexpr int NBINS = 1024; // pruning histogram bins per query
+constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
+constexpr uint32_t QF_OVERFLOW = 1; // candidate list overflowed: the query's result is not trustworthy
+constexpr int MAPCAP = 4096; // direct-map probe window (rowids) per decoded block
 
 struct DevTerm {
   uint32_t blk_first; // index of the term's first block in blk_*[]
@@ -39,6 +52,8 @@ struct DevTerm {
   float idf;
   uint32_t qpos;      // atom position
   uint64_t spd_end;   // doclist_off + doclist_len
+  uint32_t exc_first; // tf exceptions of this term in pk_exc
+  uint32_t exc_n;
 };
 
 struct DevQuery {
@@ -49,7 +64,11 @@ struct DevQuery {
   uint32_t index_weight;
   uint32_t item_first;
   uint32_t n_items;
-  uint32_t pad;
+  uint32_t bin_mode;  // BIN_WEIGHT / BIN_ROWID: what the pruning histogram is keyed on
+  int32_t bin_lo;     // weight (or rowid) that maps to the edge of bin 0
+  uint32_t bin_shift;
+  uint32_t cand_cap;  // capacity of this query's candidate list
+  uint64_t cand_off;  // its offset in the candidate arena
   int32_t weights[32];
   DevTerm t[MRK_MAX_AND_TERMS];
 };
@@ -77,6 +96,23 @@ struct ScanArgs {
   uint64_t* q_total;   // [n_queries]
   uint64_t* q_tau;     // [n_queries] running K-th best key (lower bound), atomicMax
   uint32_t n_items;
+  // packed path: global pruning histograms + per-query candidate lists
+  uint32_t* q_hist;    // [n_queries][NBINS]
+  uint32_t* q_cand_n;  // [n_queries]
+  uint32_t* q_flags;   // [n_queries]
+  uint32_t* q_tau_bin; // [n_queries] running pruning threshold (bin index), atomicMax
+  uint64_t* cand;      // candidate arena
+};
+
+struct SelectArgs {
+  const DevQuery* queries;
+  const uint32_t* q_hist;
+  const uint32_t* q_cand_n;
+  const uint64_t* cand;
+  uint32_t n_queries;
+  uint32_t rowid_base;
+  uint64_t* out_keys; // [n_queries][KCAP], sorted descending
+  uint32_t* out_cnt;
 };
 
 struct MergeArgs {
@@ -93,6 +129,8 @@ struct MergeArgs {
 };
 
 void launch_scan(const ScanArgs& a, void* stream);
+void launch_scan_pk(const ScanArgs& a, void* stream);
+void launch_select(const SelectArgs& a, void* stream);
 void launch_merge(const MergeArgs& a, void* stream);
 
 } // namespace mrk

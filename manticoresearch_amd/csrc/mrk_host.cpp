@@ -10,10 +10,13 @@
 
 #include <algorithm>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mrk_dev.h"
+#include "mrk_pack.h"
 
 using namespace mrk;
 
@@ -45,11 +48,15 @@ struct mrk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   int64_t item_bytes = 128 << 10; // target doclist bytes per work item
+  int path = 0;                   // 0 = packed doclists when the segment has them, 1 = VLB (.spd) direct, 2 = packed only
+  int pack = 1;                   // build packed doclists at segment load
 };
 
 struct HostTerm {
   uint64_t doclist_off = 0, doclist_len = 0;
+  uint64_t packed_bytes = 0;
   uint32_t blk_first = 0, nblocks = 0, docs = 0, hits = 0;
+  uint32_t exc_first = 0, exc_n = 0;
 };
 
 struct mrk_segment {
@@ -64,6 +71,13 @@ struct mrk_segment {
   void* d_blk_base = nullptr;
   void* d_blk_off = nullptr;
   void* d_blk_hit = nullptr;
+  bool has_packed = false;
+  void* d_pk_base = nullptr;
+  void* d_pk_doff = nullptr;
+  void* d_pk_w = nullptr;
+  void* d_pk_delta = nullptr;
+  void* d_pk_attr = nullptr;
+  void* d_pk_exc = nullptr;
 };
 
 template <typename T>
@@ -130,11 +144,17 @@ struct mrk_batch {
   DevBuf<uint32_t> d_list_first, d_list_n, d_kq;
   DevBuf<uint64_t> d_out_keys;
   DevBuf<uint32_t> d_out_cnt;
+  // packed path: pruning histograms, candidate lists
+  DevBuf<uint32_t> d_q_hist, d_q_cand_n, d_q_flags, d_q_tau_bin;
+  PinBuf<uint32_t> h_cand_n;
+  DevBuf<uint64_t> d_cand;
+  PinBuf<uint32_t> h_flags;
   // decoded results
   std::vector<uint32_t> rowid;
   std::vector<int32_t> weight;
   std::vector<int32_t> status;
   bool decoded = false;
+  bool packed_run = false;
   hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_merge1 = nullptr;
   mrk_batch_stats stats{};
 };
@@ -174,6 +194,15 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
     c->item_bytes = value;
     return MRK_OK;
   }
+  if (!strcmp(key, "path")) {
+    if (value < 0 || value > 2) return mrk_fail(MRK_E_INVAL, "path must be 0 (auto), 1 (vlb) or 2 (packed)");
+    c->path = (int)value;
+    return MRK_OK;
+  }
+  if (!strcmp(key, "pack")) {
+    c->pack = value != 0;
+    return MRK_OK;
+  }
   return mrk_fail(MRK_E_INVAL, "mrk_ctx_set: unknown key '%s'", key);
 }
 
@@ -203,6 +232,12 @@ extern "C" void mrk_segment_destroy(mrk_segment* s) {
   if (s->d_blk_base) (void)hipFree(s->d_blk_base);
   if (s->d_blk_off) (void)hipFree(s->d_blk_off);
   if (s->d_blk_hit) (void)hipFree(s->d_blk_hit);
+  if (s->d_pk_base) (void)hipFree(s->d_pk_base);
+  if (s->d_pk_doff) (void)hipFree(s->d_pk_doff);
+  if (s->d_pk_w) (void)hipFree(s->d_pk_w);
+  if (s->d_pk_delta) (void)hipFree(s->d_pk_delta);
+  if (s->d_pk_attr) (void)hipFree(s->d_pk_attr);
+  if (s->d_pk_exc) (void)hipFree(s->d_pk_exc);
   delete s;
 }
 
@@ -293,8 +328,75 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
     }
   }
 
+  // ---- packed doclists: lossless transcode of every term's .spd run (mrk_pack.cpp)
+  std::vector<uint32_t> pk_base, pk_doff, pk_delta, pk_attr;
+  std::vector<uint8_t> pk_w;
+  std::vector<uint64_t> pk_exc;
+  bool packed = ctx->pack && d->n_fields <= 8;
+  if (packed) {
+    std::vector<PackedTerm> pt(d->n_terms);
+    std::vector<std::string> errs(d->n_terms);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    const bool inl = d->hit_format == MRK_HITFMT_INLINE;
+    unsigned nth = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    nth = (unsigned)std::min<size_t>(nth, d->n_terms ? d->n_terms : 1);
+    auto work = [&] {
+      for (;;) {
+        const size_t t = next.fetch_add(1);
+        if (t >= d->n_terms) break;
+        if (!pack_term(d->spd, d->spd_len, d->dict[t], inl, pt[t], errs[t])) bad = true;
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nth; ++i) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    if (bad) {
+      // e.g. field masks wider than 8 bits: this segment is served by the VLB path only
+      packed = false;
+    } else {
+      size_t nd = 0, ne = 0, nblk = 0;
+      for (auto& x : pt) nd += x.delta.size(), ne += x.exc.size(), nblk += x.base.size();
+      if (nblk != blk_base.size() || nd + 64 > 0xFFFFFFFFull) {
+        packed = false;
+      } else {
+        pk_base.reserve(nblk), pk_doff.reserve(nblk), pk_w.reserve(nblk);
+        pk_delta.reserve(nd + 64), pk_attr.reserve(nblk * 64), pk_exc.reserve(ne + 1);
+        for (uint32_t t = 0; t < d->n_terms; ++t) {
+          PackedTerm& x = pt[t];
+          HostTerm& h = s->terms[t];
+          h.packed_bytes = x.packed_bytes;
+          h.exc_first = (uint32_t)pk_exc.size();
+          h.exc_n = (uint32_t)x.exc.size();
+          const uint32_t dbase = (uint32_t)pk_delta.size();
+          pk_base.insert(pk_base.end(), x.base.begin(), x.base.end());
+          for (uint32_t o : x.doff) pk_doff.push_back(dbase + o);
+          pk_w.insert(pk_w.end(), x.w.begin(), x.w.end());
+          pk_delta.insert(pk_delta.end(), x.delta.begin(), x.delta.end());
+          pk_attr.insert(pk_attr.end(), x.attr.begin(), x.attr.end());
+          pk_exc.insert(pk_exc.end(), x.exc.begin(), x.exc.end());
+          x = PackedTerm();
+        }
+      }
+    }
+  }
+
   int rc;
   const size_t nb = blk_base.size();
+  if (packed) {
+    if ((rc = upload(&s->d_pk_base, pk_base.data(), pk_base.size() * 4, 64, ctx->stream)) != MRK_OK ||
+        (rc = upload(&s->d_pk_doff, pk_doff.data(), pk_doff.size() * 4, 64, ctx->stream)) != MRK_OK ||
+        (rc = upload(&s->d_pk_w, pk_w.data(), pk_w.size(), 64, ctx->stream)) != MRK_OK ||
+        (rc = upload(&s->d_pk_delta, pk_delta.data(), pk_delta.size() * 4, 1024, ctx->stream)) != MRK_OK ||
+        (rc = upload(&s->d_pk_attr, pk_attr.data(), pk_attr.size() * 4, 64, ctx->stream)) != MRK_OK ||
+        (rc = upload(&s->d_pk_exc, pk_exc.data(), pk_exc.size() * 8, 64, ctx->stream)) != MRK_OK) {
+      mrk_segment_destroy(s);
+      return rc;
+    }
+    s->has_packed = true;
+    s->device_bytes += pk_base.size() * 9 + pk_delta.size() * 4 + pk_attr.size() * 4 + pk_exc.size() * 8;
+  }
   if ((rc = upload(&s->d_spd, d->spd, d->spd_len, 64, ctx->stream)) != MRK_OK ||
       (rc = upload(&s->d_spp, d->spp, d->spp ? d->spp_len : 0, 64, ctx->stream)) != MRK_OK ||
       (rc = upload(&s->d_blk_base, blk_base.data(), nb * 4, 64, ctx->stream)) != MRK_OK ||
@@ -308,7 +410,13 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
     mrk_segment_destroy(s);
     return mrk_fail(MRK_E_HIP, "segment upload: %s", hipGetErrorString(e));
   }
-  s->device_bytes = d->spd_len + (d->spp ? d->spp_len : 0) + nb * 20 + 5 * 64;
+  s->device_bytes += d->spd_len + (d->spp ? d->spp_len : 0) + nb * 20 + 5 * 64;
+  s->dev.pk_base = (const uint32_t*)s->d_pk_base;
+  s->dev.pk_doff = (const uint32_t*)s->d_pk_doff;
+  s->dev.pk_w = (const uint8_t*)s->d_pk_w;
+  s->dev.pk_delta = (const uint32_t*)s->d_pk_delta;
+  s->dev.pk_attr = (const uint32_t*)s->d_pk_attr;
+  s->dev.pk_exc = (const uint64_t*)s->d_pk_exc;
   s->dev.spd = (const uint8_t*)s->d_spd;
   s->dev.spp = (const uint8_t*)s->d_spp;
   s->dev.blk_base = (const uint32_t*)s->d_blk_base;
@@ -355,8 +463,9 @@ struct PlanTerm {
 };
 
 // returns MRK_OK, or MRK_E_UNSUPPORTED / MRK_E_INVAL with the message set
-static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, DevQuery& dq,
-                      std::vector<DevItem>& items, uint32_t qi, uint64_t& algo_bytes) {
+static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
+                      std::vector<DevItem>& items, uint32_t qi, uint64_t& algo_bytes, uint64_t& dev_bytes,
+                      uint64_t& cand_total) {
   memset(&dq, 0, sizeof dq);
   dq.item_first = (uint32_t)items.size();
   if (!q.nodes || q.n_nodes <= 0 || q.root < 0 || q.root >= q.n_nodes) return mrk_fail(MRK_E_INVAL, "query %u: bad tree", qi);
@@ -444,7 +553,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   dq.index_weight = (uint32_t)(q.index_weight ? q.index_weight : 1);
   for (uint32_t f = 0; f < 32; ++f)
     dq.weights[f] = (q.field_weights && (int)f < q.n_weights) ? q.field_weights[f] : 1; // BindWeights default
-  uint64_t bytes = 0;
+  uint64_t bytes = 0, pbytes = 0;
   bool empty = false;
   for (int i = 0; i < n; ++i) {
     const PlanTerm& t = terms[ord[i]];
@@ -461,17 +570,74 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
     dt.idf = t.weighted_first ? t.idf : 0.0f;
     dt.qpos = (uint32_t)t.atom_pos;
     dt.spd_end = h.doclist_off + h.doclist_len;
+    dt.exc_first = h.exc_first;
+    dt.exc_n = h.exc_n;
     bytes += h.doclist_len;
+    pbytes += h.packed_bytes;
   }
   if (empty) {
     dq.n_items = 0;
     return MRK_OK;
   }
+  // pruning histogram geometry (packed path): bins must be monotone in the sorter's order
+  {
+    dq.bin_mode = BIN_WEIGHT;
+    dq.bin_lo = INT32_MIN;
+    dq.bin_shift = 31; // fallback: (almost) no pruning, always correct
+    if (ranker == MRK_RANK_NONE) {
+      // all weights equal: order is rowid ascending => bin on the (global) rowid
+      dq.bin_mode = BIN_ROWID;
+      const uint64_t max_row = (uint64_t)seg->dev.rowid_base + (seg->total_docs ? seg->total_docs : 1);
+      uint32_t sh = 0;
+      while (sh < 31 && (max_row >> sh) >= (uint64_t)NBINS) ++sh;
+      if (max_row > 0xFFFFFFFFull) sh = 22;
+      dq.bin_shift = sh;
+      dq.bin_lo = 0;
+    } else {
+      // weight = ((int)((sum tfidf + 0.5f) * 1000) + rank * 1000) * index_weight
+      double lo = 0.0, hi = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double idf = dq.t[i].idf;
+        const double a0 = idf * (1.0 / 2.2), a1 = idf;
+        lo += std::min(a0, a1);
+        hi += std::max(a0, a1);
+      }
+      const int64_t bm_lo = (int64_t)floor((lo + 0.5) * 1000.0) - 2, bm_hi = (int64_t)ceil((hi + 0.5) * 1000.0) + 2;
+      int64_t rmin = INT64_MAX, rmax = INT64_MIN;
+      const uint32_t nwf = std::min<uint32_t>(dq.n_weights, 8u);
+      for (uint32_t m = 0; m < 256; ++m) {
+        int64_t r = 0;
+        if (!m)
+          r = 1;
+        else
+          for (uint32_t f = 0; f < nwf; ++f)
+            if (m & (1u << f)) r += dq.weights[f];
+        rmin = std::min(rmin, r);
+        rmax = std::max(rmax, r);
+      }
+      const int64_t iw = (int32_t)dq.index_weight;
+      const int64_t c[4] = {(bm_lo + rmin * 1000) * iw, (bm_lo + rmax * 1000) * iw, (bm_hi + rmin * 1000) * iw,
+                            (bm_hi + rmax * 1000) * iw};
+      const int64_t wlo = *std::min_element(c, c + 4), whi = *std::max_element(c, c + 4);
+      if (wlo > INT32_MIN && whi < INT32_MAX && std::llabs(rmin * 1000) < INT32_MAX && std::llabs(rmax * 1000) < INT32_MAX) {
+        const uint64_t span = (uint64_t)(whi - wlo) + 1;
+        uint32_t sh = 0;
+        while (sh < 31 && ((span - 1) >> sh) >= (uint64_t)NBINS) ++sh;
+        dq.bin_lo = (int32_t)wlo;
+        dq.bin_shift = sh;
+      }
+    }
+    const uint64_t cap = std::min<uint64_t>(dq.t[0].docs, (uint64_t)1 << 20);
+    dq.cand_cap = (uint32_t)cap;
+    dq.cand_off = cand_total;
+    cand_total += cap;
+  }
   algo_bytes += bytes;
+  dev_bytes += use_packed ? pbytes : bytes;
 
   // work items: contiguous ranges of driver-term blocks, ~item_bytes of doclist each
   const uint32_t nb0 = dq.t[0].nblocks;
-  const double per_block = (double)bytes / (double)nb0;
+  const double per_block = (double)(use_packed ? pbytes : bytes) / (double)nb0;
   uint64_t bpi = (uint64_t)((double)item_bytes / per_block);
   bpi = std::max<uint64_t>(T0_BLOCKS, (bpi / T0_BLOCKS) * T0_BLOCKS);
   for (uint64_t b = 0; b < nb0; b += bpi) {
@@ -511,6 +677,13 @@ extern "C" void mrk_batch_destroy(mrk_batch* b) {
   b->d_kq.release();
   b->d_out_keys.release();
   b->d_out_cnt.release();
+  b->d_q_hist.release();
+  b->d_q_cand_n.release();
+  b->d_q_flags.release();
+  b->d_q_tau_bin.release();
+  b->h_cand_n.release();
+  b->d_cand.release();
+  b->h_flags.release();
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
   if (b->ev_scan1) (void)hipEventDestroy(b->ev_scan1);
   if (b->ev_merge1) (void)hipEventDestroy(b->ev_merge1);
@@ -530,7 +703,9 @@ extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** 
       (rc = b->h_kq.reserve(nq)) || (rc = b->h_keys.reserve(nq * KCAP)) || (rc = b->h_cnt.reserve(nq)) ||
       (rc = b->h_total.reserve(nq)) || (rc = b->d_queries.reserve(nq)) || (rc = b->d_q_total.reserve(nq)) ||
       (rc = b->d_q_tau.reserve(nq)) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
-      (rc = b->d_kq.reserve(nq)) || (rc = b->d_out_keys.reserve(nq * KCAP)) || (rc = b->d_out_cnt.reserve(nq))) {
+      (rc = b->d_kq.reserve(nq)) || (rc = b->d_out_keys.reserve(nq * KCAP)) || (rc = b->d_out_cnt.reserve(nq)) ||
+      (rc = b->d_q_hist.reserve(nq * NBINS)) || (rc = b->d_q_cand_n.reserve(nq)) || (rc = b->d_q_flags.reserve(nq)) ||
+      (rc = b->h_flags.reserve(nq)) || (rc = b->d_q_tau_bin.reserve(nq)) || (rc = b->h_cand_n.reserve(nq))) {
     mrk_batch_destroy(b);
     return rc;
   }
@@ -563,9 +738,12 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   // ---- plan
   std::vector<DevItem> items;
   items.reserve(n * 4);
-  uint64_t algo_bytes = 0;
+  uint64_t algo_bytes = 0, dev_bytes = 0, cand_total = 0;
+  if (b->ctx->path == 2 && !seg->has_packed) return mrk_fail(MRK_E_UNSUPPORTED, "path=packed but the segment has no packed doclists");
+  const bool use_packed = seg->has_packed && b->ctx->path != 1;
   for (uint32_t i = 0; i < n; ++i) {
-    int rc = plan_query(seg, queries[i], b->ctx->item_bytes, b->h_queries.p[i], items, i, algo_bytes);
+    int rc = plan_query(seg, queries[i], b->ctx->item_bytes, use_packed, b->h_queries.p[i], items, i, algo_bytes, dev_bytes,
+                        cand_total);
     b->status[i] = rc;
     if (rc == MRK_E_INVAL) return rc;
     if (rc != MRK_OK) { // unsupported: reported per query, runs no device work
@@ -578,12 +756,15 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   }
   const size_t n_items = items.size();
   b->stats.algo_bytes = algo_bytes;
+  b->stats.dev_bytes = dev_bytes;
+  b->stats.packed = use_packed ? 1 : 0;
   b->stats.n_items = n_items;
   int rc;
   if ((rc = b->h_items.reserve(n_items + 1)) || (rc = b->d_items.reserve(n_items + 1)) ||
       (rc = b->d_item_cand.reserve((n_items + 1) * KCAP)) || (rc = b->d_item_cnt.reserve(n_items + 1)))
     return rc;
   if (n_items) memcpy(b->h_items.p, items.data(), n_items * sizeof(DevItem));
+  if (use_packed && (rc = b->d_cand.reserve(cand_total + 64))) return rc;
 
   // ---- copy descriptors, launch
   HIP_TRY(hipMemcpyAsync(b->d_queries.p, b->h_queries.p, n * sizeof(DevQuery), hipMemcpyHostToDevice, st));
@@ -593,6 +774,12 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   HIP_TRY(hipMemcpyAsync(b->d_kq.p, b->h_kq.p, n * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(b->d_q_total.p, 0, n * 8, st));
   HIP_TRY(hipMemsetAsync(b->d_q_tau.p, 0, n * 8, st));
+  if (use_packed) {
+    HIP_TRY(hipMemsetAsync(b->d_q_hist.p, 0, (size_t)n * NBINS * 4, st));
+    HIP_TRY(hipMemsetAsync(b->d_q_cand_n.p, 0, n * 4, st));
+    HIP_TRY(hipMemsetAsync(b->d_q_flags.p, 0, n * 4, st));
+    HIP_TRY(hipMemsetAsync(b->d_q_tau_bin.p, 0, n * 4, st));
+  }
 
   ScanArgs sa{};
   sa.seg = seg->dev;
@@ -603,8 +790,16 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   sa.q_total = b->d_q_total.p;
   sa.q_tau = b->d_q_tau.p;
   sa.n_items = (uint32_t)n_items;
+  sa.q_hist = b->d_q_hist.p;
+  sa.q_cand_n = b->d_q_cand_n.p;
+  sa.q_flags = b->d_q_flags.p;
+  sa.q_tau_bin = b->d_q_tau_bin.p;
+  sa.cand = b->d_cand.p;
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
-  launch_scan(sa, st);
+  if (use_packed)
+    launch_scan_pk(sa, st);
+  else
+    launch_scan(sa, st);
   HIP_TRY(hipEventRecord(b->ev_scan1, st));
 
   MergeArgs ma{};
@@ -618,9 +813,26 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   ma.k = KCAP;
   ma.out_keys = b->d_out_keys.p;
   ma.out_cnt = b->d_out_cnt.p;
-  launch_merge(ma, st);
+  if (use_packed) {
+    SelectArgs se{};
+    se.queries = b->d_queries.p;
+    se.q_hist = b->d_q_hist.p;
+    se.q_cand_n = b->d_q_cand_n.p;
+    se.cand = b->d_cand.p;
+    se.n_queries = n;
+    se.rowid_base = seg->dev.rowid_base;
+    se.out_keys = b->d_out_keys.p;
+    se.out_cnt = b->d_out_cnt.p;
+    launch_select(se, st);
+  } else
+    launch_merge(ma, st);
   HIP_TRY(hipEventRecord(b->ev_merge1, st));
   HIP_TRY(hipGetLastError());
+  b->packed_run = use_packed;
+  if (use_packed) {
+    HIP_TRY(hipMemcpyAsync(b->h_flags.p, b->d_q_flags.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b->h_cand_n.p, b->d_q_cand_n.p, n * 4, hipMemcpyDeviceToHost, st));
+  }
 
   // ---- results to pinned host memory
   HIP_TRY(hipMemcpyAsync(b->h_cnt.p, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToHost, st));
@@ -639,6 +851,15 @@ extern "C" int mrk_batch_wait(mrk_batch* b) {
   float ms = 0;
   if (hipEventElapsedTime(&ms, b->ev_scan0, b->ev_scan1) == hipSuccess) b->stats.scan_ms = ms;
   if (hipEventElapsedTime(&ms, b->ev_scan1, b->ev_merge1) == hipSuccess) b->stats.merge_ms = ms;
+  b->stats.n_cands = 0;
+  if (b->packed_run)
+    for (uint32_t i = 0; i < b->n_queries; ++i) b->stats.n_cands += b->h_cand_n.p[i];
+  if (b->packed_run)
+    for (uint32_t i = 0; i < b->n_queries; ++i)
+      if (b->status[i] == MRK_OK && (b->h_flags.p[i] & QF_OVERFLOW)) {
+        // never hand back a silently truncated result
+        b->status[i] = mrk_fail(MRK_E_UNSUPPORTED, "query %u: candidate list overflowed (%u slots); rerun with path=1", i, 1u << 20);
+      }
   return MRK_OK;
 }
 

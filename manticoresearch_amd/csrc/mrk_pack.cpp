@@ -1,0 +1,145 @@
+// mrk_pack.cpp -- lossless load-time transcode of a reference-format doclist (.spd, VLB
+// varints: DiskIndexQword_c::ReadNext, sphinx.cpp:511-549) into the device's packed blocks.
+//
+// Per block of 128 docs (the last one may be short):
+//   base   first possible rowid = rowid of the previous block's last doc + 1 (0 for block 0);
+//          same meaning as SkiplistEntry_t::m_tBaseRowIDPlus1
+//   deltas d[0] = rowid[0] - base, d[i] = rowid[i] - rowid[i-1] - 1, packed with w = bits(max d)
+//          bits each in lane order: value slot 2*l + r holds doc l + 64*r, so lane l finds both
+//          of its docs in one 2w-bit field; w > 16 => two planes of plain 32-bit deltas
+//   attrs  one word per lane: tf[l] | tf[l+64] << 8 | fields[l] << 16 | fields[l+64] << 24
+//          (tf >= 255 is stored as 255 and listed in the term's exception array; needs <= 8 fields)
+// rowid[i] = base + i + sum(d[0..i]).  Everything the BM25 / NONE rankers read survives
+// exactly: rowid, hit count, low field-mask bits.
+#include "mrk_pack.h"
+
+#include <string.h>
+
+namespace mrk {
+
+namespace {
+struct Rd {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  uint64_t vlb() {
+    uint64_t v = 0;
+    for (;;) {
+      if (p >= end) {
+        ok = false;
+        return 0;
+      }
+      const uint32_t b = *p++;
+      v = (v << 7) + (b & 0x7f);
+      if (!(b & 0x80)) return v;
+    }
+  }
+};
+} // namespace
+
+bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, PackedTerm& out,
+               std::string& err) {
+  out = PackedTerm();
+  if (!e.docs) return true;
+  if (e.doclist_off == 0 || e.doclist_off + e.doclist_len > spd_len) {
+    err = "doclist outside .spd";
+    return false;
+  }
+  Rd rd{spd + e.doclist_off, spd + e.doclist_off + e.doclist_len};
+  const uint32_t nd_total = e.docs;
+  const uint32_t nblk = (nd_total + 127) / 128;
+  out.base.reserve(nblk);
+  out.doff.reserve(nblk);
+  out.w.reserve(nblk);
+  out.attr.assign((size_t)nblk * 64, 0);
+  out.delta.reserve((size_t)nblk * 32 + 8);
+
+  uint32_t rowid = 0xFFFFFFFFu; // decoder starts at INVALID_ROWID (sphinx.cpp:12947)
+  uint32_t d[128], tf[128], fl[128], rows[128];
+  for (uint32_t b = 0; b < nblk; ++b) {
+    const uint32_t n = nd_total - b * 128 < 128 ? nd_total - b * 128 : 128;
+    const uint32_t base = rowid + 1u;
+    uint32_t dmax = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t delta = (uint32_t)rd.vlb();
+      if (!rd.ok || delta == 0) {
+        err = "doclist shorter than the dictionary's doc count";
+        return false;
+      }
+      const uint32_t prev = rowid;
+      rowid += delta;
+      if (prev != 0xFFFFFFFFu && rowid <= prev) {
+        err = "rowids do not ascend";
+        return false;
+      }
+      uint32_t hits, fields;
+      if (inline_hits) {
+        hits = (uint32_t)rd.vlb();
+        const uint32_t first = (uint32_t)rd.vlb();
+        if (hits == 1) {
+          const uint32_t fe = (uint32_t)rd.vlb();
+          const uint32_t f = (fe >> 1) & 255u;
+          fields = f < 32 ? (1u << f) : 0u;
+        } else {
+          fields = first;
+          (void)rd.vlb(); // hitlist offset delta
+        }
+      } else {
+        (void)rd.vlb();
+        fields = (uint32_t)rd.vlb();
+        hits = (uint32_t)rd.vlb();
+      }
+      if (!rd.ok) {
+        err = "truncated doclist entry";
+        return false;
+      }
+      if (fields > 0xFFu) {
+        err = "field mask wider than 8 bits";
+        return false;
+      }
+      rows[i] = rowid;
+      d[i] = i == 0 ? rowid - base : rowid - prev - 1u;
+      if (d[i] > dmax) dmax = d[i];
+      tf[i] = hits;
+      fl[i] = fields;
+      if (hits >= 255) out.exc.push_back(((uint64_t)rowid << 32) | hits);
+    }
+    for (uint32_t i = n; i < 128; ++i) d[i] = 0, tf[i] = 0, fl[i] = 0;
+    uint32_t w = 0;
+    while (w < 32 && (dmax >> w)) ++w;
+    out.base.push_back(base);
+    out.doff.push_back((uint32_t)out.delta.size());
+    uint32_t* attr = out.attr.data() + (size_t)b * 64;
+    for (uint32_t l = 0; l < 64; ++l) {
+      const uint32_t t0 = tf[l] < 255 ? tf[l] : 255, t1 = tf[l + 64] < 255 ? tf[l + 64] : 255;
+      attr[l] = t0 | (t1 << 8) | (fl[l] << 16) | (fl[l + 64] << 24);
+    }
+    if (w <= 16) {
+      out.w.push_back((uint8_t)w);
+      const uint32_t words = 4 * w + 1; // 128*w bits + one spare word for the 2-word window read
+      const size_t at = out.delta.size();
+      out.delta.resize(at + words, 0);
+      uint32_t* dst = out.delta.data() + at;
+      for (uint32_t l = 0; l < 64; ++l)
+        for (uint32_t r = 0; r < 2; ++r) {
+          const uint64_t bit = (uint64_t)(2 * l + r) * w;
+          const uint64_t v = (uint64_t)d[l + 64 * r] << (bit & 31);
+          dst[bit >> 5] |= (uint32_t)v;
+          if (v >> 32) dst[(bit >> 5) + 1] |= (uint32_t)(v >> 32);
+        }
+    } else {
+      out.w.push_back((uint8_t)0xFF);
+      const size_t at = out.delta.size();
+      out.delta.resize(at + 128, 0);
+      memcpy(out.delta.data() + at, d, 128 * 4);
+    }
+  }
+  if (rd.vlb() != 0 || !rd.ok) {
+    err = "doclist longer than the dictionary's doc count";
+    return false;
+  }
+  out.packed_bytes = out.delta.size() * 4 + out.attr.size() * 4 + (uint64_t)nblk * 9;
+  return true;
+}
+
+} // namespace mrk

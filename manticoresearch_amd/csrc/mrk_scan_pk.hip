@@ -1,0 +1,552 @@
+// mrk_scan_pk.hip -- scan kernel over PACKED doclists (mrk_pack.cpp), gfx950 / wave64.
+//
+// Same work decomposition and semantics as scan_kernel (mrk_kernels.hip): one workgroup per
+// (query, range of driver-term blocks), each wave streams its own run of driver blocks against
+// the other terms' blocks, results go through the workgroup's top-K buffer.  What changes is the
+// per-block cost: a block's rowids come out of one bit-field extract + two wave prefix sums
+// (no byte-stream parsing), tf / field bits arrive pre-split in one word per lane, probing uses
+// a direct rowid -> slot map in LDS, and per-term tfidf(tf) and per-mask field-weight sums are
+// table lookups filled once per workgroup with the reference's exact fp32 ops
+// (searchnode.cpp:2828, sphinxsearch.cpp:1112-1129).  No MFMA: integer streaming work.
+#include "mrk_kcommon.h"
+
+#ifndef MRK_EXP
+#define MRK_EXP 0
+#endif
+
+namespace mrk {
+
+constexpr int CBUF = 256; // candidates a wave collects before it publishes them
+
+struct __align__(16) PkWaveLds {
+  uint64_t cbuf[CBUF];  // candidates not yet published to the query's global list
+  uint32_t hist[NBINS]; // scratch for publishing: per-bin counts of the candidates being flushed
+  uint32_t tj_rowid[DEVBLK];
+  uint32_t tj_attr[64];
+  uint8_t map[MAPCAP];
+};
+
+struct __align__(16) PkSmem {
+  PkWaveLds w[WAVES];
+  float tfidf[MRK_MAX_AND_TERMS][256];
+  uint32_t rank[256];
+};
+
+// Pruning bin of a match: monotone non-decreasing in the sorter's order (weight, then lower
+// rowid), so "K matches already sit in higher bins" proves a match cannot reach the top K.
+__device__ __forceinline__ uint32_t bin_of(uint32_t mode, int32_t lo, uint32_t shift, int32_t weight, uint32_t grow) {
+  if (mode == BIN_WEIGHT) {
+    if (weight < lo) return 0u;
+    const uint32_t b = (uint32_t)(weight - lo) >> shift;
+    return b < (uint32_t)NBINS ? b : (uint32_t)NBINS - 1u;
+  }
+  const uint32_t b = grow >> shift;
+  return (uint32_t)NBINS - 1u - (b < (uint32_t)NBINS ? b : (uint32_t)NBINS - 1u);
+}
+
+// Largest bin b with sum(hist[b..]) >= k (0 if the whole histogram holds fewer than k).
+// The histogram is read quarter by quarter from the top, lane l taking 4 consecutive bins of
+// each quarter (coalesced 1 KiB per quarter, L1 bypassed so other CUs' adds are seen).
+__device__ uint32_t threshold_bin(const uint32_t* __restrict__ gh, uint32_t k) {
+  const uint32_t lane = lane_id();
+  uint32_t acc = 0;
+  for (int qd = NBINS / 256 - 1; qd >= 0; --qd) {
+    const uint32_t* p = gh + 256 * qd + 4 * lane;
+    const uint32_t g0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t g1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t g2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t g3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t sum = g0 + g1 + g2 + g3;
+    const uint32_t pre = wave_incl_scan(sum);
+    const uint32_t tot = rdlane(pre, 63);
+    if (acc + tot >= k) { // the threshold lies in this quarter
+      const uint32_t above = acc + tot - pre; // everything above my 4 bins
+      const uint64_t okl = __ballot(above + sum >= k);
+      const uint32_t L = 63u - (uint32_t)__builtin_clzll(okl | 1ull);
+      uint32_t run = above + g3, bi = 3;
+      if (run < k) run += g2, bi = 2;
+      if (run < k && bi == 2) run += g1, bi = 1;
+      if (run < k && bi == 1) bi = 0;
+      return 256u * (uint32_t)qd + 4u * L + rdlane(bi, L);
+    }
+    acc += tot;
+  }
+  return 0u;
+}
+
+// add this wave's per-bin counts to the query's global histogram and clear them
+__device__ __forceinline__ void flush_hist(uint32_t* lh, uint32_t* gh) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t b = 16 * lane + (uint32_t)i;
+    const uint32_t c = lh[b];
+    if (c) {
+      atomicAdd(gh + b, c);
+      lh[b] = 0;
+    }
+  }
+}
+
+struct PkChunk {
+  uint32_t first; // block index (within the term) held by lane 0
+  uint32_t bp1;   // first possible rowid of block first+lane (INF past the end)
+  uint32_t doff;  // word offset of its deltas
+  uint32_t w;     // bits per delta / PK_WIDE
+};
+
+__device__ __forceinline__ void load_pk_chunk(PkChunk& c, const DevSegment& seg, const DevTerm& T, uint32_t first) {
+  const uint32_t i = first + lane_id();
+  c.first = first;
+  if (i < T.nblocks) {
+    const uint32_t g = T.blk_first + i;
+    c.bp1 = seg.pk_base[g];
+    c.doff = seg.pk_doff[g];
+    c.w = seg.pk_w[g];
+  } else {
+    c.bp1 = INF_ROWID;
+    c.doff = 0;
+    c.w = 0;
+  }
+}
+
+struct PkRaw {
+  uint32_t lo, hi, attr;
+};
+
+// a block's words for this lane, straight into registers (issued early, used late)
+__device__ __forceinline__ PkRaw issue_pk(const DevSegment& seg, const DevTerm& T, const PkChunk& c, uint32_t ci) {
+  const uint32_t lane = lane_id();
+  const uint32_t w = rdlane(c.w, ci);
+  const uint32_t* __restrict__ dp = seg.pk_delta + rdlane(c.doff, ci);
+  PkRaw r;
+  if (w == PK_WIDE) {
+    r.lo = dp[lane];
+    r.hi = dp[64 + lane];
+  } else {
+    const uint32_t wi = (lane * 2 * w) >> 5;
+    r.lo = dp[wi];
+    r.hi = dp[wi + 1];
+  }
+  r.attr = seg.pk_attr[(uint64_t)(T.blk_first + c.first + ci) * 64 + lane];
+  return r;
+}
+
+// rowids of the block's docs lane and lane+64
+__device__ __forceinline__ void decode_pk(const PkRaw& raw, uint32_t w, uint32_t bp1, uint32_t nd, uint32_t& r0, uint32_t& r1,
+                                          bool& ok0, bool& ok1) {
+  const uint32_t lane = lane_id();
+  uint32_t d0, d1;
+  if (w == PK_WIDE) {
+    d0 = raw.lo;
+    d1 = raw.hi;
+  } else {
+    const uint32_t f = __builtin_amdgcn_alignbit(raw.hi, raw.lo, (lane * 2 * w) & 31u);
+    const uint32_t mask = (1u << w) - 1u;
+    d0 = f & mask;
+    d1 = (f >> w) & mask;
+  }
+  ok0 = lane < nd;
+  ok1 = lane + 64 < nd;
+  const uint32_t s0 = wave_incl_scan(ok0 ? d0 : 0u);
+  const uint32_t tot0 = rdlane(s0, 63);
+  const uint32_t s1 = wave_incl_scan(ok1 ? d1 : 0u);
+  r0 = bp1 + s0 + lane;
+  r1 = bp1 + tot0 + s1 + 64u + lane;
+}
+
+// exact hit count of a doc whose packed tf saturated (>= 255)
+__device__ uint32_t exc_tf(const DevSegment& seg, const DevTerm& T, uint32_t rowid) {
+  const uint64_t* __restrict__ e = seg.pk_exc + T.exc_first;
+  uint32_t lo = 0, hi = T.exc_n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((uint32_t)(e[mid] >> 32) < rowid)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo < T.exc_n && (uint32_t)(e[lo] >> 32) == rowid) return (uint32_t)e[lo];
+  return 255u;
+}
+
+__global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
+  __shared__ PkSmem s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (blockIdx.x >= a.n_items) return;
+  const DevItem item = a.items[blockIdx.x];
+  const DevQuery* __restrict__ Q = a.queries + item.query;
+  const uint32_t nterms = Q->n_terms, K = Q->k, ranker = Q->ranker;
+  const uint32_t nw = Q->n_weights < 8u ? Q->n_weights : 8u;
+  const uint32_t index_weight = Q->index_weight;
+  const DevTerm T0 = Q->t[0];
+  PkWaveLds& L = s.w[wave];
+  // per-workgroup tables: tfidf(tf) per term, field-weight sum per mask
+  for (uint32_t j = 0; j < nterms; ++j) s.tfidf[j][tid] = term_tfidf(tid, Q->t[j].idf);
+  {
+    uint32_t rk = 0;
+    if (!tid)
+      rk = 1; // empty mask: "just fake it" (sphinxsearch.cpp:1114-1118)
+    else
+      for (uint32_t f = 0; f < nw; ++f)
+        if (tid & (1u << f)) rk += (uint32_t)Q->weights[f];
+    s.rank[tid] = rk;
+  }
+  for (uint32_t i = lane; i < (uint32_t)NBINS; i += 64) L.hist[i] = 0;
+  const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
+  const int32_t bin_lo = Q->bin_lo;
+  const uint32_t cand_cap = Q->cand_cap;
+  uint64_t* __restrict__ cand = a.cand + Q->cand_off;
+  uint32_t* __restrict__ ghist = a.q_hist + (uint64_t)item.query * NBINS;
+  uint32_t* __restrict__ gcount = a.q_cand_n + item.query;
+  uint32_t* __restrict__ gtaubin = a.q_tau_bin + item.query;
+  const uint32_t nb = item.blk_end - item.blk_begin;
+  const uint32_t per = (nb + WAVES - 1) / WAVES;
+  const uint32_t wb0 = item.blk_begin + wave * per;
+  const uint32_t wb1 = wb0 + per < item.blk_end ? wb0 + per : item.blk_end;
+
+  uint32_t total = 0;
+  PkChunk c0, cj;
+  cj.first = NOBLK;
+  uint32_t cj_term = 0, slot_blk = NOBLK, slot_term = 0, kj = 0;
+  bool slot_map = false;
+  // register rings of blocks whose words are in flight (deep prefetch = memory-level parallelism):
+  // driver term: blocks b .. b+3 ; other term: blocks pf_first .. pf_first+pf_n-1
+  const PkRaw zraw{0, 0, 0};
+  PkRaw d0 = zraw, d1 = zraw, d2 = zraw, d3 = zraw;
+  uint32_t dw0 = 0, dw1 = 0, dw2 = 0, dw3 = 0;     // their bit widths
+  uint32_t dbp0 = 0, dbp1 = 0, dbp2 = 0, dbp3 = 0; // and bases
+  // other term: a burst of up to 8 consecutive blocks requested back to back (hipcc drains the
+  // whole VMEM queue at the first use, so one round trip is paid per burst, not per block)
+  PkRaw q0r = zraw, q1r = zraw, q2r = zraw, q3r = zraw, q4r = zraw, q5r = zraw, q6r = zraw, q7r = zraw;
+  uint32_t bq_first = 0, bq_n = 0, last_dec = NOBLK;
+  uint32_t gt_new = 0;
+  auto issue_drv = [&](uint32_t blk, PkRaw& r, uint32_t& w, uint32_t& bp) {
+    if (blk < wb1) {
+      if (blk < c0.first || blk - c0.first >= (uint32_t)CHUNK) load_pk_chunk(c0, a.seg, T0, blk);
+      const uint32_t ci = blk - c0.first;
+      r = issue_pk(a.seg, T0, c0, ci);
+      w = rdlane(c0.w, ci);
+      bp = rdlane(c0.bp1, ci);
+    }
+  };
+  c0.first = NOBLK;
+  if (wb0 < wb1) {
+    load_pk_chunk(c0, a.seg, T0, wb0);
+    issue_drv(wb0, d0, dw0, dbp0);
+    issue_drv(wb0 + 1, d1, dw1, dbp1);
+    issue_drv(wb0 + 2, d2, dw2, dbp2);
+    issue_drv(wb0 + 3, d3, dw3, dbp3);
+  }
+  __syncthreads(); // tables ready; from here on the waves never meet again
+  uint32_t tau_bin = 0, cn = 0, flush_at = 64;
+
+  // publish the wave's buffered candidates: reserve a slice of the query's list with ONE atomic,
+  // write it coalesced, add the per-bin counts to the global histogram, re-read the threshold
+  auto publish = [&]() {
+    if (cn) {
+      uint32_t basep = 0;
+      if (lane == 0) basep = atomicAdd(gcount, cn);
+      basep = rdlane(basep, 0);
+      const bool fits = basep + cn <= cand_cap;
+      const uint32_t npub = cn;
+      wave_lds_fence();
+      for (uint32_t i = lane; i < cn; i += 64) {
+        const uint64_t key = L.cbuf[i];
+        if (fits) cand[basep + i] = key;
+        atomicAdd(&L.hist[bin_of(bin_mode, bin_lo, bin_shift, key_weight(key), key_rowid(key))], 1u);
+      }
+      if (!fits && lane == 0) atomicOr(a.q_flags + item.query, QF_OVERFLOW);
+      wave_lds_fence();
+#if MRK_EXP != 4
+      flush_hist(L.hist, ghist);
+#endif
+      cn = 0;
+      // recompute the query's threshold from the merged histogram and share it (one word)
+      // Recomputing the threshold reads the whole (hot) histogram: only the publisher whose slice
+      // crosses a 2048-candidate boundary of the query's list does it, and shares the result.
+      if ((basep >> 11) != ((basep + npub) >> 11) || basep == 0) {
+        const uint32_t tb = threshold_bin(ghist, K);
+        if (tb > tau_bin) {
+          tau_bin = tb;
+          if (lane == 0) atomicMax(gtaubin, tb);
+        }
+      }
+    }
+    const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gt > tau_bin) tau_bin = gt;
+  };
+
+  for (uint32_t b = wb0; b < wb1; ++b) {
+    {
+
+      // ---- driver block b: its words were requested 4 blocks ago; rotate the ring, request b+4
+      const uint32_t w0 = dw0, bp0 = dbp0;
+      const uint32_t left0 = T0.docs - b * DEVBLK;
+      const PkRaw cur0 = d0;
+      d0 = d1, dw0 = dw1, dbp0 = dbp1;
+      d1 = d2, dw1 = dw2, dbp1 = dbp2;
+      d2 = d3, dw2 = dw3, dbp2 = dbp3;
+      issue_drv(b + 4, d3, dw3, dbp3);
+      uint32_t row[2];
+      bool ok[2];
+      decode_pk(cur0, w0, bp0, left0 < (uint32_t)DEVBLK ? left0 : (uint32_t)DEVBLK, row[0], row[1], ok[0], ok[1]);
+
+      uint32_t fld[2];
+      float acc[2];
+      bool live[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const uint32_t tf = (cur0.attr >> (8 * r)) & 0xffu;
+        fld[r] = (cur0.attr >> (16 + 8 * r)) & 0xffu & T0.queried32; // FitsFields
+        live[r] = ok[r] && fld[r] != 0;
+        float t = s.tfidf[0][tf];
+        if (tf == 255u && live[r]) t = term_tfidf(exc_tf(a.seg, T0, row[r]), T0.idf);
+        acc[r] = 0.0f + t;
+      }
+
+      // ---- the other terms, in ascending-docs order
+#if MRK_EXP == 2
+      for (uint32_t j = 1; j < 1; ++j) {
+#else
+      for (uint32_t j = 1; j < nterms; ++j) {
+#endif
+        if (!__ballot(live[0] || live[1])) break;
+        const DevTerm Tj = Q->t[j];
+        bool done[2] = {!live[0], !live[1]};
+        bool hit[2] = {false, false};
+        if (cj_term != j) {
+          cj_term = j;
+          kj = 0;
+          cj.first = NOBLK;
+          bq_n = 0;
+          last_dec = NOBLK;
+        }
+        for (;;) {
+          // smallest driver rowid still waiting for this term (docs are in rowid order lane by lane)
+          const uint64_t p0 = __ballot(!done[0]), p1 = __ballot(!done[1]);
+          if (!(p0 | p1)) break;
+          const uint32_t r_min = p0 ? rdlane(row[0], (uint32_t)__builtin_ctzll(p0)) : rdlane(row[1], (uint32_t)__builtin_ctzll(p1));
+          // its block: the last one whose base <= r_min (HintRowID's FindSpan), never behind the cursor
+          if (cj.first == NOBLK || kj < cj.first || kj - cj.first >= (uint32_t)CHUNK) load_pk_chunk(cj, a.seg, Tj, kj);
+          {
+            const uint64_t le = __ballot(cj.bp1 <= r_min);
+            uint32_t p = le ? 63u - (uint32_t)__builtin_clzll(le) : 0u;
+            if (p >= (uint32_t)CHUNK) { // beyond this chunk: wave-wide 64-ary search, then reload
+              kj = wave_find_block(a.seg.pk_base + Tj.blk_first, cj.first + CHUNK - 1, Tj.nblocks, r_min);
+              load_pk_chunk(cj, a.seg, Tj, kj);
+              p = 0;
+            }
+            const uint32_t k_new = cj.first + p;
+            if (k_new > kj) kj = k_new;
+          }
+          const uint32_t ci = kj - cj.first;
+          const uint32_t bp1_k = rdlane(cj.bp1, ci), bp1_n = rdlane(cj.bp1, ci + 1);
+          if (slot_blk != kj || slot_term != j) {
+            if (!(bq_n && kj >= bq_first && kj - bq_first < bq_n)) {
+              // sequential access bets on 8 blocks, a jump on 2
+              const uint32_t want = (last_dec == NOBLK || last_dec + 1 == kj) ? 8u : 2u;
+              uint32_t nbq = Tj.nblocks - kj;
+              if (nbq > want) nbq = want;
+              if (nbq > (uint32_t)CHUNK - ci) nbq = (uint32_t)CHUNK - ci;
+              bq_first = kj;
+              bq_n = nbq;
+              q0r = issue_pk(a.seg, Tj, cj, ci);
+              if (nbq > 1) q1r = issue_pk(a.seg, Tj, cj, ci + 1);
+              if (nbq > 2) q2r = issue_pk(a.seg, Tj, cj, ci + 2);
+              if (nbq > 3) q3r = issue_pk(a.seg, Tj, cj, ci + 3);
+              if (nbq > 4) q4r = issue_pk(a.seg, Tj, cj, ci + 4);
+              if (nbq > 5) q5r = issue_pk(a.seg, Tj, cj, ci + 5);
+              if (nbq > 6) q6r = issue_pk(a.seg, Tj, cj, ci + 6);
+              if (nbq > 7) q7r = issue_pk(a.seg, Tj, cj, ci + 7);
+              // the shared threshold word rides along with the burst
+              gt_new = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            last_dec = kj;
+            PkRaw rj;
+            switch (kj - bq_first) {
+              case 0: rj = q0r; break;
+              case 1: rj = q1r; break;
+              case 2: rj = q2r; break;
+              case 3: rj = q3r; break;
+              case 4: rj = q4r; break;
+              case 5: rj = q5r; break;
+              case 6: rj = q6r; break;
+              default: rj = q7r; break;
+            }
+            const uint32_t wj = rdlane(cj.w, ci);
+            const uint32_t leftj = Tj.docs - kj * DEVBLK;
+            const uint32_t ndj = leftj < (uint32_t)DEVBLK ? leftj : (uint32_t)DEVBLK;
+            uint32_t e0, e1;
+            bool k0, k1;
+            decode_pk(rj, wj, bp1_k, ndj, e0, e1, k0, k1);
+            // rowid window the block covers; small enough => direct map
+            const uint32_t last = ndj > 64 ? rdlane(e1, ndj - 65) : rdlane(e0, ndj - 1);
+            slot_map = last - bp1_k < (uint32_t)MAPCAP;
+            L.tj_rowid[lane] = k0 ? e0 : INF_ROWID;
+            L.tj_rowid[lane + 64] = k1 ? e1 : INF_ROWID;
+            L.tj_attr[lane] = rj.attr;
+            if (slot_map) {
+              if (k0) L.map[e0 - bp1_k] = (uint8_t)lane;
+              if (k1) L.map[e1 - bp1_k] = (uint8_t)(lane + 64);
+            }
+            slot_blk = kj;
+            slot_term = j;
+            wave_lds_fence();
+          }
+          // probe: driver docs that fall into [bp1_k, bp1_n)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            if (!done[r] && row[r] >= bp1_k && row[r] < bp1_n) {
+              done[r] = true;
+              const uint32_t rowid = row[r];
+              uint32_t pos = 0;
+              if (slot_map) {
+                const uint32_t o = rowid - bp1_k;
+                pos = o < (uint32_t)MAPCAP ? (L.map[o] & 127u) : 0u; // stale bytes are caught by the rowid check
+              } else {
+#pragma unroll
+                for (uint32_t step = DEVBLK / 2; step; step >>= 1)
+                  if (L.tj_rowid[pos + step - 1] < rowid) pos += step;
+              }
+              if (L.tj_rowid[pos] == rowid) {
+                const uint32_t aw = L.tj_attr[pos & 63u];
+                const uint32_t sh = (pos >> 6) * 8;
+                const uint32_t f = (aw >> (16 + sh)) & 0xffu & Tj.queried32;
+                if (f) {
+                  const uint32_t tf = (aw >> sh) & 0xffu;
+                  hit[r] = true;
+                  acc[r] = acc[r] + (tf == 255u ? term_tfidf(exc_tf(a.seg, Tj, rowid), Tj.idf) : s.tfidf[j][tf]);
+                  fld[r] |= f;
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            if (!done[r] && row[r] < bp1_k) done[r] = true; // cannot happen (cursor only moves forward)
+        }
+        live[0] = live[0] && hit[0];
+        live[1] = live[1] && hit[1];
+      }
+
+      if (gt_new > tau_bin) tau_bin = gt_new;
+      // ---- matches: weight, pruning bin, candidates
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        bool push = false;
+        uint64_t key = 0;
+        if (live[r]) {
+          ++total;
+          uint32_t weight;
+          if (ranker == MRK_RANK_NONE)
+            weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
+          else {
+            // ExtRanker_WeightSum_c<BM25>, sphinxsearch.cpp:1070, 1112-1129
+            const int32_t bm = (int32_t)((acc[r] + 0.5f) * 1000.0f);
+            weight = (uint32_t)bm + s.rank[fld[r]] * 1000u;
+          }
+          weight *= index_weight; // MatchExtended, sphinx.cpp:12220
+          const uint32_t grow = a.seg.rowid_base + row[r];
+          const uint32_t bin = bin_of(bin_mode, bin_lo, bin_shift, (int32_t)weight, grow);
+#if MRK_EXP != 1
+          if (bin >= tau_bin) {
+            push = true;
+            key = make_key((int32_t)weight, grow);
+          }
+#endif
+        }
+        const uint64_t bal = __ballot(push);
+        if (bal) {
+          const uint32_t n = (uint32_t)__popcll(bal);
+          if (cn + n > (uint32_t)CBUF) publish(); // keys pushed under the older threshold stay valid candidates
+          if (push) L.cbuf[cn + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+          cn += n;
+          if (cn >= flush_at) {
+            publish();
+            flush_at = CBUF - 64;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- wave epilogue
+  if (cn) publish();
+  {
+    uint32_t t = total;
+    for (int dlt = 32; dlt; dlt >>= 1) t += __shfl_down(t, dlt, 64);
+    if (lane == 0 && t) atomicAdd((unsigned long long*)(a.q_total + item.query), (unsigned long long)t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// select: exact top-K of a query's candidate list, one workgroup per query
+// ---------------------------------------------------------------------------------------
+struct __align__(16) SelSmem {
+  uint64_t cand[CAND];
+  uint32_t wave_cnt[2 * WAVES];
+  uint32_t cand_n;
+  uint32_t tau_bin;
+  uint64_t tau;
+};
+
+__global__ __launch_bounds__(WG) void select_kernel(SelectArgs a) {
+  __shared__ SelSmem s;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+  if (q >= a.n_queries) return;
+  const DevQuery* __restrict__ Q = a.queries + q;
+  const uint32_t K = Q->k ? Q->k : 1u;
+  uint32_t n = a.q_cand_n[q];
+  if (n > Q->cand_cap) n = Q->cand_cap;
+  if (tid == 0) {
+    s.cand_n = 0;
+    s.tau = 0;
+  }
+  if (tid < 64) {
+    const uint32_t tb = threshold_bin(a.q_hist + (uint64_t)q * NBINS, K);
+    if (lane == 0) s.tau_bin = tb;
+  }
+  __syncthreads();
+  const uint32_t tau_bin = s.tau_bin;
+  const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
+  const int32_t bin_lo = Q->bin_lo;
+  const uint64_t* __restrict__ src = a.cand + Q->cand_off;
+  for (uint32_t f0 = 0; f0 < n; f0 += 4 * WG) {
+    if (s.cand_n > (uint32_t)(CAND - 4 * WG)) compact_cand(s, K, &s.tau);
+    const uint64_t tau = s.tau;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t f = f0 + r * WG + tid;
+      uint64_t key = 0;
+      bool push = false;
+      if (f < n) {
+        key = src[f];
+        push = key >= tau && bin_of(bin_mode, bin_lo, bin_shift, key_weight(key), key_rowid(key)) >= tau_bin;
+      }
+      const uint64_t bal = __ballot(push);
+      if (bal) {
+        uint32_t basep = 0;
+        if (lane == 0) basep = atomicAdd(&s.cand_n, (uint32_t)__popcll(bal));
+        basep = rdlane(basep, 0);
+        if (push) s.cand[basep + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t m = compact_cand(s, K, &s.tau); // sorted best-first
+  for (uint32_t i = tid; i < m; i += WG) a.out_keys[(uint64_t)q * KCAP + i] = s.cand[i];
+  if (tid == 0) a.out_cnt[q] = m;
+}
+
+void launch_scan_pk(const ScanArgs& a, void* stream) {
+  if (!a.n_items) return;
+  hipLaunchKernelGGL(scan_pk_kernel, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
+}
+
+void launch_select(const SelectArgs& a, void* stream) {
+  if (!a.n_queries) return;
+  hipLaunchKernelGGL(select_kernel, dim3(a.n_queries), dim3(WG), 0, (hipStream_t)stream, a);
+}
+
+} // namespace mrk

@@ -12,11 +12,14 @@ from test_oracle_golden import T019, T019_IDS, T037, T322
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def dev():
+@pytest.fixture(scope="module", params=["packed", "vlb"])
+def dev(request):
+    """Both device paths: packed doclists (load-time transcode, the default) and VLB-direct."""
     import manticoresearch_amd as m
 
     ctx = m.Context(0)
+    ctx.set("path", 0 if request.param == "packed" else 1)
+    ctx._path = 0 if request.param == "packed" else 1
     batch = m.Batch(ctx, 256)
     yield m, ctx, batch
     batch.close()
@@ -47,6 +50,8 @@ def check_batch(orc, dev, hi, queries, rowid_base=0):
         for i in range(0, len(queries), batch.max_queries):
             chunk = queries[i:i + batch.max_queries]
             got = batch.search(seg, chunk)
+            if hi.n_fields <= 8 and ctx_path(ctx) == 0:
+                assert batch.stats()["packed"] == 1
             for q, g in zip(chunk, got):
                 want = to_orc(orc, q).run(oi)
                 assert g.status == 0
@@ -56,6 +61,10 @@ def check_batch(orc, dev, hi, queries, rowid_base=0):
                 assert (g.weight == want.weight).all(), (g.weight[:10], want.weight[:10])
     finally:
         seg.close()
+
+
+def ctx_path(ctx):
+    return getattr(ctx, "_path", 0)
 
 
 def kw(m, t, pos, mask=0xFFFFFFFF, boost=1.0):
