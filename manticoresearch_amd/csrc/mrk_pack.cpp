@@ -4,12 +4,14 @@
 // Per block of 128 docs (the last one may be short):
 //   base   first possible rowid = rowid of the previous block's last doc + 1 (0 for block 0);
 //          same meaning as SkiplistEntry_t::m_tBaseRowIDPlus1
-//   deltas d[0] = rowid[0] - base, d[i] = rowid[i] - rowid[i-1] - 1, packed with w = bits(max d)
-//          bits each in lane order: value slot 2*l + r holds doc l + 64*r, so lane l finds both
-//          of its docs in one 2w-bit field; w > 16 => two planes of plain 32-bit deltas
+//   offs   o[i] = rowid[i] - base, packed with w = bits(o[n-1]) bits each in lane order: value
+//          slot 2*l + r holds doc l + 64*r, so lane l finds both of its docs in one 2w-bit field
+//          and no prefix sum is needed to get a rowid; w > 16 => two planes of 32-bit offsets
+//          (offsets cost ~4 more bits per doc than deltas; the scan kernel is issue-bound, not
+//          HBM-bound, and two wave-wide prefix sums per block cost more than those bits)
 //   attrs  one word per lane: tf[l] | tf[l+64] << 8 | fields[l] << 16 | fields[l+64] << 24
 //          (tf >= 255 is stored as 255 and listed in the term's exception array; needs <= 8 fields)
-// rowid[i] = base + i + sum(d[0..i]).  Everything the BM25 / NONE rankers read survives
+// rowid[i] = base + o[i].  Everything the BM25 / NONE rankers read survives
 // exactly: rowid, hit count, low field-mask bits.
 #include "mrk_pack.h"
 
@@ -98,7 +100,7 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
         return false;
       }
       rows[i] = rowid;
-      d[i] = i == 0 ? rowid - base : rowid - prev - 1u;
+      d[i] = rowid - base;
       if (d[i] > dmax) dmax = d[i];
       tf[i] = hits;
       fl[i] = fields;

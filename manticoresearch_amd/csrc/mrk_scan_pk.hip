@@ -20,11 +20,14 @@ constexpr int CBUF = 256; // candidates a wave collects before it publishes them
 
 struct __align__(16) PkWaveLds {
   uint64_t cbuf[CBUF];  // candidates not yet published to the query's global list
-  uint32_t hist[NBINS]; // scratch for publishing: per-bin counts of the candidates being flushed
   uint32_t tj_rowid[DEVBLK];
   uint32_t tj_attr[64];
-  uint8_t map[MAPCAP];
+  union {
+    uint8_t map[MAPCAP];  // rowid offset -> slot of the decoded other-term block
+    uint32_t hist[NBINS]; // publishing scratch: per-bin counts of the candidates being flushed
+  };                      // (publishing invalidates the decoded block: it is simply decoded again)
 };
+static_assert(NBINS * 4 <= MAPCAP, "hist must fit the map area");
 
 struct __align__(16) PkSmem {
   PkWaveLds w[WAVES];
@@ -81,10 +84,7 @@ __device__ __forceinline__ void flush_hist(uint32_t* lh, uint32_t* gh) {
   for (int i = 0; i < 16; ++i) {
     const uint32_t b = 16 * lane + (uint32_t)i;
     const uint32_t c = lh[b];
-    if (c) {
-      atomicAdd(gh + b, c);
-      lh[b] = 0;
-    }
+    if (c) atomicAdd(gh + b, c);
   }
 }
 
@@ -132,27 +132,23 @@ __device__ __forceinline__ PkRaw issue_pk(const DevSegment& seg, const DevTerm& 
   return r;
 }
 
-// rowids of the block's docs lane and lane+64
+// rowids of the block's docs lane and lane+64 (o0/o1: their offsets from the block base)
 __device__ __forceinline__ void decode_pk(const PkRaw& raw, uint32_t w, uint32_t bp1, uint32_t nd, uint32_t& r0, uint32_t& r1,
-                                          bool& ok0, bool& ok1) {
+                                          uint32_t& o0, uint32_t& o1, bool& ok0, bool& ok1) {
   const uint32_t lane = lane_id();
-  uint32_t d0, d1;
   if (w == PK_WIDE) {
-    d0 = raw.lo;
-    d1 = raw.hi;
+    o0 = raw.lo;
+    o1 = raw.hi;
   } else {
     const uint32_t f = __builtin_amdgcn_alignbit(raw.hi, raw.lo, (lane * 2 * w) & 31u);
     const uint32_t mask = (1u << w) - 1u;
-    d0 = f & mask;
-    d1 = (f >> w) & mask;
+    o0 = f & mask;
+    o1 = (f >> w) & mask;
   }
   ok0 = lane < nd;
   ok1 = lane + 64 < nd;
-  const uint32_t s0 = wave_incl_scan(ok0 ? d0 : 0u);
-  const uint32_t tot0 = rdlane(s0, 63);
-  const uint32_t s1 = wave_incl_scan(ok1 ? d1 : 0u);
-  r0 = bp1 + s0 + lane;
-  r1 = bp1 + tot0 + s1 + 64u + lane;
+  r0 = bp1 + o0;
+  r1 = bp1 + o1;
 }
 
 // exact hit count of a doc whose packed tf saturated (>= 255)
@@ -180,6 +176,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const uint32_t nw = Q->n_weights < 8u ? Q->n_weights : 8u;
   const uint32_t index_weight = Q->index_weight;
   const DevTerm T0 = Q->t[0];
+  const DevTerm T1 = Q->t[nterms > 1 ? 1 : 0];
   PkWaveLds& L = s.w[wave];
   // per-workgroup tables: tfidf(tf) per term, field-weight sum per mask
   for (uint32_t j = 0; j < nterms; ++j) s.tfidf[j][tid] = term_tfidf(tid, Q->t[j].idf);
@@ -192,7 +189,6 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         if (tid & (1u << f)) rk += (uint32_t)Q->weights[f];
     s.rank[tid] = rk;
   }
-  for (uint32_t i = lane; i < (uint32_t)NBINS; i += 64) L.hist[i] = 0;
   const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
   const int32_t bin_lo = Q->bin_lo;
   const uint32_t cand_cap = Q->cand_cap;
@@ -210,34 +206,17 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   cj.first = NOBLK;
   uint32_t cj_term = 0, slot_blk = NOBLK, slot_term = 0, kj = 0;
   bool slot_map = false;
-  // register rings of blocks whose words are in flight (deep prefetch = memory-level parallelism):
-  // driver term: blocks b .. b+3 ; other term: blocks pf_first .. pf_first+pf_n-1
+  // Blocks are requested in bursts of up to 8 (hipcc drains the whole VMEM queue at the first use of
+  // any load, so one memory round trip is paid per burst, not per block).
   const PkRaw zraw{0, 0, 0};
-  PkRaw d0 = zraw, d1 = zraw, d2 = zraw, d3 = zraw;
-  uint32_t dw0 = 0, dw1 = 0, dw2 = 0, dw3 = 0;     // their bit widths
-  uint32_t dbp0 = 0, dbp1 = 0, dbp2 = 0, dbp3 = 0; // and bases
+  PkRaw t0r = zraw, t1r = zraw, t2r = zraw, t3r = zraw, t4r = zraw, t5r = zraw, t6r = zraw, t7r = zraw;
+  uint32_t tb_first = 0, tb_n = 0; // driver-term burst: blocks tb_first .. tb_first+tb_n-1
+  c0.first = NOBLK;
   // other term: a burst of up to 8 consecutive blocks requested back to back (hipcc drains the
   // whole VMEM queue at the first use, so one round trip is paid per burst, not per block)
   PkRaw q0r = zraw, q1r = zraw, q2r = zraw, q3r = zraw, q4r = zraw, q5r = zraw, q6r = zraw, q7r = zraw;
   uint32_t bq_first = 0, bq_n = 0, last_dec = NOBLK;
   uint32_t gt_new = 0;
-  auto issue_drv = [&](uint32_t blk, PkRaw& r, uint32_t& w, uint32_t& bp) {
-    if (blk < wb1) {
-      if (blk < c0.first || blk - c0.first >= (uint32_t)CHUNK) load_pk_chunk(c0, a.seg, T0, blk);
-      const uint32_t ci = blk - c0.first;
-      r = issue_pk(a.seg, T0, c0, ci);
-      w = rdlane(c0.w, ci);
-      bp = rdlane(c0.bp1, ci);
-    }
-  };
-  c0.first = NOBLK;
-  if (wb0 < wb1) {
-    load_pk_chunk(c0, a.seg, T0, wb0);
-    issue_drv(wb0, d0, dw0, dbp0);
-    issue_drv(wb0 + 1, d1, dw1, dbp1);
-    issue_drv(wb0 + 2, d2, dw2, dbp2);
-    issue_drv(wb0 + 3, d3, dw3, dbp3);
-  }
   __syncthreads(); // tables ready; from here on the waves never meet again
   uint32_t tau_bin = 0, cn = 0, flush_at = 64;
 
@@ -250,6 +229,8 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       basep = rdlane(basep, 0);
       const bool fits = basep + cn <= cand_cap;
       const uint32_t npub = cn;
+      for (uint32_t i = lane; i < (uint32_t)NBINS; i += 64) L.hist[i] = 0;
+      slot_blk = NOBLK; // the map area is being reused
       wave_lds_fence();
       for (uint32_t i = lane; i < cn; i += 64) {
         const uint64_t key = L.cbuf[i];
@@ -280,17 +261,39 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   for (uint32_t b = wb0; b < wb1; ++b) {
     {
 
-      // ---- driver block b: its words were requested 4 blocks ago; rotate the ring, request b+4
-      const uint32_t w0 = dw0, bp0 = dbp0;
+      // ---- driver block b, out of the current burst (request the next 8 when it runs dry)
+      if (!(tb_n && b - tb_first < tb_n)) {
+        if (c0.first == NOBLK || b < c0.first || b - c0.first + 8 > (uint32_t)CHUNK) load_pk_chunk(c0, a.seg, T0, b);
+        const uint32_t ci = b - c0.first;
+        uint32_t nbq = wb1 - b;
+        if (nbq > 8) nbq = 8;
+        tb_first = b;
+        tb_n = nbq;
+        t0r = issue_pk(a.seg, T0, c0, ci);
+        if (nbq > 1) t1r = issue_pk(a.seg, T0, c0, ci + 1);
+        if (nbq > 2) t2r = issue_pk(a.seg, T0, c0, ci + 2);
+        if (nbq > 3) t3r = issue_pk(a.seg, T0, c0, ci + 3);
+        if (nbq > 4) t4r = issue_pk(a.seg, T0, c0, ci + 4);
+        if (nbq > 5) t5r = issue_pk(a.seg, T0, c0, ci + 5);
+        if (nbq > 6) t6r = issue_pk(a.seg, T0, c0, ci + 6);
+        if (nbq > 7) t7r = issue_pk(a.seg, T0, c0, ci + 7);
+      }
+      const uint32_t w0 = rdlane(c0.w, b - c0.first), bp0 = rdlane(c0.bp1, b - c0.first);
       const uint32_t left0 = T0.docs - b * DEVBLK;
-      const PkRaw cur0 = d0;
-      d0 = d1, dw0 = dw1, dbp0 = dbp1;
-      d1 = d2, dw1 = dw2, dbp1 = dbp2;
-      d2 = d3, dw2 = dw3, dbp2 = dbp3;
-      issue_drv(b + 4, d3, dw3, dbp3);
-      uint32_t row[2];
+      PkRaw cur0;
+      switch (b - tb_first) {
+        case 0: cur0 = t0r; break;
+        case 1: cur0 = t1r; break;
+        case 2: cur0 = t2r; break;
+        case 3: cur0 = t3r; break;
+        case 4: cur0 = t4r; break;
+        case 5: cur0 = t5r; break;
+        case 6: cur0 = t6r; break;
+        default: cur0 = t7r; break;
+      }
+      uint32_t row[2], off0[2];
       bool ok[2];
-      decode_pk(cur0, w0, bp0, left0 < (uint32_t)DEVBLK ? left0 : (uint32_t)DEVBLK, row[0], row[1], ok[0], ok[1]);
+      decode_pk(cur0, w0, bp0, left0 < (uint32_t)DEVBLK ? left0 : (uint32_t)DEVBLK, row[0], row[1], off0[0], off0[1], ok[0], ok[1]);
 
       uint32_t fld[2];
       float acc[2];
@@ -306,13 +309,13 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       }
 
       // ---- the other terms, in ascending-docs order
-#if MRK_EXP == 2
+#if MRK_EXP == 2 || MRK_EXP == 6
       for (uint32_t j = 1; j < 1; ++j) {
 #else
       for (uint32_t j = 1; j < nterms; ++j) {
 #endif
         if (!__ballot(live[0] || live[1])) break;
-        const DevTerm Tj = Q->t[j];
+        const DevTerm Tj = j == 1 ? T1 : Q->t[j];
         bool done[2] = {!live[0], !live[1]};
         bool hit[2] = {false, false};
         if (cj_term != j) {
@@ -377,48 +380,76 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
             const uint32_t wj = rdlane(cj.w, ci);
             const uint32_t leftj = Tj.docs - kj * DEVBLK;
             const uint32_t ndj = leftj < (uint32_t)DEVBLK ? leftj : (uint32_t)DEVBLK;
-            uint32_t e0, e1;
+            uint32_t e0, e1, f0, f1;
             bool k0, k1;
-            decode_pk(rj, wj, bp1_k, ndj, e0, e1, k0, k1);
-            // rowid window the block covers; small enough => direct map
-            const uint32_t last = ndj > 64 ? rdlane(e1, ndj - 65) : rdlane(e0, ndj - 1);
-            slot_map = last - bp1_k < (uint32_t)MAPCAP;
+            decode_pk(rj, wj, bp1_k, ndj, e0, e1, f0, f1, k0, k1);
+            // offsets of a w-bit block stay below 2^w: small enough => direct map
+            slot_map = wj != PK_WIDE && (1u << wj) <= (uint32_t)MAPCAP;
             L.tj_rowid[lane] = k0 ? e0 : INF_ROWID;
             L.tj_rowid[lane + 64] = k1 ? e1 : INF_ROWID;
             L.tj_attr[lane] = rj.attr;
             if (slot_map) {
-              if (k0) L.map[e0 - bp1_k] = (uint8_t)lane;
-              if (k1) L.map[e1 - bp1_k] = (uint8_t)(lane + 64);
+              if (k0) L.map[f0] = (uint8_t)lane;
+              if (k1) L.map[f1] = (uint8_t)(lane + 64);
             }
             slot_blk = kj;
             slot_term = j;
             wave_lds_fence();
           }
-          // probe: driver docs that fall into [bp1_k, bp1_n)
+          // probe: driver docs that fall into [bp1_k, bp1_n).  Both docs of a lane go through the
+          // dependent LDS reads side by side (map -> {rowid, attr} -> tfidf) instead of one after the other.
+          {
+            bool inr[2];
+            uint32_t pos[2];
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            if (!done[r] && row[r] >= bp1_k && row[r] < bp1_n) {
-              done[r] = true;
-              const uint32_t rowid = row[r];
-              uint32_t pos = 0;
-              if (slot_map) {
-                const uint32_t o = rowid - bp1_k;
-                pos = o < (uint32_t)MAPCAP ? (L.map[o] & 127u) : 0u; // stale bytes are caught by the rowid check
-              } else {
+            for (int r = 0; r < 2; ++r) {
+              inr[r] = !done[r] && row[r] >= bp1_k && row[r] < bp1_n;
+              done[r] = done[r] || inr[r];
+            }
+            if (slot_map) {
+              uint32_t mb[2];
+#pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                const uint32_t o = row[r] - bp1_k;
+                mb[r] = L.map[inr[r] && o < (uint32_t)MAPCAP ? o : 0u]; // stale bytes are caught by the rowid check
+              }
+#pragma unroll
+              for (int r = 0; r < 2; ++r) pos[r] = mb[r] & 127u;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                uint32_t p = 0;
+                const uint32_t rowid = inr[r] ? row[r] : 0u;
 #pragma unroll
                 for (uint32_t step = DEVBLK / 2; step; step >>= 1)
-                  if (L.tj_rowid[pos + step - 1] < rowid) pos += step;
+                  if (L.tj_rowid[p + step - 1] < rowid) p += step;
+                pos[r] = p;
               }
-              if (L.tj_rowid[pos] == rowid) {
-                const uint32_t aw = L.tj_attr[pos & 63u];
-                const uint32_t sh = (pos >> 6) * 8;
-                const uint32_t f = (aw >> (16 + sh)) & 0xffu & Tj.queried32;
-                if (f) {
-                  const uint32_t tf = (aw >> sh) & 0xffu;
-                  hit[r] = true;
-                  acc[r] = acc[r] + (tf == 255u ? term_tfidf(exc_tf(a.seg, Tj, rowid), Tj.idf) : s.tfidf[j][tf]);
-                  fld[r] |= f;
-                }
+            }
+            uint32_t rid[2], aw[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              rid[r] = L.tj_rowid[pos[r]];
+              aw[r] = L.tj_attr[pos[r] & 63u];
+            }
+            uint32_t tfj[2], fj[2];
+            bool hp[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const uint32_t sh = (pos[r] >> 6) * 8;
+              tfj[r] = (aw[r] >> sh) & 0xffu;
+              fj[r] = (aw[r] >> (16 + sh)) & 0xffu & Tj.queried32;
+              hp[r] = inr[r] && rid[r] == row[r] && fj[r] != 0;
+            }
+            float tv[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) tv[r] = s.tfidf[j][tfj[r]];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              if (hp[r]) {
+                hit[r] = true;
+                acc[r] = acc[r] + (tfj[r] == 255u ? term_tfidf(exc_tf(a.seg, Tj, row[r]), Tj.idf) : tv[r]);
+                fld[r] |= fj[r];
               }
             }
           }
@@ -449,7 +480,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
           weight *= index_weight; // MatchExtended, sphinx.cpp:12220
           const uint32_t grow = a.seg.rowid_base + row[r];
           const uint32_t bin = bin_of(bin_mode, bin_lo, bin_shift, (int32_t)weight, grow);
-#if MRK_EXP != 1
+#if MRK_EXP != 1 && MRK_EXP != 6 && MRK_EXP != 7
           if (bin >= tau_bin) {
             push = true;
             key = make_key((int32_t)weight, grow);

@@ -14,6 +14,8 @@
 #include "cpu_ref.h"
 
 #include <limits.h>
+#include <pthread.h>
+#include <time.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1646,4 +1648,59 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
   free(hv.p);
   en_free(root);
   return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* throughput harness for bench.py's cpu_baseline leg: n_threads workers pull  */
+/* queries off a shared counter, one independent query per thread at a time   */
+/* (the reference's model: one coroutine per query x chunk, searchd.cpp:5654). */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const orc_index* idx;
+  const orc_query* const* queries;
+  int n_queries, repeat;
+  volatile int next;
+  int max_k;
+  int errors;
+} many_ctx;
+
+static void* many_worker(void* p) {
+  many_ctx* c = (many_ctx*)p;
+  uint32_t* rowid = (uint32_t*)malloc((size_t)c->max_k * sizeof(uint32_t));
+  int32_t* weight = (int32_t*)malloc((size_t)c->max_k * sizeof(int32_t));
+  for (;;) {
+    int i = __sync_fetch_and_add(&c->next, 1);
+    if (i >= c->n_queries * c->repeat) break;
+    orc_result r;
+    r.rowid = rowid;
+    r.weight = weight;
+    if (orc_search(c->idx, c->queries[i % c->n_queries], &r) != 0) __sync_fetch_and_add(&c->errors, 1);
+  }
+  free(rowid);
+  free(weight);
+  return NULL;
+}
+
+/* runs every query `repeat` times over n_threads threads; returns wall seconds (<0 on error) */
+double orc_search_many(const orc_index* idx, const orc_query* const* queries, int n_queries, int repeat, int n_threads) {
+  many_ctx c;
+  c.idx = idx;
+  c.queries = queries;
+  c.n_queries = n_queries;
+  c.repeat = repeat;
+  c.next = 0;
+  c.errors = 0;
+  c.max_k = 1;
+  for (int i = 0; i < n_queries; i++)
+    if (queries[i]->max_matches > c.max_k) c.max_k = queries[i]->max_matches;
+  if (n_threads < 1) n_threads = 1;
+  pthread_t* th = (pthread_t*)malloc((size_t)n_threads * sizeof(pthread_t));
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, many_worker, &c);
+  for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  free(th);
+  if (c.errors) return -1.0;
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

@@ -146,6 +146,10 @@ typedef struct {
 int orc_search(const orc_index* idx, const orc_query* q, orc_result* res);
 const char* orc_last_error(void);
 
+/* bench.py cpu_baseline: run every query `repeat` times over n_threads threads (one independent
+   query per thread); returns wall seconds, < 0 on error */
+double orc_search_many(const orc_index* idx, const orc_query* const* queries, int n_queries, int repeat, int n_threads);
+
 /* IDF per sphCreateRanker (src/sphinxsearch.cpp:4317-4361) */
 float orc_idf(int64_t term_docs, int64_t total_docs, int plain_idf, int normalized, int n_qwords, float boost);
 

@@ -89,6 +89,8 @@ def lib():
         L.orc_search.argtypes = [C.POINTER(_Index), C.POINTER(_Query), C.POINTER(_Result)]
         L.orc_search.restype = C.c_int
         L.orc_last_error.restype = C.c_char_p
+        L.orc_search_many.argtypes = [C.POINTER(_Index), C.POINTER(C.POINTER(_Query)), C.c_int, C.c_int, C.c_int]
+        L.orc_search_many.restype = C.c_double
         L.orc_idf.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]
         L.orc_idf.restype = C.c_float
         L.orc_decode_doclist.argtypes = [C.POINTER(_Index), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -297,3 +299,25 @@ def search(index: Index, root: QNode, **kw) -> Result:
 def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool = True, n_qwords: int = 1,
         boost: float = 1.0) -> float:
     return float(lib().orc_idf(term_docs, total_docs, int(plain), int(normalized), n_qwords, boost))
+
+
+def search_many(index: Index, flat_queries: Sequence["FlatQuery"], repeat: int, n_threads: int) -> float:
+    """Wall seconds for running every query `repeat` times on n_threads threads (C worker pool)."""
+    arr = (C.POINTER(_Query) * len(flat_queries))(*[C.pointer(q.q) for q in flat_queries])
+    s = index.c_struct()
+    t = lib().orc_search_many(C.byref(s), arr, len(flat_queries), repeat, n_threads)
+    if t < 0:
+        raise RuntimeError("oracle: a query failed in search_many")
+    return float(t)
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
