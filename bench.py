@@ -121,6 +121,9 @@ def main() -> None:
     ctx.set("path", args.path)
     seg = m.Segment(ctx, hi, rowid_base=rank * shard_docs)
     batch = m.Batch(ctx, args.queries)
+    # one batch object per stratum: all three are submitted before the first wait, so host-side
+    # planning and result copies of one overlap the kernels of another
+    batches = {"cc": batch, "sc": m.Batch(ctx, args.queries), "ss": m.Batch(ctx, args.queries)}
 
     # global DF / N so that every shard ranks with the same IDF (local_df, sphinxrt.cpp:6501-6521)
     local_docs = hi.dict["docs"].astype(np.int64)
@@ -144,13 +147,18 @@ def main() -> None:
     per = {s: {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0} for s in ["cc", "sc", "ss"]}
 
     def step(record: bool) -> None:
+        if merger is None:
+            for s in names:
+                batches[s].submit_prepared(seg, prepared[s], nq)
         for s in names:
-            batch.submit_prepared(seg, prepared[s], nq)
-            batch.wait()
             if merger is not None:
+                batch.submit_prepared(seg, prepared[s], nq)
+                batch.wait()
                 merger.merge()
+            else:
+                batches[s].wait()
             if record:
-                st = batch.stats()
+                st = (batch if merger is not None else batches[s]).stats()
                 per[s]["scan_ms"] += st["scan_ms"]
                 per[s]["merge_ms"] += st["merge_ms"]
                 per[s]["algo_bytes"] = st["algo_bytes"]
@@ -161,7 +169,8 @@ def main() -> None:
                 per[s]["n"] += 1
 
     def sync() -> None:
-        batch.wait()
+        for bb in batches.values():
+            bb.wait()
         if world > 1:
             import torch
 
@@ -279,7 +288,8 @@ def main() -> None:
     elif rank == 0:
         out["cpu_baseline"] = None
 
-    batch.close()
+    for bb in batches.values():
+        bb.close()
     seg.close()
     ctx.close()
     if world > 1:

@@ -129,7 +129,7 @@ struct MergeArgs {
 };
 
 void launch_scan(const ScanArgs& a, void* stream);
-void launch_scan_pk(const ScanArgs& a, void* stream);
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, void* stream);
 void launch_select(const SelectArgs& a, void* stream);
 void launch_merge(const MergeArgs& a, void* stream);
 

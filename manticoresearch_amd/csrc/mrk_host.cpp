@@ -739,6 +739,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   std::vector<DevItem> items;
   items.reserve(n * 4);
   uint64_t algo_bytes = 0, dev_bytes = 0, cand_total = 0;
+  uint32_t max_terms = 1;
   if (b->ctx->path == 2 && !seg->has_packed) return mrk_fail(MRK_E_UNSUPPORTED, "path=packed but the segment has no packed doclists");
   const bool use_packed = seg->has_packed && b->ctx->path != 1;
   for (uint32_t i = 0; i < n; ++i) {
@@ -750,6 +751,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
       items.resize(b->h_queries.p[i].item_first);
       b->h_queries.p[i].n_items = 0;
     }
+    max_terms = std::max(max_terms, b->h_queries.p[i].n_terms);
     b->h_list_first.p[i] = b->h_queries.p[i].item_first;
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;
@@ -797,7 +799,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   sa.cand = b->d_cand.p;
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
   if (use_packed)
-    launch_scan_pk(sa, st);
+    launch_scan_pk(sa, max_terms, st);
   else
     launch_scan(sa, st);
   HIP_TRY(hipEventRecord(b->ev_scan1, st));

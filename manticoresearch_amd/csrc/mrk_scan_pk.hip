@@ -13,10 +13,16 @@
 #ifndef MRK_EXP
 #define MRK_EXP 0
 #endif
+#ifndef MRK_BURST
+#define MRK_BURST 4 // blocks requested back to back per stream (4 or 8); 4 keeps VGPRs <= 96 => 5 waves/SIMD
+#endif
 
 namespace mrk {
 
-constexpr int CBUF = 256; // candidates a wave collects before it publishes them
+#ifndef MRK_CBUF
+#define MRK_CBUF 128
+#endif
+constexpr int CBUF = MRK_CBUF; // candidates a wave collects before it publishes them
 
 struct __align__(16) PkWaveLds {
   uint64_t cbuf[CBUF];  // candidates not yet published to the query's global list
@@ -31,8 +37,8 @@ static_assert(NBINS * 4 <= MAPCAP, "hist must fit the map area");
 
 struct __align__(16) PkSmem {
   PkWaveLds w[WAVES];
-  float tfidf[MRK_MAX_AND_TERMS][256];
   uint32_t rank[256];
+  float tfidf[1][256]; // really [n_terms][256]: the tail lives in dynamic LDS right behind this struct
 };
 
 // Pruning bin of a match: monotone non-decreasing in the sorter's order (weight, then lower
@@ -167,7 +173,8 @@ __device__ uint32_t exc_tf(const DevSegment& seg, const DevTerm& T, uint32_t row
 }
 
 __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
-  __shared__ PkSmem s;
+  extern __shared__ __align__(16) uint8_t smem_raw[];
+  PkSmem& s = *reinterpret_cast<PkSmem*>(smem_raw);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= a.n_items) return;
   const DevItem item = a.items[blockIdx.x];
@@ -209,12 +216,18 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   // Blocks are requested in bursts of up to 8 (hipcc drains the whole VMEM queue at the first use of
   // any load, so one memory round trip is paid per burst, not per block).
   const PkRaw zraw{0, 0, 0};
-  PkRaw t0r = zraw, t1r = zraw, t2r = zraw, t3r = zraw, t4r = zraw, t5r = zraw, t6r = zraw, t7r = zraw;
+  PkRaw t0r = zraw, t1r = zraw, t2r = zraw, t3r = zraw;
+#if MRK_BURST > 4
+  PkRaw t4r = zraw, t5r = zraw, t6r = zraw, t7r = zraw;
+#endif
   uint32_t tb_first = 0, tb_n = 0; // driver-term burst: blocks tb_first .. tb_first+tb_n-1
   c0.first = NOBLK;
   // other term: a burst of up to 8 consecutive blocks requested back to back (hipcc drains the
   // whole VMEM queue at the first use, so one round trip is paid per burst, not per block)
-  PkRaw q0r = zraw, q1r = zraw, q2r = zraw, q3r = zraw, q4r = zraw, q5r = zraw, q6r = zraw, q7r = zraw;
+  PkRaw q0r = zraw, q1r = zraw, q2r = zraw, q3r = zraw;
+#if MRK_BURST > 4
+  PkRaw q4r = zraw, q5r = zraw, q6r = zraw, q7r = zraw;
+#endif
   uint32_t bq_first = 0, bq_n = 0, last_dec = NOBLK;
   uint32_t gt_new = 0;
   __syncthreads(); // tables ready; from here on the waves never meet again
@@ -263,20 +276,22 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
 
       // ---- driver block b, out of the current burst (request the next 8 when it runs dry)
       if (!(tb_n && b - tb_first < tb_n)) {
-        if (c0.first == NOBLK || b < c0.first || b - c0.first + 8 > (uint32_t)CHUNK) load_pk_chunk(c0, a.seg, T0, b);
+        if (c0.first == NOBLK || b < c0.first || b - c0.first + MRK_BURST > (uint32_t)CHUNK) load_pk_chunk(c0, a.seg, T0, b);
         const uint32_t ci = b - c0.first;
         uint32_t nbq = wb1 - b;
-        if (nbq > 8) nbq = 8;
+        if (nbq > MRK_BURST) nbq = MRK_BURST;
         tb_first = b;
         tb_n = nbq;
         t0r = issue_pk(a.seg, T0, c0, ci);
         if (nbq > 1) t1r = issue_pk(a.seg, T0, c0, ci + 1);
         if (nbq > 2) t2r = issue_pk(a.seg, T0, c0, ci + 2);
         if (nbq > 3) t3r = issue_pk(a.seg, T0, c0, ci + 3);
+#if MRK_BURST > 4
         if (nbq > 4) t4r = issue_pk(a.seg, T0, c0, ci + 4);
         if (nbq > 5) t5r = issue_pk(a.seg, T0, c0, ci + 5);
         if (nbq > 6) t6r = issue_pk(a.seg, T0, c0, ci + 6);
         if (nbq > 7) t7r = issue_pk(a.seg, T0, c0, ci + 7);
+#endif
       }
       const uint32_t w0 = rdlane(c0.w, b - c0.first), bp0 = rdlane(c0.bp1, b - c0.first);
       const uint32_t left0 = T0.docs - b * DEVBLK;
@@ -285,11 +300,15 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         case 0: cur0 = t0r; break;
         case 1: cur0 = t1r; break;
         case 2: cur0 = t2r; break;
+#if MRK_BURST > 4
         case 3: cur0 = t3r; break;
         case 4: cur0 = t4r; break;
         case 5: cur0 = t5r; break;
         case 6: cur0 = t6r; break;
         default: cur0 = t7r; break;
+#else
+        default: cur0 = t3r; break;
+#endif
       }
       uint32_t row[2], off0[2];
       bool ok[2];
@@ -348,7 +367,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
           if (slot_blk != kj || slot_term != j) {
             if (!(bq_n && kj >= bq_first && kj - bq_first < bq_n)) {
               // sequential access bets on 8 blocks, a jump on 2
-              const uint32_t want = (last_dec == NOBLK || last_dec + 1 == kj) ? 8u : 2u;
+              const uint32_t want = (last_dec == NOBLK || last_dec + 1 == kj) ? (uint32_t)MRK_BURST : 2u;
               uint32_t nbq = Tj.nblocks - kj;
               if (nbq > want) nbq = want;
               if (nbq > (uint32_t)CHUNK - ci) nbq = (uint32_t)CHUNK - ci;
@@ -358,10 +377,12 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
               if (nbq > 1) q1r = issue_pk(a.seg, Tj, cj, ci + 1);
               if (nbq > 2) q2r = issue_pk(a.seg, Tj, cj, ci + 2);
               if (nbq > 3) q3r = issue_pk(a.seg, Tj, cj, ci + 3);
+#if MRK_BURST > 4
               if (nbq > 4) q4r = issue_pk(a.seg, Tj, cj, ci + 4);
               if (nbq > 5) q5r = issue_pk(a.seg, Tj, cj, ci + 5);
               if (nbq > 6) q6r = issue_pk(a.seg, Tj, cj, ci + 6);
               if (nbq > 7) q7r = issue_pk(a.seg, Tj, cj, ci + 7);
+#endif
               // the shared threshold word rides along with the burst
               gt_new = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -371,11 +392,15 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
               case 0: rj = q0r; break;
               case 1: rj = q1r; break;
               case 2: rj = q2r; break;
+#if MRK_BURST > 4
               case 3: rj = q3r; break;
               case 4: rj = q4r; break;
               case 5: rj = q5r; break;
               case 6: rj = q6r; break;
               default: rj = q7r; break;
+#else
+              default: rj = q3r; break;
+#endif
             }
             const uint32_t wj = rdlane(cj.w, ci);
             const uint32_t leftj = Tj.docs - kj * DEVBLK;
@@ -570,9 +595,11 @@ __global__ __launch_bounds__(WG) void select_kernel(SelectArgs a) {
   if (tid == 0) a.out_cnt[q] = m;
 }
 
-void launch_scan_pk(const ScanArgs& a, void* stream) {
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, void* stream) {
   if (!a.n_items) return;
-  hipLaunchKernelGGL(scan_pk_kernel, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
+  if (max_terms < 1) max_terms = 1;
+  const size_t lds = sizeof(PkSmem) + (size_t)(max_terms - 1) * 256 * sizeof(float);
+  hipLaunchKernelGGL(scan_pk_kernel, dim3(a.n_items), dim3(WG), lds, (hipStream_t)stream, a);
 }
 
 void launch_select(const SelectArgs& a, void* stream) {
