@@ -37,8 +37,9 @@ def exchange_partial_topk(keys, counts, totals):
     world = dist.get_world_size()
     keys_all = torch.empty((world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
     counts_all = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(keys_all, keys.contiguous())
-    dist.all_gather_into_tensor(counts_all, counts.contiguous())
+    # list-of-views form: identical on gloo and nccl (RCCL gathers straight into the slices)
+    dist.all_gather([keys_all[i] for i in range(world)], keys.contiguous())
+    dist.all_gather([counts_all[i] for i in range(world)], counts.contiguous())
     dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     return keys_all, counts_all, totals
 

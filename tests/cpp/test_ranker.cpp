@@ -1,0 +1,94 @@
+// Drives mrk::GpuRanker / mrk::GpuTopK the way CSphIndex_VLN::MatchExtended drives ISphRanker /
+// ISphMatchSorter (sphinx.cpp:12201-12268), over two segments merged like RT disk chunks
+// (sphinxrt.cpp:5945-5950).  Prints "rowid weight" lines + totals; tests/test_gpu_cpp.py compares
+// them with the oracle.  Usage: test_ranker <n_docs> <p0> <p1> <seed>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <string>
+#include <vector>
+
+#include "../../manticoresearch_amd/csrc/mrk_ranker.h"
+
+static mrk_segment* make_segment(mrk_ctx* ctx, uint64_t n_docs, const double* probs, uint32_t n_terms, uint64_t seed,
+                                 uint32_t shard, mrk_host_index** keep) {
+  mrk_synth_params p{};
+  p.seed = seed, p.n_docs = n_docs, p.shard = shard, p.term_prob = probs, p.n_terms = n_terms, p.n_fields = 2;
+  p.title_frac = 0.1, p.max_pos = 1024, p.skiplist_block_size = 32, p.hit_format = MRK_HITFMT_INLINE, p.n_threads = 2;
+  if (mrk_synth_generate(&p, keep) != MRK_OK) return nullptr;
+  mrk_segment_desc d{};
+  d.spd = mrk_host_index_spd(*keep, &d.spd_len);
+  d.spp = mrk_host_index_spp(*keep, &d.spp_len);
+  d.spe = mrk_host_index_spe(*keep, &d.spe_len);
+  d.dict = mrk_host_index_dict(*keep, &d.n_terms);
+  d.total_docs = n_docs, d.skiplist_block_size = 32, d.hit_format = MRK_HITFMT_INLINE, d.n_fields = 2;
+  mrk_segment* s = nullptr;
+  if (mrk_segment_create(ctx, &d, &s) != MRK_OK) return nullptr;
+  return s;
+}
+
+int main(int argc, char** argv) {
+  const uint64_t n_docs = argc > 1 ? strtoull(argv[1], 0, 10) : 100000;
+  const double probs[2] = {argc > 2 ? atof(argv[2]) : 0.2, argc > 3 ? atof(argv[3]) : 0.05};
+  const uint64_t seed = argc > 4 ? strtoull(argv[4], 0, 10) : 7;
+  mrk_ctx* ctx = nullptr;
+  if (mrk_ctx_create(0, &ctx) != MRK_OK) return fprintf(stderr, "ctx: %s\n", mrk_last_error()), 2;
+  mrk_batch* batch = nullptr;
+  if (mrk_batch_create(ctx, 4, &batch) != MRK_OK) return fprintf(stderr, "batch: %s\n", mrk_last_error()), 2;
+  mrk_host_index* hi[2] = {nullptr, nullptr};
+  mrk_segment* seg[2];
+  for (int s = 0; s < 2; ++s)
+    if (!(seg[s] = make_segment(ctx, n_docs, probs, 2, seed, (uint32_t)s, &hi[s]))) return fprintf(stderr, "segment: %s\n", mrk_last_error()), 2;
+
+  // "aa bb": AND of two keywords, BM25, max_matches 1000; local_df as RtIndex_c::MultiQuery sets it up
+  mrk_node nodes[3] = {};
+  nodes[0].op = MRK_OP_AND, nodes[0].n_children = 2, nodes[0].first_child = 0, nodes[0].field_mask = MRK_ALL_FIELDS, nodes[0].boost = 1.f;
+  for (int i = 0; i < 2; ++i) {
+    nodes[1 + i].op = MRK_OP_TERM, nodes[1 + i].term_id = i, nodes[1 + i].atom_pos = i + 1;
+    nodes[1 + i].field_mask = MRK_ALL_FIELDS, nodes[1 + i].boost = 1.f;
+  }
+  const int32_t children[2] = {1, 2};
+  uint32_t nt;
+  int64_t local_docs[3] = {-1, 0, 0};
+  for (int s = 0; s < 2; ++s) {
+    const mrk_dict_entry* d = mrk_host_index_dict(hi[s], &nt);
+    local_docs[1] += d[0].docs, local_docs[2] += d[1].docs;
+  }
+  mrk_query q{};
+  q.nodes = nodes, q.n_nodes = 3, q.children = children, q.root = 0, q.ranker = MRK_RANK_BM25, q.max_matches = 1000;
+  q.normalized_tfidf = 1, q.total_docs_override = (int64_t)(2 * n_docs), q.local_docs = local_docs;
+
+  mrk::GpuTopK tParent(1000);
+  std::string sError;
+  for (int s = 0; s < 2; ++s) { // one ranker + one sorter per chunk, then MoveTo the parent
+    mrk::GpuRanker* pRanker = mrk::GpuRanker::Create(batch, seg[s], q, sError);
+    if (!pRanker) return fprintf(stderr, "ranker: %s\n", sError.c_str()), 3;
+    mrk::GpuTopK tSorter(1000);
+    mrk::Match* pMatch = pRanker->GetMatchesBuffer();
+    for (;;) { // MatchExtended
+      const int iMatches = pRanker->GetMatches();
+      if (iMatches <= 0) break;
+      for (int i = 0; i < iMatches; ++i) {
+        pMatch[i].m_iTag = s;
+        tSorter.Push(pMatch[i]);
+      }
+    }
+    tSorter.SetTotal(pRanker->GetTotalFound());
+    printf("chunk %d total %lld length %d\n", s, (long long)tSorter.GetTotalCount(), tSorter.GetLength());
+    tSorter.MoveTo(&tParent);
+    delete pRanker;
+  }
+  printf("total %lld\n", (long long)tParent.GetTotalCount());
+  std::vector<mrk::Match> out(1000);
+  const int n = tParent.Flatten(out.data());
+  for (int i = 0; i < n; ++i) printf("%d %u %d\n", out[i].m_iTag, out[i].m_tRowID, out[i].m_iWeight);
+  // an unsupported query shape must fail loudly, reference-style (nullptr + error string)
+  nodes[0].op = MRK_OP_OR;
+  mrk::GpuRanker* pBad = mrk::GpuRanker::Create(batch, seg[0], q, sError);
+  printf("or_query %s\n", pBad ? "accepted" : "rejected");
+  delete pBad;
+  for (int s = 0; s < 2; ++s) mrk_segment_destroy(seg[s]), mrk_host_index_free(hi[s]);
+  mrk_batch_destroy(batch);
+  mrk_ctx_destroy(ctx);
+  return 0;
+}

@@ -1,0 +1,42 @@
+"""GPU: the C++ ISphRanker / ISphMatchSorter mirrors (csrc/mrk_ranker.h) driven like the
+reference's MatchExtended loop over two chunks, checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_ranker_two_chunks(orc, tmp_path):
+    import manticoresearch_amd as m
+
+    exe = str(tmp_path / "test_ranker")
+    lib = os.path.join(ROOT, "manticoresearch_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "test_ranker.cpp"), "-o", exe,
+                           "-L" + lib, "-lmrk", "-Wl,-rpath," + lib])
+    n_docs, p0, p1, seed = 150000, 0.2, 0.05, 7
+    out = subprocess.check_output([exe, str(n_docs), str(p0), str(p1), str(seed)], text=True).splitlines()
+    assert out[-1] == "or_query rejected"
+    total = int([l for l in out if l.startswith("total ")][0].split()[1])
+    got = [tuple(int(x) for x in l.split()) for l in out if l[0].isdigit()]
+    # oracle on the same two segments (same generator parameters), merged with the reference comparator
+    allm, tot = [], 0
+    gdocs = [0, 0]
+    his = [m.synth_index(n_docs, [p0, p1], seed=seed, shard=s, skiplist_block_size=32, n_threads=2) for s in range(2)]
+    for t in range(2):
+        gdocs[t] = int(his[0].dict[t]["docs"]) + int(his[1].dict[t]["docs"])
+    for s, hi in enumerate(his):
+        oi = orc.Index(hi.spd, hi.spp, hi.spe, hi.dict.view(orc.DICT_DTYPE), n_docs, 32, 1, 2)
+        r = orc.search(oi, orc.op(orc.OP_AND, orc.term(0, 1), orc.term(1, 2)), ranker=orc.RANK_BM25, max_matches=1000,
+                       total_docs_override=2 * n_docs, local_docs={0: gdocs[0], 1: gdocs[1]})
+        tot += r.total_found
+        allm += [(-int(w), int(rid), s) for rid, w in zip(r.rowid, r.weight)]
+    assert total == tot
+    # MatchRelevanceLt_fn: weight desc, rowid asc; equal (weight, rowid) across chunks is unordered in the
+    # reference, so compare (weight, rowid) multisets of the top 1000
+    allm.sort()
+    want = sorted((w, r) for w, r, _ in allm[:1000])
+    assert sorted((-w, r) for _, r, w in got) == want
