@@ -96,7 +96,9 @@ def main() -> None:
     if world != max(1, args.gpus) and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    # MRK_FORCE_DIST=1 runs the sharded code path (RCCL exchange + device merge) even with one rank
+    force_dist = bool(os.environ.get("MRK_FORCE_DIST")) and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
@@ -127,7 +129,7 @@ def main() -> None:
 
     # global DF / N so that every shard ranks with the same IDF (local_df, sphinxrt.cpp:6501-6521)
     local_docs = hi.dict["docs"].astype(np.int64)
-    if world > 1:
+    if world > 1 or force_dist:
         global_docs, total_docs = mdist.global_df(local_docs, shard_docs, local_rank)
     else:
         global_docs, total_docs = local_docs, shard_docs
@@ -142,7 +144,7 @@ def main() -> None:
     names = [x for x in ["cc", "sc", "ss"] if x in args.strata.split(",")]
     prepared = {s: m.prepare([mkq(a, b) for a, b in strata[s]]) for s in names}
     nq = args.queries
-    merger = mdist.ShardMerger(ctx, batch, nq, K, world, local_rank) if world > 1 else None
+    merger = mdist.ShardMerger(ctx, batch, nq, K, world, local_rank) if (world > 1 or force_dist) else None
 
     per = {s: {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0} for s in ["cc", "sc", "ss"]}
 
@@ -186,7 +188,7 @@ def main() -> None:
         step(True)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         import torch
 
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -292,7 +294,7 @@ def main() -> None:
         bb.close()
     seg.close()
     ctx.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
