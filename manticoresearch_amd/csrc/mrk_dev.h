@@ -36,6 +36,8 @@ struct DevSegment {
   const uint32_t* pk_delta; // delta arena
   const uint32_t* pk_attr;  // per block 64 words: tf[l] | tf[l+64]<<8 | fields[l]<<16 | fields[l+64]<<24
   const uint64_t* pk_exc;   // tf exceptions (tf >= 255): rowid<<32 | tf, sorted per term
+  const uint32_t* pk_hit;   // per doc slot (block*128 + i): inlined hit, or hitlist offset from pk_hbase[block]
+  const uint64_t* pk_hbase; // per block: hitlist base position in .spp
 };
 
 constexpr uint32_t PK_WIDE = 0xFFu;
@@ -129,7 +131,8 @@ struct MergeArgs {
 };
 
 void launch_scan(const ScanArgs& a, void* stream);
-void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, void* stream);
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, void* stream);
+constexpr int MAX_PROX_TERMS = 4; // keywords whose hit streams the proximity kernel merges per doc
 void launch_select(const SelectArgs& a, void* stream);
 void launch_merge(const MergeArgs& a, void* stream);
 

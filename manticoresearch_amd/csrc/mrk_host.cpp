@@ -78,6 +78,8 @@ struct mrk_segment {
   void* d_pk_delta = nullptr;
   void* d_pk_attr = nullptr;
   void* d_pk_exc = nullptr;
+  void* d_pk_hit = nullptr;
+  void* d_pk_hbase = nullptr;
 };
 
 template <typename T>
@@ -238,6 +240,8 @@ extern "C" void mrk_segment_destroy(mrk_segment* s) {
   if (s->d_pk_delta) (void)hipFree(s->d_pk_delta);
   if (s->d_pk_attr) (void)hipFree(s->d_pk_attr);
   if (s->d_pk_exc) (void)hipFree(s->d_pk_exc);
+  if (s->d_pk_hit) (void)hipFree(s->d_pk_hit);
+  if (s->d_pk_hbase) (void)hipFree(s->d_pk_hbase);
   delete s;
 }
 
@@ -329,7 +333,8 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
   }
 
   // ---- packed doclists: lossless transcode of every term's .spd run (mrk_pack.cpp)
-  std::vector<uint32_t> pk_base, pk_doff, pk_delta, pk_attr;
+  std::vector<uint32_t> pk_base, pk_doff, pk_delta, pk_attr, pk_hit;
+  std::vector<uint64_t> pk_hbase;
   std::vector<uint8_t> pk_w;
   std::vector<uint64_t> pk_exc;
   bool packed = ctx->pack && d->n_fields <= 8;
@@ -363,6 +368,7 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
       } else {
         pk_base.reserve(nblk), pk_doff.reserve(nblk), pk_w.reserve(nblk);
         pk_delta.reserve(nd + 64), pk_attr.reserve(nblk * 64), pk_exc.reserve(ne + 1);
+        pk_hit.reserve(nblk * 128), pk_hbase.reserve(nblk);
         for (uint32_t t = 0; t < d->n_terms; ++t) {
           PackedTerm& x = pt[t];
           HostTerm& h = s->terms[t];
@@ -376,6 +382,8 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
           pk_delta.insert(pk_delta.end(), x.delta.begin(), x.delta.end());
           pk_attr.insert(pk_attr.end(), x.attr.begin(), x.attr.end());
           pk_exc.insert(pk_exc.end(), x.exc.begin(), x.exc.end());
+          pk_hit.insert(pk_hit.end(), x.hit.begin(), x.hit.end());
+          pk_hbase.insert(pk_hbase.end(), x.hbase.begin(), x.hbase.end());
           x = PackedTerm();
         }
       }
@@ -390,12 +398,14 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
         (rc = upload(&s->d_pk_w, pk_w.data(), pk_w.size(), 64, ctx->stream)) != MRK_OK ||
         (rc = upload(&s->d_pk_delta, pk_delta.data(), pk_delta.size() * 4, 1024, ctx->stream)) != MRK_OK ||
         (rc = upload(&s->d_pk_attr, pk_attr.data(), pk_attr.size() * 4, 64, ctx->stream)) != MRK_OK ||
-        (rc = upload(&s->d_pk_exc, pk_exc.data(), pk_exc.size() * 8, 64, ctx->stream)) != MRK_OK) {
+        (rc = upload(&s->d_pk_exc, pk_exc.data(), pk_exc.size() * 8, 64, ctx->stream)) != MRK_OK ||
+        (rc = upload(&s->d_pk_hit, pk_hit.data(), pk_hit.size() * 4, 64, ctx->stream)) != MRK_OK ||
+        (rc = upload(&s->d_pk_hbase, pk_hbase.data(), pk_hbase.size() * 8, 64, ctx->stream)) != MRK_OK) {
       mrk_segment_destroy(s);
       return rc;
     }
     s->has_packed = true;
-    s->device_bytes += pk_base.size() * 9 + pk_delta.size() * 4 + pk_attr.size() * 4 + pk_exc.size() * 8;
+    s->device_bytes += pk_base.size() * 17 + pk_delta.size() * 4 + pk_attr.size() * 4 + pk_exc.size() * 8 + pk_hit.size() * 4;
   }
   if ((rc = upload(&s->d_spd, d->spd, d->spd_len, 64, ctx->stream)) != MRK_OK ||
       (rc = upload(&s->d_spp, d->spp, d->spp ? d->spp_len : 0, 64, ctx->stream)) != MRK_OK ||
@@ -417,6 +427,8 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
   s->dev.pk_delta = (const uint32_t*)s->d_pk_delta;
   s->dev.pk_attr = (const uint32_t*)s->d_pk_attr;
   s->dev.pk_exc = (const uint64_t*)s->d_pk_exc;
+  s->dev.pk_hit = (const uint32_t*)s->d_pk_hit;
+  s->dev.pk_hbase = (const uint64_t*)s->d_pk_hbase;
   s->dev.spd = (const uint8_t*)s->d_spd;
   s->dev.spp = (const uint8_t*)s->d_spp;
   s->dev.blk_base = (const uint32_t*)s->d_blk_base;
@@ -465,7 +477,7 @@ struct PlanTerm {
 // returns MRK_OK, or MRK_E_UNSUPPORTED / MRK_E_INVAL with the message set
 static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
                       std::vector<DevItem>& items, uint32_t qi, uint64_t& algo_bytes, uint64_t& dev_bytes,
-                      uint64_t& cand_total) {
+                      uint64_t& cand_total, bool& prox_out) {
   memset(&dq, 0, sizeof dq);
   dq.item_first = (uint32_t)items.size();
   if (!q.nodes || q.n_nodes <= 0 || q.root < 0 || q.root >= q.n_nodes) return mrk_fail(MRK_E_INVAL, "query %u: bad tree", qi);
@@ -506,13 +518,24 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, root.op);
 
   uint32_t ranker;
+  bool prox = false;
   switch (q.ranker) {
     case MRK_RANK_NONE: ranker = MRK_RANK_NONE; break;
     case MRK_RANK_BM25: ranker = MRK_RANK_BM25; break;
     case MRK_RANK_PROXIMITY_BM25:
-      // a single keyword is ranked by ExtRanker_WeightSum_c<BM25> (sphinxsearch.cpp:4195-4196)
-      if (!single_word) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity_bm25 over several keywords needs the hit path", qi);
-      ranker = MRK_RANK_BM25;
+    case MRK_RANK_PROXIMITY:
+      // a single keyword is ranked by ExtRanker_WeightSum_c (sphinxsearch.cpp:4195-4196, 4216-4217)
+      if (single_word)
+        ranker = q.ranker == MRK_RANK_PROXIMITY_BM25 ? MRK_RANK_BM25 : MRK_RANK_PROXIMITY;
+      else {
+        if (!use_packed || !seg->dev.pk_hit)
+          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity rankers run on the packed path only", qi);
+        if ((int)terms.size() > MAX_PROX_TERMS)
+          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity over %zu keywords (device path: <= %d)", qi, terms.size(), MAX_PROX_TERMS);
+        if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity path needs < 2^31 docs per segment", qi);
+        ranker = (uint32_t)q.ranker;
+        prox = true;
+      }
       break;
     default: return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker %d not on the device path", qi, q.ranker);
   }
@@ -520,6 +543,8 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   // ExtMultiAnd_T sorts its nodes by ascending docs with sphSort (searchnode.cpp:2791); for
   // query-sized arrays that is the insertion sort of sphinxstd.h:853-869, which moves an element
   // left past every element that is not less than it: equal keys end in reverse arrival order.
+  if (ranker == MRK_RANK_PROXIMITY && single_word && !use_packed)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker=proximity runs on the packed path only", qi);
   const int n = (int)terms.size();
   std::vector<int> ord(n);
   for (int i = 0; i < n; ++i) ord[i] = i;
@@ -538,6 +563,8 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
     t.weighted_first = !seen;
     if (!seen) words.push_back(ord[i]);
   }
+  if (prox && (int)words.size() != n)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: duplicate keywords need RankerState_Proximity_fn<HANDLE_DUPES>, not on the device path", qi);
   const int64_t total_docs = q.total_docs_override > 0 ? q.total_docs_override : (int64_t)seg->total_docs;
   for (int w : words) {
     PlanTerm& t = terms[w];
@@ -605,19 +632,28 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
       const int64_t bm_lo = (int64_t)floor((lo + 0.5) * 1000.0) - 2, bm_hi = (int64_t)ceil((hi + 0.5) * 1000.0) + 2;
       int64_t rmin = INT64_MAX, rmax = INT64_MIN;
       const uint32_t nwf = std::min<uint32_t>(dq.n_weights, 8u);
-      for (uint32_t m = 0; m < 256; ++m) {
-        int64_t r = 0;
-        if (!m)
-          r = 1;
-        else
-          for (uint32_t f = 0; f < nwf; ++f)
-            if (m & (1u << f)) r += dq.weights[f];
-        rmin = std::min(rmin, r);
-        rmax = std::max(rmax, r);
-      }
+      if (prox) {
+        // sum_f LCS[f] * w[f] with 0 <= LCS[f] <= number of keywords (hit weight 1, unique keywords)
+        rmin = rmax = 0;
+        for (uint32_t f = 0; f < nwf; ++f) {
+          rmin += std::min<int64_t>(0, (int64_t)n * dq.weights[f]);
+          rmax += std::max<int64_t>(0, (int64_t)n * dq.weights[f]);
+        }
+      } else
+        for (uint32_t m = 0; m < 256; ++m) {
+          int64_t r = 0;
+          if (!m)
+            r = 1;
+          else
+            for (uint32_t f = 0; f < nwf; ++f)
+              if (m & (1u << f)) r += dq.weights[f];
+          rmin = std::min(rmin, r);
+          rmax = std::max(rmax, r);
+        }
+      const bool with_bm = ranker != MRK_RANK_PROXIMITY;
       const int64_t iw = (int32_t)dq.index_weight;
-      const int64_t c[4] = {(bm_lo + rmin * 1000) * iw, (bm_lo + rmax * 1000) * iw, (bm_hi + rmin * 1000) * iw,
-                            (bm_hi + rmax * 1000) * iw};
+      const int64_t sc = with_bm ? 1000 : 1, b0 = with_bm ? bm_lo : 0, b1 = with_bm ? bm_hi : 0;
+      const int64_t c[4] = {(b0 + rmin * sc) * iw, (b0 + rmax * sc) * iw, (b1 + rmin * sc) * iw, (b1 + rmax * sc) * iw};
       const int64_t wlo = *std::min_element(c, c + 4), whi = *std::max_element(c, c + 4);
       if (wlo > INT32_MIN && whi < INT32_MAX && std::llabs(rmin * 1000) < INT32_MAX && std::llabs(rmax * 1000) < INT32_MAX) {
         const uint64_t span = (uint64_t)(whi - wlo) + 1;
@@ -634,6 +670,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   }
   algo_bytes += bytes;
   dev_bytes += use_packed ? pbytes : bytes;
+  prox_out = prox_out || prox;
 
   // work items: contiguous ranges of driver-term blocks, ~item_bytes of doclist each
   const uint32_t nb0 = dq.t[0].nblocks;
@@ -740,11 +777,12 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   items.reserve(n * 4);
   uint64_t algo_bytes = 0, dev_bytes = 0, cand_total = 0;
   uint32_t max_terms = 1;
+  bool any_prox = false;
   if (b->ctx->path == 2 && !seg->has_packed) return mrk_fail(MRK_E_UNSUPPORTED, "path=packed but the segment has no packed doclists");
   const bool use_packed = seg->has_packed && b->ctx->path != 1;
   for (uint32_t i = 0; i < n; ++i) {
     int rc = plan_query(seg, queries[i], b->ctx->item_bytes, use_packed, b->h_queries.p[i], items, i, algo_bytes, dev_bytes,
-                        cand_total);
+                        cand_total, any_prox);
     b->status[i] = rc;
     if (rc == MRK_E_INVAL) return rc;
     if (rc != MRK_OK) { // unsupported: reported per query, runs no device work
@@ -799,7 +837,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   sa.cand = b->d_cand.p;
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
   if (use_packed)
-    launch_scan_pk(sa, max_terms, st);
+    launch_scan_pk(sa, max_terms, any_prox, st);
   else
     launch_scan(sa, st);
   HIP_TRY(hipEventRecord(b->ev_scan1, st));

@@ -54,6 +54,9 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
   out.doff.reserve(nblk);
   out.w.reserve(nblk);
   out.attr.assign((size_t)nblk * 64, 0);
+  out.hit.assign((size_t)nblk * 128, 0);
+  out.hbase.reserve(nblk);
+  uint64_t hit_position = 0; // m_uHitPosition / m_iHitlistPos (sphinx.cpp:534, 542)
   out.delta.reserve((size_t)nblk * 32 + 8);
 
   uint32_t rowid = 0xFFFFFFFFu; // decoder starts at INVALID_ROWID (sphinx.cpp:12947)
@@ -62,6 +65,9 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
     const uint32_t n = nd_total - b * 128 < 128 ? nd_total - b * 128 : 128;
     const uint32_t base = rowid + 1u;
     uint32_t dmax = 0;
+    const uint64_t hb = hit_position;
+    out.hbase.push_back(hb);
+    uint32_t* hitref = out.hit.data() + (size_t)b * 128;
     for (uint32_t i = 0; i < n; ++i) {
       const uint32_t delta = (uint32_t)rd.vlb();
       if (!rd.ok || delta == 0) {
@@ -82,12 +88,23 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
           const uint32_t fe = (uint32_t)rd.vlb();
           const uint32_t f = (fe >> 1) & 255u;
           fields = f < 32 ? (1u << f) : 0u;
+          hitref[i] = first | (fe << 23); // the inlined hit, as SeekHitlist keeps it (sphinx.cpp:526, 464)
         } else {
           fields = first;
-          (void)rd.vlb(); // hitlist offset delta
+          hit_position += rd.vlb(); // hitlist offset delta
+          if (hit_position - hb > 0xFFFFFFFFull) {
+            err = "hitlists of one block span more than 4 GiB";
+            return false;
+          }
+          hitref[i] = (uint32_t)(hit_position - hb);
         }
       } else {
-        (void)rd.vlb();
+        hit_position += rd.vlb();
+        if (hit_position - hb > 0xFFFFFFFFull) {
+          err = "hitlists of one block span more than 4 GiB";
+          return false;
+        }
+        hitref[i] = (uint32_t)(hit_position - hb);
         fields = (uint32_t)rd.vlb();
         hits = (uint32_t)rd.vlb();
       }

@@ -16,6 +16,9 @@ struct PackedTerm {
   std::vector<uint32_t> delta; // this term's delta run
   std::vector<uint32_t> attr;  // 64 words per block
   std::vector<uint64_t> exc;   // rowid<<32 | tf for tf >= 255
+  std::vector<uint32_t> hit;   // 128 per block: the inlined Hitpos_t (inline format, tf == 1) or the doc's
+                               // hitlist offset in .spp relative to hbase[block]
+  std::vector<uint64_t> hbase; // per block: SkiplistEntry_t::m_iBaseHitlistPos
   uint64_t packed_bytes = 0;   // bytes a scan of the whole term reads (deltas + attrs + block index)
 };
 

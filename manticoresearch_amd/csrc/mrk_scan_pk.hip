@@ -24,8 +24,11 @@ namespace mrk {
 #endif
 constexpr int CBUF = MRK_CBUF; // candidates a wave collects before it publishes them
 
+template <bool PROX>
 struct __align__(16) PkWaveLds {
   uint64_t cbuf[CBUF];  // candidates not yet published to the query's global list
+  // proximity rankers: where each matched doc sits in the other terms' blocks (block<<7 | slot, bit 31 = lone hit)
+  uint32_t href[PROX ? MAX_PROX_TERMS - 1 : 1][PROX ? DEVBLK : 1];
   uint32_t tj_rowid[DEVBLK];
   uint32_t tj_attr[64];
   union {
@@ -35,8 +38,9 @@ struct __align__(16) PkWaveLds {
 };
 static_assert(NBINS * 4 <= MAPCAP, "hist must fit the map area");
 
+template <bool PROX>
 struct __align__(16) PkSmem {
-  PkWaveLds w[WAVES];
+  PkWaveLds<PROX> w[WAVES];
   uint32_t rank[256];
   float tfidf[1][256]; // really [n_terms][256]: the tail lives in dynamic LDS right behind this struct
 };
@@ -172,9 +176,52 @@ __device__ uint32_t exc_tf(const DevSegment& seg, const DevTerm& T, uint32_t row
   return 255u;
 }
 
+// one VLB-coded u32 out of the hitlist file at byte position p (GetHitlistEntry, sphinx.cpp:374-388):
+// two aligned dwords + a funnel shift give the 4-byte window; a 5th byte is fetched when needed
+__device__ __forceinline__ uint32_t read_vlb32(const uint8_t* __restrict__ spp, uint64_t& p) {
+  const uint64_t al = p & ~3ull;
+  const uint32_t w0 = *reinterpret_cast<const uint32_t*>(spp + al);
+  const uint32_t w1 = *reinterpret_cast<const uint32_t*>(spp + al + 4);
+  uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)p & 3u);
+  uint32_t val = 0, n = 0, bb;
+  do {
+    bb = x & 0xffu;
+    x >>= 8;
+    val = (val << 7) | (bb & 0x7fu);
+    ++n;
+  } while ((bb & 0x80u) && n < 4);
+  if (bb & 0x80u) { // 5-byte varint
+    bb = spp[p + 4];
+    val = (val << 7) | (bb & 0x7fu);
+    ++n;
+  }
+  p += n;
+  return val;
+}
+
+// next hit of one keyword in one doc (GetNextHit, sphinx.cpp:479-501); 0 (EMPTY_HIT) when exhausted
+__device__ __forceinline__ void hit_advance(const uint8_t* __restrict__ spp, uint64_t& p, uint32_t& cur) {
+  if (!p) {
+    cur = 0;
+    return;
+  }
+  const uint32_t d = read_vlb32(spp, p);
+  if (!d) {
+    p = 0;
+    cur = 0;
+  } else
+    cur += d;
+}
+
+__device__ __forceinline__ bool field_queried(uint32_t qmask, uint32_t hitpos) {
+  const uint32_t f = hitpos >> 24;
+  return f < 32 ? ((qmask >> f) & 1u) != 0 : qmask == 0xFFFFFFFFu;
+}
+
+template <bool PROX>
 __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   extern __shared__ __align__(16) uint8_t smem_raw[];
-  PkSmem& s = *reinterpret_cast<PkSmem*>(smem_raw);
+  PkSmem<PROX>& s = *reinterpret_cast<PkSmem<PROX>*>(smem_raw);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= a.n_items) return;
   const DevItem item = a.items[blockIdx.x];
@@ -184,7 +231,9 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const uint32_t index_weight = Q->index_weight;
   const DevTerm T0 = Q->t[0];
   const DevTerm T1 = Q->t[nterms > 1 ? 1 : 0];
-  PkWaveLds& L = s.w[wave];
+  const bool inline_hits = a.seg.inline_hits != 0;
+  const bool prox_ranker = PROX && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && nterms > 1;
+  PkWaveLds<PROX>& L = s.w[wave];
   // per-workgroup tables: tfidf(tf) per term, field-weight sum per mask
   for (uint32_t j = 0; j < nterms; ++j) s.tfidf[j][tid] = term_tfidf(tid, Q->t[j].idf);
   {
@@ -475,6 +524,8 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
                 hit[r] = true;
                 acc[r] = acc[r] + (tfj[r] == 255u ? term_tfidf(exc_tf(a.seg, Tj, row[r]), Tj.idf) : tv[r]);
                 fld[r] |= fj[r];
+                if (PROX && j < (uint32_t)MAX_PROX_TERMS)
+                  L.href[j - 1][lane + 64 * r] = ((inline_hits && tfj[r] == 1u) ? 0x80000000u : 0u) | (kj << 7) | pos[r];
               }
             }
           }
@@ -487,6 +538,94 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       }
 
       if (gt_new > tau_bin) tau_bin = gt_new;
+      // ---- proximity rankers: per matched doc merge the keywords' hit streams by (hitpos, qpos)
+      // (MergeHits2/3/N, searchnode.cpp:3047-3181) and run RankerState_Proximity_fn (sphinxsearch.cpp:1351-1437)
+      int prank[2] = {0, 0};
+      if (PROX && prox_ranker) {
+        wave_lds_fence();
+        const uint8_t* __restrict__ spp = a.seg.spp;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          if (live[r]) {
+            uint64_t sp[MAX_PROX_TERMS];
+            uint32_t sc[MAX_PROX_TERMS], sq[MAX_PROX_TERMS], sm[MAX_PROX_TERMS];
+#pragma unroll
+            for (int t = 0; t < MAX_PROX_TERMS; ++t) {
+              sp[t] = 0, sc[t] = 0, sq[t] = 0, sm[t] = 0;
+              if ((uint32_t)t < nterms) {
+                const DevTerm& Tt = Q->t[t];
+                uint32_t gblk, idx;
+                bool lone;
+                if (t == 0) {
+                  gblk = T0.blk_first + b;
+                  idx = lane + 64 * r;
+                  lone = inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u;
+                } else {
+                  const uint32_t h = L.href[t - 1][lane + 64 * r];
+                  gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu);
+                  idx = h & 127u;
+                  lone = (h >> 31) != 0;
+                }
+                sq[t] = Tt.qpos;
+                sm[t] = Tt.queried32;
+                const uint32_t hv = a.seg.pk_hit[(uint64_t)gblk * DEVBLK + idx];
+                if (lone) // the hit travelled in the doclist entry (SeekHitlist state 1, sphinx.cpp:461-464)
+                  sc[t] = hv;
+                else {
+                  sp[t] = a.seg.pk_hbase[gblk] + hv;
+                  hit_advance(spp, sp[t], sc[t]);
+                }
+              }
+            }
+            uint64_t lcs = 0; // m_uLCS[field], one byte per field (<= 8 fields on this path)
+            uint32_t cur_lcs = 0;
+            int exp_delta = -1, last_pwf = -1;
+            // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
+            // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
+            int phase = (nterms == 3 && (sm[0] & sm[1] & sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
+            for (;;) {
+              if (phase == 0 && !(sc[0] && sc[1] && sc[2])) {
+                if (!sc[0])
+                  tl = 1, tr = 2;
+                else if (!sc[1])
+                  tl = 0, tr = 2;
+                else
+                  tl = 0, tr = 1;
+                phase = 1;
+              }
+              if (phase == 1) {
+                const uint32_t cl = tl == 0 ? sc[0] : sc[1], cr = tr == 1 ? sc[1] : sc[2];
+                if (!(cl && cr)) phase = 2;
+              }
+              int best = -1;
+              uint32_t bh = 0, bq = 0, bmask = 0;
+#pragma unroll
+              for (int t = 0; t < MAX_PROX_TERMS; ++t)
+                if (sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && sq[t] < bq))) best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
+              if (best < 0) break;
+              if (phase == 1) bmask = best == tl ? sm[0] : sm[1];
+              // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
+              if (field_queried(bmask, bh)) {
+                // RankerState_Proximity_fn<.., false>::Update; hit weight = spanlen = 1 for plain keywords
+                const int pwf = (int)(bh & ~(1u << 23));
+                const int delta = pwf - (int)(bq & 0xFFFFu);
+                if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + 1u) & 0xffu; // BYTE arithmetic
+                const uint32_t f = bh >> 24;
+                if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu))
+                  lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
+                last_pwf = pwf;
+                exp_delta = delta;
+              }
+#pragma unroll
+              for (int t = 0; t < MAX_PROX_TERMS; ++t)
+                if (t == best) hit_advance(spp, sp[t], sc[t]);
+            }
+            int rk = 0;
+            for (uint32_t f = 0; f < nw; ++f) rk += (int)((lcs >> (8 * f)) & 0xffu) * Q->weights[f];
+            prank[r] = rk;
+          }
+        }
+      }
       // ---- matches: weight, pruning bin, candidates
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -497,7 +636,13 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
           uint32_t weight;
           if (ranker == MRK_RANK_NONE)
             weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
-          else {
+          else if (PROX && prox_ranker) {
+            // RankerState_Proximity_fn::Finalize, sphinxsearch.cpp:1415-1437
+            const int32_t bm = (int32_t)((acc[r] + 0.5f) * 1000.0f);
+            weight = ranker == MRK_RANK_PROXIMITY_BM25 ? (uint32_t)bm + (uint32_t)prank[r] * 1000u : (uint32_t)prank[r];
+          } else if (ranker == MRK_RANK_PROXIMITY) {
+            weight = s.rank[fld[r]]; // single keyword: ExtRanker_WeightSum_c<> without BM25 (sphinxsearch.cpp:4216-4217, 1131)
+          } else {
             // ExtRanker_WeightSum_c<BM25>, sphinxsearch.cpp:1070, 1112-1129
             const int32_t bm = (int32_t)((acc[r] + 0.5f) * 1000.0f);
             weight = (uint32_t)bm + s.rank[fld[r]] * 1000u;
@@ -595,11 +740,14 @@ __global__ __launch_bounds__(WG) void select_kernel(SelectArgs a) {
   if (tid == 0) a.out_cnt[q] = m;
 }
 
-void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, void* stream) {
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, void* stream) {
   if (!a.n_items) return;
   if (max_terms < 1) max_terms = 1;
-  const size_t lds = sizeof(PkSmem) + (size_t)(max_terms - 1) * 256 * sizeof(float);
-  hipLaunchKernelGGL(scan_pk_kernel, dim3(a.n_items), dim3(WG), lds, (hipStream_t)stream, a);
+  const size_t tail = (size_t)(max_terms - 1) * 256 * sizeof(float);
+  if (prox)
+    hipLaunchKernelGGL(scan_pk_kernel<true>, dim3(a.n_items), dim3(WG), sizeof(PkSmem<true>) + tail, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(scan_pk_kernel<false>, dim3(a.n_items), dim3(WG), sizeof(PkSmem<false>) + tail, (hipStream_t)stream, a);
 }
 
 void launch_select(const SelectArgs& a, void* stream) {

@@ -818,7 +818,11 @@ static int mand_next(enode* e) { /* GetDocsChunk, :2893-2981, one doc per call *
 }
 
 /* MergeHits2/3/N, :3047-3181: k-way merge by (hitpos, qpos); with distinct
-   atom positions the order is total, so one generic merge restates all three */
+   atom positions the order is total, so one generic merge restates all three.
+   One literal quirk is kept: the 3-stream merge finishes with the 2-stream DoHitMerge
+   (:3072-3077), whose AddHit calls test the hit's field against nodes 0 and 1
+   (:3052-3054) whichever two streams are left; only CopyHits (:3082-3096) uses the
+   right node again. */
 static void mand_hits(enode* e, hitvec* out) {
   uint32_t cur[32];
   int k = e->n_m;
@@ -826,7 +830,18 @@ static void mand_hits(enode* e, hitvec* out) {
     qw_seek_hitlist(&e->m[i].qw, e->m[i].stored_hitpos);
     cur[i] = qw_next_hit(&e->m[i].qw);
   }
+  int phase = (k == 3 && e->test_fields) ? 0 : 2, tl = 0, tr = 1;
   for (;;) {
+    if (phase == 0 && !(cur[0] != ORC_EMPTY_HIT && cur[1] != ORC_EMPTY_HIT && cur[2] != ORC_EMPTY_HIT)) {
+      if (cur[0] == ORC_EMPTY_HIT)
+        tl = 1, tr = 2;
+      else if (cur[1] == ORC_EMPTY_HIT)
+        tl = 0, tr = 2;
+      else
+        tl = 0, tr = 1;
+      phase = 1;
+    }
+    if (phase == 1 && !(cur[tl] != ORC_EMPTY_HIT && cur[tr] != ORC_EMPTY_HIT)) phase = 2;
     int best = -1;
     for (int i = 0; i < k; i++) {
       if (cur[i] == ORC_EMPTY_HIT) continue;
@@ -836,7 +851,9 @@ static void mand_hits(enode* e, hitvec* out) {
     }
     if (best < 0) break;
     mnode* n = &e->m[best];
-    if (!e->test_fields || queried_test(n->queried32, ORC_HIT_FIELD(cur[best]))) {
+    uint32_t fmask = n->queried32;
+    if (phase == 1) fmask = e->m[best == tl ? 0 : 1].queried32;
+    if (!e->test_fields || queried_test(fmask, ORC_HIT_FIELD(cur[best]))) {
       hit_t t;
       t.rowid = e->rowid;
       t.hitpos = cur[best];

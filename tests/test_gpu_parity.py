@@ -278,3 +278,90 @@ def test_synth_medium_and_merge_across_shards(orc, dev):
         gr = [(~k) & 0xFFFFFFFF for k in ks]
         assert [(-w, r) for w, r in zip(gw, gr)] == allm
     ctx.set("item_bytes", 128 << 10)
+
+
+# ------------------------------------------------------------------ proximity rankers (hit path)
+def test_golden_proximity_weights_on_device(dev):
+    """Reference goldens that need hitlists: test_019 'basic query' -> 111:2654, '@title sample @body world' ->
+    333:2666; test_322 'program flow' under five field-weight settings (incl. negative)."""
+    m, ctx, batch = dev
+    if ctx_path(ctx) != 0:
+        pytest.skip("proximity rankers run on the packed path")
+    W, R, H, v = make_hits(T019, 2)
+    seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(T019)))
+    r = batch.search(seg, [m.Query(m.XQNode.AND(kw(m, v["basic"], 1), kw(m, v["query"], 2))),
+                           m.Query(m.XQNode.AND(kw(m, v["sample"], 1, mask=0b01), kw(m, v["world"], 2, mask=0b10)))])
+    assert [(T019_IDS[i], int(w)) for i, w in zip(r[0].rowid, r[0].weight)] == [(111, 2654)]
+    assert [(T019_IDS[i], int(w)) for i, w in zip(r[1].rowid, r[1].weight)] == [(333, 2666)]
+    seg.close()
+    W, R, H, v = make_hits(T322)
+    seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(T322), n_fields=3))
+    ids = [1, 2, 3, 100]
+    root = m.XQNode.AND(kw(m, v["program"], 1), kw(m, v["flow"], 2))
+    want = {1: [(1, 7415), (3, 6426), (2, 4421)], 10: [(1, 25415), (3, 15426), (2, 13421)],
+            0: [(3, 5426), (1, 5415), (2, 3421)], -2: [(3, 3426), (2, 1421), (1, 1415)],
+            -10: [(3, -4574), (2, -6579), (1, -14585)]}
+    for spam, exp in want.items():
+        r = batch.search(seg, [m.Query(root, ranker=m.SPH_RANK_PROXIMITY_BM25, field_weights=[1, 2, spam])])[0]
+        assert [(ids[i], int(w)) for i, w in zip(r.rowid, r.weight)] == exp
+    seg.close()
+
+
+@pytest.mark.parametrize("block,fmt", [(128, 1), (32, 1), (128, 0)])
+def test_random_corpus_proximity(orc, dev, block, fmt):
+    m, ctx, batch = dev
+    if ctx_path(ctx) != 0:
+        pytest.skip("proximity rankers run on the packed path")
+    rng = np.random.default_rng(4321 + block + fmt)
+    n_docs = 40000
+    probs = [0.5, 0.3, 0.12, 0.05, 0.02, 0.004, 0.9]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=40, end_markers=True)
+    hi = m.index_from_hits(W, R, H, n_terms=len(probs), total_docs=n_docs, skiplist_block_size=block, hit_format=fmt, n_fields=3)
+    qs = []
+    for _ in range(120):
+        k = int(rng.integers(2, 5))
+        ts = rng.choice(len(probs), size=k, replace=False)
+        masks = [0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)) for _ in ts]
+        # atom positions as the parser numbers them, sometimes with a gap (stop word)
+        pos, ap = [], 0
+        for _ in ts:
+            ap += 1 if rng.random() < 0.85 else 2
+            pos.append(ap)
+        root = m.XQNode.AND(*[kw(m, int(t), p, mk) for t, p, mk in zip(ts, pos, masks)])
+        qs.append(m.Query(root, ranker=int(rng.choice([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY])),
+                          max_matches=int(rng.choice([5, 100, 1000])),
+                          field_weights=[int(x) for x in rng.integers(-3, 12, 3)] if rng.random() < 0.5 else None,
+                          index_weight=int(rng.choice([1, 1, 2]))))
+    for t in range(len(probs)):  # single keyword: WeightSum with / without BM25
+        qs.append(m.Query(kw(m, t, 1), ranker=m.SPH_RANK_PROXIMITY))
+        qs.append(m.Query(kw(m, t, 1), ranker=m.SPH_RANK_PROXIMITY_BM25))
+    check_batch(orc, dev, hi, qs)
+
+
+def test_proximity_long_hitlists(orc, dev):
+    """Docs with hundreds of hits per keyword, 5-byte hit deltas (field jumps), phrases that do line up."""
+    m, ctx, batch = dev
+    if ctx_path(ctx) != 0:
+        pytest.skip("proximity rankers run on the packed path")
+    rng = np.random.default_rng(77)
+    W, R, H = [], [], []
+    n_docs = 3000
+    for t in range(3):
+        for r in range(n_docs):
+            if rng.random() < 0.6:
+                n = int(rng.integers(1, 300)) if rng.random() < 0.2 else int(rng.integers(1, 6))
+                fields = rng.choice([0, 1, 7], size=n)
+                # keyword t often sits at position base+t so that consecutive keywords form runs
+                base = rng.integers(1, 200, size=n)
+                hp = np.unique((fields.astype(np.uint32) << 24) | (base + t).astype(np.uint32))
+                W += [t + 1] * len(hp)
+                R += [r] * len(hp)
+                H += list(hp)
+    order = np.lexsort((np.array(H), np.array(R), np.array(W)))
+    W, R, H = np.array(W, np.uint64)[order], np.array(R, np.uint32)[order], np.array(H, np.uint32)[order]
+    hi = m.index_from_hits(W, R, H, n_terms=3, total_docs=n_docs, n_fields=8)
+    qs = [m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2), kw(m, 2, 3)), ranker=m.SPH_RANK_PROXIMITY_BM25,
+                  field_weights=[3, 2, 1, 1, 1, 1, 1, 5]),
+          m.Query(m.XQNode.AND(kw(m, 2, 1), kw(m, 0, 2)), ranker=m.SPH_RANK_PROXIMITY_BM25),
+          m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_PROXIMITY, max_matches=50)]
+    check_batch(orc, dev, hi, qs)
