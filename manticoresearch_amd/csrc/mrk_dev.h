@@ -43,6 +43,10 @@ struct DevSegment {
 constexpr uint32_t PK_WIDE = 0xFFu;
 constexpr int NBINS = 1024; // pruning histogram bins per query
 constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
+constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4; // prog[] opcodes
+constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
+constexpr int TREE_STACK = 4;       // evaluation stack depth of the tree program
+constexpr int MAX_PASSES = 4; // driver keywords per query (size of the tree's candidate cover)
 constexpr uint32_t QF_OVERFLOW = 1; // candidate list overflowed: the query's result is not trustworthy
 constexpr int MAPCAP = 4096; // direct-map probe window (rowids) per decoded block
 
@@ -71,6 +75,14 @@ struct DevQuery {
   uint32_t bin_shift;
   uint32_t cand_cap;  // capacity of this query's candidate list
   uint64_t cand_off;  // its offset in the candidate arena
+  // boolean trees (ExtAnd_c / ExtOr_c / ExtMaybe_c / ExtAndNot_c): a query may run as several
+  // passes, one per driver keyword; all passes feed the logical query out_q
+  uint32_t out_q;     // logical query slot (histogram, candidate list, totals)
+  uint32_t n_nodes;   // 0 = plain N-way AND of t[]; else post-order program in prog[]
+  uint32_t req_mask;  // keywords (bit = index in t[]) without which the tree cannot match
+  uint32_t excl_mask; // keywords whose presence hands the doc to an earlier pass
+  uint32_t tree_flags; // TF_*
+  uint32_t prog[16];  // op | left node << 8 | right node << 16 | keyword << 24
   int32_t weights[32];
   DevTerm t[MRK_MAX_AND_TERMS];
 };
@@ -131,7 +143,7 @@ struct MergeArgs {
 };
 
 void launch_scan(const ScanArgs& a, void* stream);
-void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, void* stream);
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, void* stream);
 constexpr int MAX_PROX_TERMS = 4; // keywords whose hit streams the proximity kernel merges per doc
 void launch_select(const SelectArgs& a, void* stream);
 void launch_merge(const MergeArgs& a, void* stream);

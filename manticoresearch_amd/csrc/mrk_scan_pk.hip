@@ -24,13 +24,16 @@ namespace mrk {
 #endif
 constexpr int CBUF = MRK_CBUF; // candidates a wave collects before it publishes them
 
-template <bool PROX>
+template <bool PROX, bool TREE>
 struct __align__(16) PkWaveLds {
   uint64_t cbuf[CBUF];  // candidates not yet published to the query's global list
   // proximity rankers: where each matched doc sits in the other terms' blocks (block<<7 | slot, bit 31 = lone hit)
   uint32_t href[PROX ? MAX_PROX_TERMS - 1 : 1][PROX ? DEVBLK : 1];
   uint32_t tj_rowid[DEVBLK];
   uint32_t tj_attr[64];
+  // boolean trees: what each keyword contributes to each doc of the driver block (tfidf term, field bits)
+  float kv[TREE ? MRK_MAX_AND_TERMS : 1][TREE ? DEVBLK : 4];
+  uint8_t kf[TREE ? MRK_MAX_AND_TERMS : 1][TREE ? DEVBLK : 16];
   union {
     uint8_t map[MAPCAP];  // rowid offset -> slot of the decoded other-term block
     uint32_t hist[NBINS]; // publishing scratch: per-bin counts of the candidates being flushed
@@ -38,9 +41,9 @@ struct __align__(16) PkWaveLds {
 };
 static_assert(NBINS * 4 <= MAPCAP, "hist must fit the map area");
 
-template <bool PROX>
+template <bool PROX, bool TREE>
 struct __align__(16) PkSmem {
-  PkWaveLds<PROX> w[WAVES];
+  PkWaveLds<PROX, TREE> w[WAVES];
   uint32_t rank[256];
   float tfidf[1][256]; // really [n_terms][256]: the tail lives in dynamic LDS right behind this struct
 };
@@ -218,10 +221,18 @@ __device__ __forceinline__ bool field_queried(uint32_t qmask, uint32_t hitpos) {
   return f < 32 ? ((qmask >> f) & 1u) != 0 : qmask == 0xFFFFFFFFu;
 }
 
-template <bool PROX>
+// one value of the boolean-tree evaluation stack, for the two docs a lane owns
+struct TreeEnt {
+  bool m[2];     // subtree matches the doc
+  float v[2];    // its tfidf sum (0 when unmatched)
+  uint32_t f[2]; // its matched-fields bits
+  uint32_t a[2]; // keywords whose hits it emits
+};
+
+template <bool PROX, bool TREE>
 __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   extern __shared__ __align__(16) uint8_t smem_raw[];
-  PkSmem<PROX>& s = *reinterpret_cast<PkSmem<PROX>*>(smem_raw);
+  PkSmem<PROX, TREE>& s = *reinterpret_cast<PkSmem<PROX, TREE>*>(smem_raw);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= a.n_items) return;
   const DevItem item = a.items[blockIdx.x];
@@ -233,7 +244,11 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const DevTerm T1 = Q->t[nterms > 1 ? 1 : 0];
   const bool inline_hits = a.seg.inline_hits != 0;
   const bool prox_ranker = PROX && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && nterms > 1;
-  PkWaveLds<PROX>& L = s.w[wave];
+  PkWaveLds<PROX, TREE>& L = s.w[wave];
+  const uint32_t oq = Q->out_q; // logical query: several passes (driver keywords) may feed one result
+  const uint32_t req_mask = TREE ? Q->req_mask : 0u, excl_mask = TREE ? Q->excl_mask : 0u;
+  const uint32_t n_nodes = TREE ? Q->n_nodes : 0u;
+  const bool multi_and = !TREE || (Q->tree_flags & TF_MULTIAND) != 0;
   // per-workgroup tables: tfidf(tf) per term, field-weight sum per mask
   for (uint32_t j = 0; j < nterms; ++j) s.tfidf[j][tid] = term_tfidf(tid, Q->t[j].idf);
   {
@@ -249,9 +264,9 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const int32_t bin_lo = Q->bin_lo;
   const uint32_t cand_cap = Q->cand_cap;
   uint64_t* __restrict__ cand = a.cand + Q->cand_off;
-  uint32_t* __restrict__ ghist = a.q_hist + (uint64_t)item.query * NBINS;
-  uint32_t* __restrict__ gcount = a.q_cand_n + item.query;
-  uint32_t* __restrict__ gtaubin = a.q_tau_bin + item.query;
+  uint32_t* __restrict__ ghist = a.q_hist + (uint64_t)oq * NBINS;
+  uint32_t* __restrict__ gcount = a.q_cand_n + oq;
+  uint32_t* __restrict__ gtaubin = a.q_tau_bin + oq;
   const uint32_t nb = item.blk_end - item.blk_begin;
   const uint32_t per = (nb + WAVES - 1) / WAVES;
   const uint32_t wb0 = item.blk_begin + wave * per;
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         if (fits) cand[basep + i] = key;
         atomicAdd(&L.hist[bin_of(bin_mode, bin_lo, bin_shift, key_weight(key), key_rowid(key))], 1u);
       }
-      if (!fits && lane == 0) atomicOr(a.q_flags + item.query, QF_OVERFLOW);
+      if (!fits && lane == 0) atomicOr(a.q_flags + oq, QF_OVERFLOW);
       wave_lds_fence();
 #if MRK_EXP != 4
       flush_hist(L.hist, ghist);
@@ -375,6 +390,16 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         if (tf == 255u && live[r]) t = term_tfidf(exc_tf(a.seg, T0, row[r]), T0.idf);
         acc[r] = 0.0f + t;
       }
+      // trees: live = "still a possible match of this pass"; pres = keywords present in the doc
+      uint32_t pres[2] = {0u, 0u}, act[2] = {0u, 0u};
+      if (TREE) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          pres[r] = live[r] ? 1u : 0u;
+          L.kv[0][lane + 64 * r] = acc[r];
+          L.kf[0][lane + 64 * r] = (uint8_t)fld[r];
+        }
+      }
 
       // ---- the other terms, in ascending-docs order
 #if MRK_EXP == 2 || MRK_EXP == 6
@@ -384,6 +409,10 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
 #endif
         if (!__ballot(live[0] || live[1])) break;
         const DevTerm Tj = j == 1 ? T1 : Q->t[j];
+        if (TREE && Tj.nblocks == 0) { // keyword without postings: present nowhere
+          if ((req_mask >> j) & 1u) live[0] = live[1] = false;
+          continue;
+        }
         bool done[2] = {!live[0], !live[1]};
         bool hit[2] = {false, false};
         if (cj_term != j) {
@@ -522,8 +551,14 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
             for (int r = 0; r < 2; ++r) {
               if (hp[r]) {
                 hit[r] = true;
-                acc[r] = acc[r] + (tfj[r] == 255u ? term_tfidf(exc_tf(a.seg, Tj, row[r]), Tj.idf) : tv[r]);
-                fld[r] |= fj[r];
+                const float tvx = tfj[r] == 255u ? term_tfidf(exc_tf(a.seg, Tj, row[r]), Tj.idf) : tv[r];
+                if (TREE) {
+                  L.kv[j][lane + 64 * r] = tvx;
+                  L.kf[j][lane + 64 * r] = (uint8_t)fj[r];
+                } else {
+                  acc[r] = acc[r] + tvx;
+                  fld[r] |= fj[r];
+                }
                 if (PROX && j < (uint32_t)MAX_PROX_TERMS)
                   L.href[j - 1][lane + 64 * r] = ((inline_hits && tfj[r] == 1u) ? 0x80000000u : 0u) | (kj << 7) | pos[r];
               }
@@ -533,8 +568,73 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
           for (int r = 0; r < 2; ++r)
             if (!done[r] && row[r] < bp1_k) done[r] = true; // cannot happen (cursor only moves forward)
         }
-        live[0] = live[0] && hit[0];
-        live[1] = live[1] && hit[1];
+        if (TREE) {
+          const bool rq = ((req_mask >> j) & 1u) != 0, ex = ((excl_mask >> j) & 1u) != 0;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            if (hit[r]) pres[r] |= 1u << j;
+            if (rq) live[r] = live[r] && hit[r];
+            if (ex) live[r] = live[r] && !hit[r]; // an earlier pass owns this doc
+          }
+        } else {
+          live[0] = live[0] && hit[0];
+          live[1] = live[1] && hit[1];
+        }
+      }
+
+      // ---- boolean tree: post-order program over the keywords' presence bits.  Value rules restate
+      // ExtAnd_c / ExtOr_c / ExtMaybe_c / ExtAndNot_c (searchnode.cpp:2585-2594, 3494-3540, 3587-3600,
+      // 3650-3680): tfidf adds left + right where both sides hold the doc, fields OR together.
+      if (TREE && __ballot(live[0] || live[1])) {
+        TreeEnt s0{}, s1{}, s2{}, s3{};
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+          const uint32_t ins = Q->prog[i];
+          const uint32_t op = ins & 0xffu, kw = ins >> 24;
+          if (op == PN_TERM) {
+            s3 = s2;
+            s2 = s1;
+            s1 = s0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const bool m = live[r] && ((pres[r] >> kw) & 1u);
+              const float v = L.kv[kw][lane + 64 * r];
+              const uint32_t f = L.kf[kw][lane + 64 * r];
+              s0.m[r] = m;
+              s0.v[r] = m ? v : 0.0f;
+              s0.f[r] = m ? f : 0u;
+              s0.a[r] = m ? 1u << kw : 0u;
+            }
+          } else {
+            TreeEnt o;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              bool m;
+              if (op == PN_AND)
+                m = s1.m[r] && s0.m[r];
+              else if (op == PN_OR)
+                m = s1.m[r] || s0.m[r];
+              else if (op == PN_MAYBE)
+                m = s1.m[r];
+              else
+                m = s1.m[r] && !s0.m[r];
+              const bool both = op != PN_ANDNOT; // ANDNOT passes its left side through
+              o.m[r] = m;
+              o.v[r] = m ? (both ? s1.v[r] + s0.v[r] : s1.v[r]) : 0.0f; // x + 0.0f == x: an absent side adds nothing
+              o.f[r] = m ? (both ? s1.f[r] | s0.f[r] : s1.f[r]) : 0u;
+              o.a[r] = m ? (both ? s1.a[r] | s0.a[r] : s1.a[r]) : 0u;
+            }
+            s0 = o;
+            s1 = s2;
+            s2 = s3;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          live[r] = live[r] && s0.m[r];
+          acc[r] = s0.v[r];
+          fld[r] = s0.f[r];
+          act[r] = s0.a[r];
+        }
       }
 
       if (gt_new > tau_bin) tau_bin = gt_new;
@@ -552,7 +652,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
 #pragma unroll
             for (int t = 0; t < MAX_PROX_TERMS; ++t) {
               sp[t] = 0, sc[t] = 0, sq[t] = 0, sm[t] = 0;
-              if ((uint32_t)t < nterms) {
+              if ((uint32_t)t < nterms && (!TREE || ((act[r] >> t) & 1u))) {
                 const DevTerm& Tt = Q->t[t];
                 uint32_t gblk, idx;
                 bool lone;
@@ -582,7 +682,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
             int exp_delta = -1, last_pwf = -1;
             // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
             // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
-            int phase = (nterms == 3 && (sm[0] & sm[1] & sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
+            int phase = (multi_and && nterms == 3 && (sm[0] & sm[1] & sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
             for (;;) {
               if (phase == 0 && !(sc[0] && sc[1] && sc[2])) {
                 if (!sc[0])
@@ -677,7 +777,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   {
     uint32_t t = total;
     for (int dlt = 32; dlt; dlt >>= 1) t += __shfl_down(t, dlt, 64);
-    if (lane == 0 && t) atomicAdd((unsigned long long*)(a.q_total + item.query), (unsigned long long)t);
+    if (lane == 0 && t) atomicAdd((unsigned long long*)(a.q_total + oq), (unsigned long long)t);
   }
 }
 
@@ -740,14 +840,20 @@ __global__ __launch_bounds__(WG) void select_kernel(SelectArgs a) {
   if (tid == 0) a.out_cnt[q] = m;
 }
 
-void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, void* stream) {
+template <bool PROX, bool TREE>
+static void launch_pk(const ScanArgs& a, size_t tail, hipStream_t st) {
+  hipLaunchKernelGGL((scan_pk_kernel<PROX, TREE>), dim3(a.n_items), dim3(WG), sizeof(PkSmem<PROX, TREE>) + tail, st, a);
+}
+
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, void* stream) {
   if (!a.n_items) return;
   if (max_terms < 1) max_terms = 1;
   const size_t tail = (size_t)(max_terms - 1) * 256 * sizeof(float);
-  if (prox)
-    hipLaunchKernelGGL(scan_pk_kernel<true>, dim3(a.n_items), dim3(WG), sizeof(PkSmem<true>) + tail, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (tree)
+    prox ? launch_pk<true, true>(a, tail, st) : launch_pk<false, true>(a, tail, st);
   else
-    hipLaunchKernelGGL(scan_pk_kernel<false>, dim3(a.n_items), dim3(WG), sizeof(PkSmem<false>) + tail, (hipStream_t)stream, a);
+    prox ? launch_pk<true, false>(a, tail, st) : launch_pk<false, false>(a, tail, st);
 }
 
 void launch_select(const SelectArgs& a, void* stream) {

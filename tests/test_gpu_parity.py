@@ -215,7 +215,7 @@ def test_unsupported_shapes_fail_loudly(dev):
     m, ctx, batch = dev
     hi = m.synth_index(1000, [0.5, 0.5], seed=1)
     seg = m.Segment(ctx, hi)
-    q_or = m.Query(m.XQNode(m.SPH_QUERY_OR, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
+    q_or = m.Query(m.XQNode(m.SPH_QUERY_PHRASE, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
     q_big = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25, max_matches=5000)
     q_ok = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25)
     r = batch.search(seg, [q_or, q_ok, q_big])
@@ -365,3 +365,109 @@ def test_proximity_long_hitlists(orc, dev):
           m.Query(m.XQNode.AND(kw(m, 2, 1), kw(m, 0, 2)), ranker=m.SPH_RANK_PROXIMITY_BM25),
           m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_PROXIMITY, max_matches=50)]
     check_batch(orc, dev, hi, qs)
+
+
+# ------------------------------------------------------------------ boolean trees (ExtAnd / ExtOr / ExtMaybe / ExtAndNot)
+def _tree_only(dev):
+    if ctx_path(dev[1]) != 0:
+        pytest.skip("boolean trees run on the packed path")
+
+
+def OR(m, *k):
+    return m.XQNode(m.SPH_QUERY_OR, list(k))
+
+
+def MAYBE(m, *k):
+    return m.XQNode(m.SPH_QUERY_MAYBE, list(k))
+
+
+def ANDNOT(m, *k):
+    return m.XQNode(m.SPH_QUERY_ANDNOT, list(k))
+
+
+def test_golden_boolean_weights_on_device(dev):
+    """test_019 goldens: 'basic | china' -> 444:1610 111:1577 555:1577; '@title sample @body -basic' -> 333:1555 666:1555."""
+    _tree_only(dev)
+    m, ctx, batch = dev
+    W, R, H, v = make_hits(T019, 2)
+    seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(T019)))
+    r = batch.search(seg, [m.Query(OR(m, kw(m, v["basic"], 1), kw(m, v["china"], 2))),
+                           m.Query(ANDNOT(m, kw(m, v["sample"], 1, mask=0b01), kw(m, v["basic"], 2, mask=0b10)))])
+    assert r[0].status == 0 and r[1].status == 0
+    assert [(T019_IDS[i], int(w)) for i, w in zip(r[0].rowid, r[0].weight)] == [(444, 1610), (111, 1577), (555, 1577)]
+    assert [(T019_IDS[i], int(w)) for i, w in zip(r[1].rowid, r[1].weight)] == [(333, 1555), (666, 1555)]
+    seg.close()
+
+
+def _random_tree(m, rng, nt, depth=0):
+    """A random boolean tree over distinct keywords, atom positions in traversal order."""
+    state = {"pos": 0, "used": set()}
+
+    def leaf():
+        while True:
+            t = int(rng.integers(0, nt))
+            if t not in state["used"]:
+                break
+        state["used"].add(t)
+        state["pos"] += 1
+        mk = 0xFFFFFFFF if rng.random() < 0.75 else int(rng.integers(1, 8))
+        return kw(m, t, state["pos"], mk)
+
+    def node(d, budget):
+        if budget <= 1 or d >= 3 or rng.random() < 0.25:
+            return leaf()
+        op = rng.choice(["and", "or", "maybe", "andnot"], p=[0.35, 0.35, 0.15, 0.15])
+        k = 2 if op in ("maybe", "andnot") else int(rng.integers(2, min(3, budget) + 1))
+        kids = [node(d + 1, max(1, budget // k)) for _ in range(k)]
+        return {"and": m.XQNode.AND, "or": lambda *c: OR(m, *c), "maybe": lambda *c: MAYBE(m, *c),
+                "andnot": lambda *c: ANDNOT(m, *c)}[op](*kids)
+
+    return node(0, int(rng.integers(2, 7)))
+
+
+@pytest.mark.parametrize("block,fmt", [(128, 1), (32, 0)])
+def test_random_boolean_trees(orc, dev, block, fmt):
+    _tree_only(dev)
+    m, ctx, batch = dev
+    rng = np.random.default_rng(777 + block + fmt)
+    n_docs = 50000
+    probs = [0.5, 0.3, 0.12, 0.05, 0.02, 0.006, 0.002, 0.9, 0.3, 0.0001]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=30, end_markers=True)
+    nt = len(probs) + 1  # last keyword has no postings
+    hi = m.index_from_hits(W, R, H, n_terms=nt, total_docs=n_docs, skiplist_block_size=block, hit_format=fmt, n_fields=3)
+    a, b, c, d = (kw(m, t, i + 1) for i, t in enumerate((1, 3, 4, 0)))
+    fixed = [OR(m, a, b), OR(m, b, a), m.XQNode.AND(OR(m, a, b), c), m.XQNode.AND(c, OR(m, a, b)), ANDNOT(m, a, b),
+             m.XQNode.AND(a, ANDNOT(m, b, c)), MAYBE(m, b, a), MAYBE(m, c, OR(m, a, b)), OR(m, a, b, c, d),
+             OR(m, m.XQNode.AND(a, b), m.XQNode.AND(c, d)), m.XQNode.AND(OR(m, a, b), OR(m, c, d)),
+             OR(m, a, kw(m, nt - 1, 2)), m.XQNode.AND(OR(m, a, kw(m, nt - 1, 2)), c), ANDNOT(m, a, kw(m, nt - 1, 2)),
+             ANDNOT(m, OR(m, a, b), c), OR(m, ANDNOT(m, a, b), c), m.XQNode.AND(m.XQNode.AND(a, b), c)]
+    qs = []
+    for root in fixed:
+        for rk in (m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_PROXIMITY_BM25):
+            qs.append(m.Query(root, ranker=rk, max_matches=int(rng.choice([10, 1000]))))
+    for _ in range(160):
+        root = _random_tree(m, rng, nt)
+        qs.append(m.Query(root, ranker=int(rng.choice([m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_PROXIMITY_BM25,
+                                                       m.SPH_RANK_PROXIMITY])),
+                          max_matches=int(rng.choice([1, 20, 1000])),
+                          field_weights=[int(x) for x in rng.integers(-3, 12, 3)] if rng.random() < 0.5 else None,
+                          index_weight=int(rng.choice([1, 1, 3])), normalized_tfidf=bool(rng.random() < 0.8)))
+    m_, ctx_, batch_ = dev
+    seg = m.Segment(ctx, hi)
+    oi = orc_index_of(orc, hi)
+    n_ok = 0
+    try:
+        for i in range(0, len(qs), batch.max_queries):
+            chunk = qs[i:i + batch.max_queries]
+            got = batch.search(seg, chunk)
+            for q, g in zip(chunk, got):
+                if g.status == -2:
+                    continue  # shapes the device path declines (too many drivers / keywords for a hit ranker)
+                want = to_orc(orc, q).run(oi)
+                assert g.status == 0
+                assert g.total_found == want.total_found, (g.total_found, want.total_found)
+                assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+                n_ok += 1
+    finally:
+        seg.close()
+    assert n_ok >= len(fixed) * 3 - 6 + 100, n_ok
