@@ -45,9 +45,12 @@ constexpr int NBINS = 1024; // pruning histogram bins per query
 constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
 constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4; // prog[] opcodes
 constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
+constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[] = atom positions in phrase order
+constexpr int PHRASE_STATES = 8;    // live FSMphrase_c states per doc (>= phrase span + 1)
 constexpr int TREE_STACK = 4;       // evaluation stack depth of the tree program
 constexpr int MAX_PASSES = 4; // driver keywords per query (size of the tree's candidate cover)
 constexpr uint32_t QF_OVERFLOW = 1; // candidate list overflowed: the query's result is not trustworthy
+constexpr int MAX_PROX_TERMS_ = 4;
 constexpr int MAPCAP = 4096; // direct-map probe window (rowids) per decoded block
 
 struct DevTerm {
@@ -83,6 +86,7 @@ struct DevQuery {
   uint32_t excl_mask; // keywords whose presence hands the doc to an earlier pass
   uint32_t tree_flags; // TF_*
   uint32_t prog[16];  // op | left node << 8 | right node << 16 | keyword << 24
+  uint32_t ph_atoms[MAX_PROX_TERMS_]; // PHRASE: query positions of its words, in phrase order
   int32_t weights[32];
   DevTerm t[MRK_MAX_AND_TERMS];
 };
@@ -144,7 +148,7 @@ struct MergeArgs {
 
 void launch_scan(const ScanArgs& a, void* stream);
 void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, void* stream);
-constexpr int MAX_PROX_TERMS = 4; // keywords whose hit streams the proximity kernel merges per doc
+constexpr int MAX_PROX_TERMS = MAX_PROX_TERMS_; // keywords whose hit streams the hit kernel merges per doc
 void launch_select(const SelectArgs& a, void* stream);
 void launch_merge(const MergeArgs& a, void* stream);
 

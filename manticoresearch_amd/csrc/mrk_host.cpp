@@ -495,6 +495,8 @@ struct PlanTree {
   std::vector<PlanKw> kws;     // in GetQwords traversal order
   std::vector<PlanNode> nodes; // post-order; root = last
   bool multiand3_inner = false; // a 3-keyword ExtMultiAnd_T below the root (MergeHits3 quirk not restated there)
+  bool phrase = false;          // root is a PHRASE (ExtNWay_T<FSMphrase_c>)
+  std::vector<int> atoms;       // its words' query positions, phrase order
 };
 
 // Mirrors ExtNode_i::Create (searchnode.cpp:1599-1811) for the operators the device path knows:
@@ -530,7 +532,9 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     return (int)T.nodes.size() - 1;
   };
   if (n.op == MRK_OP_TERM) return leaf(ni);
-  if (n.op != MRK_OP_AND && n.op != MRK_OP_OR && n.op != MRK_OP_MAYBE && n.op != MRK_OP_ANDNOT)
+  if (n.op == MRK_OP_PHRASE && !is_root)
+    return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE below another operator is not on the device path yet", qi), -1;
+  if (n.op != MRK_OP_PHRASE && n.op != MRK_OP_AND && n.op != MRK_OP_OR && n.op != MRK_OP_MAYBE && n.op != MRK_OP_ANDNOT)
     return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, n.op), -1;
   if (n.n_children < 1 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
   std::vector<int32_t> kids(n.n_children);
@@ -540,7 +544,22 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     if (kids[i] < 0 || kids[i] >= q.n_nodes) return err = mrk_fail(MRK_E_INVAL, "query %u: child index out of range", qi), -1;
     all_terms &= q.nodes[kids[i]].op == MRK_OP_TERM;
   }
-  if (n.op == MRK_OP_AND && all_terms && n.n_children > 1) {
+  if (n.op == MRK_OP_PHRASE) {
+    // CreateMultiNode<ExtPhrase_c> (searchnode.cpp:984-1041): plain keywords only; ExtNWay_T::ConstructNode
+    // (:3767-3787) chains them left-deep in ascending doc-count order, so docs / tfidf come out as for a MultiAnd
+    if (!all_terms || n.n_children < 2 || n.n_children > MAX_PROX_TERMS)
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE of %d nodes (device path: 2..%d plain keywords)", qi, n.n_children,
+                            MAX_PROX_TERMS), -1;
+    T.phrase = true;
+    for (int i = 0; i < n.n_children; ++i) {
+      T.atoms.push_back(q.nodes[kids[i]].atom_pos);
+      if (i && T.atoms[i] <= T.atoms[i - 1]) return err = mrk_fail(MRK_E_INVAL, "query %u: phrase atom positions must ascend", qi), -1;
+    }
+    if (T.atoms.back() - T.atoms.front() >= PHRASE_STATES)
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: phrase spans %d positions (device path: < %d)", qi,
+                            T.atoms.back() - T.atoms.front(), PHRASE_STATES), -1;
+  }
+  if ((n.op == MRK_OP_AND || n.op == MRK_OP_PHRASE) && all_terms && n.n_children > 1) {
     std::vector<int> ord(n.n_children), docs(n.n_children);
     for (int i = 0; i < n.n_children; ++i) {
       const mrk_node& t = q.nodes[kids[i]];
@@ -558,6 +577,8 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
       const int r = leaf(kids[ord[i]]);
       cur = join(PN_AND, cur, r);
     }
+    if (n.op == MRK_OP_PHRASE) // the words are created with the phrase node's field limit (searchnode.cpp:1020-1024)
+      for (PlanKw& k : T.kws) k.queried32 &= n.field_mask;
     return cur;
   }
   const uint32_t op = n.op == MRK_OP_AND ? PN_AND : n.op == MRK_OP_OR ? PN_OR : n.op == MRK_OP_MAYBE ? PN_MAYBE : PN_ANDNOT;
@@ -643,7 +664,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   const bool single_word = T.nodes.size() == 1;
   bool pure_and = true; // single keyword or one ExtMultiAnd_T: the kernel's N-way AND loop, no program
   for (const PlanNode& pn : T.nodes) pure_and &= pn.op == PN_TERM || pn.op == PN_AND;
-  if (pure_and && q.nodes[q.root].op == MRK_OP_AND)
+  if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE))
     for (int i = 0; i < q.nodes[q.root].n_children; ++i) pure_and &= q.nodes[q.children[q.nodes[q.root].first_child + i]].op == MRK_OP_TERM;
   if (!pure_and && !use_packed) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: boolean trees run on the packed path only", qi);
   if (!pure_and) { // the device evaluates the program on a TREE_STACK-deep register stack
@@ -657,6 +678,10 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
 
   uint32_t ranker;
   bool prox = false;
+  if (T.phrase) {
+    if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE runs on the packed path only", qi);
+    if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+  }
   switch (q.ranker) {
     case MRK_RANK_NONE: ranker = MRK_RANK_NONE; break;
     case MRK_RANK_BM25: ranker = MRK_RANK_BM25; break;
@@ -763,10 +788,12 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
     const uint32_t nwf = std::min<uint32_t>(dq.n_weights, 8u);
     if (prox) {
       // sum_f LCS[f] * w[f] with 0 <= LCS[f] <= number of keywords (hit weight 1, unique keywords)
+      // (a phrase occurrence weighs its word count; back-to-back occurrences can add up -- beyond 2n the bins clamp)
       rmin = rmax = 0;
+      const int64_t top = T.phrase ? 2 * n : n;
       for (uint32_t f = 0; f < nwf; ++f) {
-        rmin += std::min<int64_t>(0, (int64_t)n * dq.weights[f]);
-        rmax += std::max<int64_t>(0, (int64_t)n * dq.weights[f]);
+        rmin += std::min<int64_t>(0, top * dq.weights[f]);
+        rmax += std::max<int64_t>(0, top * dq.weights[f]);
       }
     } else
       for (uint32_t m = 0; m < 256; ++m) {
@@ -807,7 +834,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   }
   algo_bytes += bytes;
   dev_bytes += use_packed ? pbytes : bytes;
-  prox_out = prox_out || prox;
+  prox_out = prox_out || prox || T.phrase;
   tree_out = tree_out || !pure_and;
 
   const DevQuery base = dq;
@@ -841,7 +868,8 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
     P->n_terms = (uint32_t)n;
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
     P->req_mask = P->excl_mask = 0;
-    P->tree_flags = pure_and ? TF_MULTIAND : 0;
+    P->tree_flags = T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : 0;
+    for (size_t i = 0; i < T.atoms.size(); ++i) P->ph_atoms[i] = (uint32_t)T.atoms[i];
     {
       for (int k = 0; k < n; ++k)
         if (req >> k & 1u) P->req_mask |= 1u << slot[k];

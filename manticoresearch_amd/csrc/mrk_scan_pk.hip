@@ -248,7 +248,11 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const uint32_t oq = Q->out_q; // logical query: several passes (driver keywords) may feed one result
   const uint32_t req_mask = TREE ? Q->req_mask : 0u, excl_mask = TREE ? Q->excl_mask : 0u;
   const uint32_t n_nodes = TREE ? Q->n_nodes : 0u;
-  const bool multi_and = !TREE || (Q->tree_flags & TF_MULTIAND) != 0;
+  const bool phrase = PROX && (Q->tree_flags & TF_PHRASE) != 0;
+  const bool multi_and = (!TREE || (Q->tree_flags & TF_MULTIAND) != 0) && !phrase;
+  // PHRASE: query positions of its words in phrase order (FSMphrase_c::m_dAtomPos, searchnode.cpp:3884-3899)
+  const uint32_t ap0 = PROX ? Q->ph_atoms[0] : 0u, ap1 = PROX ? Q->ph_atoms[1] : 0u, ap2 = PROX ? Q->ph_atoms[2] : 0u,
+                 ap3 = PROX ? Q->ph_atoms[3] : 0u;
   // per-workgroup tables: tfidf(tf) per term, field-weight sum per mask
   for (uint32_t j = 0; j < nterms; ++j) s.tfidf[j][tid] = term_tfidf(tid, Q->t[j].idf);
   {
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       // ---- proximity rankers: per matched doc merge the keywords' hit streams by (hitpos, qpos)
       // (MergeHits2/3/N, searchnode.cpp:3047-3181) and run RankerState_Proximity_fn (sphinxsearch.cpp:1351-1437)
       int prank[2] = {0, 0};
-      if (PROX && prox_ranker) {
+      if (PROX && (prox_ranker || phrase)) {
         wave_lds_fence();
         const uint8_t* __restrict__ spp = a.seg.spp;
 #pragma unroll
@@ -683,6 +687,12 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
             // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
             // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
             int phase = (multi_and && nterms == 3 && (sm[0] & sm[1] & sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
+            // FSMphrase_c states (searchnode.cpp:3901-3947): expected hit position per live state, 2-bit word index
+            uint32_t fexp[PHRASE_STATES], ftag = 0, fvalid = 0, ffield = 0;
+#pragma unroll
+            for (int i = 0; i < PHRASE_STATES; ++i) fexp[i] = 0;
+            bool fmatched = false, fover = false;
+            const uint32_t span = (nterms == 2 ? ap1 : nterms == 3 ? ap2 : ap3) - ap0;
             for (;;) {
               if (phase == 0 && !(sc[0] && sc[1] && sc[2])) {
                 if (!sc[0])
@@ -700,21 +710,72 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
               int best = -1;
               uint32_t bh = 0, bq = 0, bmask = 0;
 #pragma unroll
-              for (int t = 0; t < MAX_PROX_TERMS; ++t)
-                if (sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && sq[t] < bq))) best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
+              for (int t = 0; t < MAX_PROX_TERMS; ++t) // a phrase's top ExtAnd_c orders equal positions by DESCENDING qpos
+                if (sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && (phrase ? sq[t] > bq : sq[t] < bq))))
+                  best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
               if (best < 0) break;
               if (phase == 1) bmask = best == tl ? sm[0] : sm[1];
               // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
               if (field_queried(bmask, bh)) {
-                // RankerState_Proximity_fn<.., false>::Update; hit weight = spanlen = 1 for plain keywords
-                const int pwf = (int)(bh & ~(1u << 23));
-                const int delta = pwf - (int)(bq & 0xFFFFu);
-                if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + 1u) & 0xffu; // BYTE arithmetic
-                const uint32_t f = bh >> 24;
-                if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu))
-                  lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
-                last_pwf = pwf;
-                exp_delta = delta;
+                uint32_t hp = bh & ~(1u << 23), hq = bq & 0xFFFFu, hw = 1u, hspan = 0u; // what the ranker sees
+                bool emit = true;
+                if (phrase) {
+                  // HitFSM: a first-word hit opens a state; states whose expected position was passed die;
+                  // a state that reads its last word folds the occurrence into one hit and resets the FSM
+                  emit = false;
+                  if (hq == (ap0 & 0xFFFFu)) {
+                    const uint32_t freeb = ~fvalid & ((1u << PHRASE_STATES) - 1u);
+                    if (!freeb)
+                      fover = true;
+                    else {
+                      const uint32_t idx = (uint32_t)__builtin_ctz(freeb);
+#pragma unroll
+                      for (int i = 0; i < PHRASE_STATES; ++i)
+                        if ((uint32_t)i == idx) fexp[i] = hp + (ap1 - ap0);
+                      ftag &= ~(3u << (2 * idx));
+                      fvalid |= 1u << idx;
+                    }
+                  }
+#pragma unroll
+                  for (int i = 0; i < PHRASE_STATES; ++i) {
+                    if (!emit && ((fvalid >> i) & 1u)) {
+                      if (fexp[i] < hp)
+                        fvalid &= ~(1u << i);
+                      else {
+                        uint32_t tg = (ftag >> (2 * i)) & 3u;
+                        const uint32_t nextq = tg == 0 ? ap1 : tg == 1 ? ap2 : ap3;
+                        if (fexp[i] == hp && tg + 1 < nterms && (nextq & 0xFFFFu) == hq) {
+                          ++tg;
+                          const uint32_t cq = tg == 1 ? ap1 : tg == 2 ? ap2 : ap3, nq = tg == 1 ? ap2 : ap3;
+                          fexp[i] = tg + 1 < nterms ? hp + (nq - cq) : hp - 0x7FFFFFFFu; // FSMphrase_c: -INT_MAX past the last word
+                          ftag = (ftag & ~(3u << (2 * i))) | (tg << (2 * i));
+                        }
+                        if (tg == nterms - 1) emit = true;
+                      }
+                    }
+                  }
+                  if (emit) {
+                    fvalid = 0; // ResetFSM
+                    if (!fmatched) ffield = (bh >> 24) & 31u; // the doc's field mask comes from its first occurrence (:3836)
+                    fmatched = true;
+                    hp = hp - span;
+                    hq = ap0 & 0xFFFFu;
+                    hw = nterms;
+                    hspan = span;
+                  }
+                }
+                if (emit) {
+                  // RankerState_Proximity_fn<.., false>::Update; plain keyword: weight = spanlen = 1
+                  const int pwf = (int)hp;
+                  const int delta = pwf - (int)hq;
+                  if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + hw) & 0xffu; // BYTE arithmetic
+                  const uint32_t f = hp >> 24;
+                  if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu))
+                    lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
+                  last_pwf = pwf;
+                  exp_delta = delta + (int)hspan;
+                  if (phrase && !prox_ranker) break; // one occurrence settles the match
+                }
               }
 #pragma unroll
               for (int t = 0; t < MAX_PROX_TERMS; ++t)
@@ -723,6 +784,11 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
             int rk = 0;
             for (uint32_t f = 0; f < nw; ++f) rk += (int)((lcs >> (8 * f)) & 0xffu) * Q->weights[f];
             prank[r] = rk;
+            if (phrase) {
+              if (fover) atomicOr(a.q_flags + oq, QF_OVERFLOW); // more live states than we keep: fail the query loudly
+              live[r] = fmatched;
+              fld[r] = 1u << ffield;
+            }
           }
         }
       }

@@ -83,9 +83,9 @@ int main(int argc, char** argv) {
   const int n = tParent.Flatten(out.data());
   for (int i = 0; i < n; ++i) printf("%d %u %d\n", out[i].m_iTag, out[i].m_tRowID, out[i].m_iWeight);
   // an unsupported query shape must fail loudly, reference-style (nullptr + error string)
-  nodes[0].op = MRK_OP_PHRASE;
+  nodes[0].op = 6; // an operator beyond MRK_OP_PHRASE (NEAR, QUORUM, ...)
   mrk::GpuRanker* pBad = mrk::GpuRanker::Create(batch, seg[0], q, sError);
-  printf("phrase_query %s\n", pBad ? "accepted" : "rejected");
+  printf("unknown_op %s\n", pBad ? "accepted" : "rejected");
   delete pBad;
   for (int s = 0; s < 2; ++s) mrk_segment_destroy(seg[s]), mrk_host_index_free(hi[s]);
   mrk_batch_destroy(batch);

@@ -19,7 +19,7 @@ def test_cpp_ranker_two_chunks(orc, tmp_path):
                            "-L" + lib, "-lmrk", "-Wl,-rpath," + lib])
     n_docs, p0, p1, seed = 150000, 0.2, 0.05, 7
     out = subprocess.check_output([exe, str(n_docs), str(p0), str(p1), str(seed)], text=True).splitlines()
-    assert out[-1] == "phrase_query rejected"
+    assert out[-1] == "unknown_op rejected"
     total = int([l for l in out if l.startswith("total ")][0].split()[1])
     got = [tuple(int(x) for x in l.split()) for l in out if l[0].isdigit()]
     # oracle on the same two segments (same generator parameters), merged with the reference comparator

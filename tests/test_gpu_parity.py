@@ -215,7 +215,8 @@ def test_unsupported_shapes_fail_loudly(dev):
     m, ctx, batch = dev
     hi = m.synth_index(1000, [0.5, 0.5], seed=1)
     seg = m.Segment(ctx, hi)
-    q_or = m.Query(m.XQNode(m.SPH_QUERY_PHRASE, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
+    # an operator the device path does not know (proximity / near / quorum ... would be op codes > PHRASE)
+    q_or = m.Query(m.XQNode(6, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
     q_big = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25, max_matches=5000)
     q_ok = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25)
     r = batch.search(seg, [q_or, q_ok, q_big])
@@ -471,3 +472,60 @@ def test_random_boolean_trees(orc, dev, block, fmt):
     finally:
         seg.close()
     assert n_ok >= len(fixed) * 3 - 6 + 100, n_ok
+
+
+# ------------------------------------------------------------------ PHRASE (ExtNWay_T<FSMphrase_c>)
+def PHRASE(m, *k, mask=0xFFFFFFFF):
+    return m.XQNode(m.SPH_QUERY_PHRASE, list(k), None, mask)
+
+
+def test_golden_phrase_weight_on_device(dev):
+    """test_019: '"phrase query"' under the default ranker -> 222:2687."""
+    _tree_only(dev)
+    m, ctx, batch = dev
+    W, R, H, v = make_hits(T019, 2)
+    seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(T019)))
+    r = batch.search(seg, [m.Query(PHRASE(m, kw(m, v["phrase"], 1), kw(m, v["query"], 2)))])[0]
+    assert r.status == 0
+    assert [(T019_IDS[i], int(w)) for i, w in zip(r.rowid, r.weight)] == [(222, 2687)]
+    seg.close()
+
+
+@pytest.mark.parametrize("block,fmt", [(128, 1), (32, 0)])
+def test_random_corpus_phrases(orc, dev, block, fmt):
+    """Dense little docs (positions 1..12 over 3 fields) so that 2-4 word phrases do occur, repeat and overlap."""
+    _tree_only(dev)
+    m, ctx, batch = dev
+    rng = np.random.default_rng(999 + block + fmt)
+    n_docs = 30000
+    probs = [0.6, 0.5, 0.4, 0.3, 0.1, 0.02, 0.9]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=12, end_markers=True)
+    hi = m.index_from_hits(W, R, H, n_terms=len(probs), total_docs=n_docs, skiplist_block_size=block, hit_format=fmt, n_fields=3)
+    qs = []
+    rankers = [m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_PROXIMITY]
+    for i in range(140):
+        k = int(rng.integers(2, 5))
+        dupes = rng.random() < 0.15
+        ts = rng.choice(len(probs), size=k, replace=dupes)
+        pos, ap = [], 0
+        for _ in ts:
+            ap += 1 if rng.random() < 0.85 else 2  # a stop word leaves a gap in the atom positions
+            pos.append(ap)
+        mask = 0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8))
+        root = PHRASE(m, *[kw(m, int(t), p) for t, p in zip(ts, pos)], mask=mask)
+        has_dupes = len(set(int(t) for t in ts)) != k
+        rk = rankers[i % 4]
+        if has_dupes and rk in (m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY):
+            rk = m.SPH_RANK_BM25  # HANDLE_DUPES is restated neither in the oracle nor on the device
+        qs.append(m.Query(root, ranker=rk, max_matches=int(rng.choice([5, 100, 1000])),
+                          field_weights=[int(x) for x in rng.integers(-3, 12, 3)] if rng.random() < 0.5 else None,
+                          index_weight=int(rng.choice([1, 1, 2]))))
+    # "a a" style phrases: back-to-back occurrences share a position
+    qs.append(m.Query(PHRASE(m, kw(m, 6, 1), kw(m, 6, 2)), ranker=m.SPH_RANK_BM25))
+    qs.append(m.Query(PHRASE(m, kw(m, 6, 1), kw(m, 6, 2), kw(m, 6, 3)), ranker=m.SPH_RANK_NONE))
+    check_batch(orc, dev, hi, qs)
+    # phrases were actually found
+    seg = m.Segment(ctx, hi)
+    r = batch.search(seg, [m.Query(PHRASE(m, kw(m, 0, 1), kw(m, 1, 2)))])[0]
+    assert r.total_found > 100
+    seg.close()
