@@ -156,6 +156,11 @@ int mrk_ctx_set(mrk_ctx* ctx, const char* key, int64_t value);
 
 int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* desc, mrk_segment** out);
 void mrk_segment_destroy(mrk_segment* seg);
+/* Dead-row map of the segment (DeadRowMap_c, killlist.h:22-46: bit rowid&31 of DWORD rowid>>5), copied
+   to the device; dead rows are dropped right after ranking, before the sorter, and do not count as found
+   (CSphIndex_VLN::MatchExtended, sphinx.cpp:12213-12217).  bitmap = NULL clears the map.  The call waits
+   for the context's running batches, so a search sees either the old or the new map. */
+int mrk_segment_set_dead_rows(mrk_segment* seg, const uint32_t* bitmap, uint64_t n_rows);
 /* device bytes held, and the reference-format doclist bytes of one term */
 uint64_t mrk_segment_device_bytes(const mrk_segment* seg);
 

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("mrk_segment_create", C.c_int, [C.c_void_p, C.POINTER(SegmentDesc), C.POINTER(C.c_void_p)]),
     ("mrk_segment_destroy", None, [C.c_void_p]),
     ("mrk_segment_device_bytes", C.c_uint64, [C.c_void_p]),
+    ("mrk_segment_set_dead_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("mrk_batch_create", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("mrk_batch_destroy", None, [C.c_void_p]),
     ("mrk_batch_submit", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Query), C.c_uint32]),

@@ -248,6 +248,14 @@ class Segment:
     def device_bytes(self) -> int:
         return int(lib().mrk_segment_device_bytes(self._h))
 
+    def set_dead_rows(self, bitmap: Optional[np.ndarray]) -> None:
+        """Install the segment's dead-row map (uint32 words, DeadRowMap_c layout); None clears it."""
+        if bitmap is None:
+            check(lib().mrk_segment_set_dead_rows(self._h, None, 0))
+            return
+        bm = np.ascontiguousarray(bitmap, dtype=np.uint32)
+        check(lib().mrk_segment_set_dead_rows(self._h, bm.ctypes.data, bm.size * 32))
+
     def close(self) -> None:
         if self._h:
             lib().mrk_segment_destroy(self._h)

@@ -38,7 +38,12 @@ struct DevSegment {
   const uint64_t* pk_exc;   // tf exceptions (tf >= 255): rowid<<32 | tf, sorted per term
   const uint32_t* pk_hit;   // per doc slot (block*128 + i): inlined hit, or hitlist offset from pk_hbase[block]
   const uint64_t* pk_hbase; // per block: hitlist base position in .spp
+  const uint32_t* dead;     // dead-row bitmap (DeadRowMap_c layout) or NULL
 };
+
+__device__ __forceinline__ bool row_is_dead(const DevSegment& seg, uint32_t rowid) {
+  return (seg.dead[rowid >> 5] >> (rowid & 31u)) & 1u; // DeadRowMap_c::IsSet, killlist.h:39-46
+}
 
 constexpr uint32_t PK_WIDE = 0xFFu;
 constexpr int NBINS = 1024; // pruning histogram bins per query

@@ -80,6 +80,7 @@ struct mrk_segment {
   void* d_pk_exc = nullptr;
   void* d_pk_hit = nullptr;
   void* d_pk_hbase = nullptr;
+  void* d_dead = nullptr;
 };
 
 template <typename T>
@@ -254,7 +255,29 @@ extern "C" void mrk_segment_destroy(mrk_segment* s) {
   if (s->d_pk_exc) (void)hipFree(s->d_pk_exc);
   if (s->d_pk_hit) (void)hipFree(s->d_pk_hit);
   if (s->d_pk_hbase) (void)hipFree(s->d_pk_hbase);
+  if (s->d_dead) (void)hipFree(s->d_dead);
   delete s;
+}
+
+extern "C" int mrk_segment_set_dead_rows(mrk_segment* s, const uint32_t* bitmap, uint64_t n_rows) {
+  if (!s || !s->ctx) return mrk_fail(MRK_E_INVAL, "mrk_segment_set_dead_rows: NULL segment");
+  if (bitmap && n_rows < s->total_docs)
+    return mrk_fail(MRK_E_INVAL, "mrk_segment_set_dead_rows: map covers %llu rows, segment has %llu", (unsigned long long)n_rows,
+                    (unsigned long long)s->total_docs);
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+  const size_t words = bitmap ? (size_t)((n_rows + 31) / 32) : 0;
+  void* fresh = nullptr;
+  if (words) {
+    // rowids the doclists may name: [0, total_docs); one spare word keeps a stray read in bounds
+    HIP_TRY(hipMalloc(&fresh, (words + 1) * 4));
+    HIP_TRY(hipMemset(fresh, 0, (words + 1) * 4));
+    HIP_TRY(hipMemcpy(fresh, bitmap, words * 4, hipMemcpyHostToDevice));
+  }
+  if (s->d_dead) (void)hipFree(s->d_dead);
+  s->d_dead = fresh;
+  s->dev.dead = (const uint32_t*)fresh;
+  return MRK_OK;
 }
 
 static int upload(void** dptr, const void* src, size_t bytes, size_t pad, hipStream_t st) {

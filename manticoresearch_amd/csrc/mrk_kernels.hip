@@ -378,6 +378,11 @@ __global__ __launch_bounds__(WG) void scan_kernel(ScanArgs a) {
         live[0] = live[0] && hit[0];
         live[1] = live[1] && hit[1];
       }
+      if (a.seg.dead) { // MatchExtended drops dead rows before they reach the sorter (sphinx.cpp:12213-12217)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          if (live[r] && row_is_dead(a.seg, d.rowid[r])) live[r] = false;
+      }
 
       // ---- matches: weight, threshold, candidates
       const uint64_t tau = s.tau;

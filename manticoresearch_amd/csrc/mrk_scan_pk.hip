@@ -642,6 +642,11 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       }
 
       if (gt_new > tau_bin) tau_bin = gt_new;
+      if (a.seg.dead) { // MatchExtended drops dead rows before they reach the sorter (sphinx.cpp:12213-12217)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          if (live[r] && row_is_dead(a.seg, row[r])) live[r] = false;
+      }
       // ---- proximity rankers: per matched doc merge the keywords' hit streams by (hitpos, qpos)
       // (MergeHits2/3/N, searchnode.cpp:3047-3181) and run RankerState_Proximity_fn (sphinxsearch.cpp:1351-1437)
       int prank[2] = {0, 0};

@@ -1642,7 +1642,8 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
           if (mask & (1u << i)) rank += (uint32_t)weights[i];
       weight = use_bm25 ? (int)((uint32_t)bm25 + rank * SPH_BM25_SCALE) : (int)rank;
     }
-    /* MatchExtended (sphinx.cpp:12211-12263) */
+    /* MatchExtended (sphinx.cpp:12211-12263): dead rows never reach the sorter (:12213-12217) */
+    if (idx->dead_rows && (idx->dead_rows[root->rowid >> 5] >> (root->rowid & 31u)) & 1u) continue;
     weight = (int)((uint32_t)weight * (uint32_t)index_weight);
     match_t m = {root->rowid, weight};
     mq_push(&mq, &m);

@@ -100,6 +100,7 @@ typedef struct {
   int skiplist_block_size;
   int inline_hits; /* hit_format=inline (1) or plain (0) */
   int n_fields;
+  const uint32_t* dead_rows; /* DeadRowMap_c bitmap (killlist.h:22-46) or NULL */
 } orc_index;
 
 /* ---- query tree ---- */

@@ -43,7 +43,7 @@ class _Index(C.Structure):
     _fields_ = [("spd", C.c_void_p), ("spd_len", C.c_size_t), ("spp", C.c_void_p), ("spp_len", C.c_size_t),
                 ("spe", C.c_void_p), ("spe_len", C.c_size_t), ("dict", C.c_void_p), ("n_terms", C.c_uint32),
                 ("total_docs", C.c_int64), ("skiplist_block_size", C.c_int), ("inline_hits", C.c_int),
-                ("n_fields", C.c_int)]
+                ("n_fields", C.c_int), ("dead_rows", C.c_void_p)]
 
 
 class _Node(C.Structure):
@@ -124,6 +124,7 @@ class Index:
     skiplist_block_size: int = 128
     inline_hits: int = 1
     n_fields: int = 2
+    dead_rows: Optional[np.ndarray] = None  # uint32 bitmap, DeadRowMap_c layout
 
     def c_struct(self) -> _Index:
         s = _Index()
@@ -135,6 +136,7 @@ class Index:
         s.skiplist_block_size = self.skiplist_block_size
         s.inline_hits = self.inline_hits
         s.n_fields = self.n_fields
+        s.dead_rows = self.dead_rows.ctypes.data if self.dead_rows is not None else None
         return s
 
     def decode_doclist(self, term_id: int):

@@ -529,3 +529,42 @@ def test_random_corpus_phrases(orc, dev, block, fmt):
     r = batch.search(seg, [m.Query(PHRASE(m, kw(m, 0, 1), kw(m, 1, 2)))])[0]
     assert r.total_found > 100
     seg.close()
+
+
+# ------------------------------------------------------------------ dead-row map (MatchExtended, sphinx.cpp:12213-12217)
+def test_dead_rows_are_dropped_before_the_sorter(orc, dev):
+    m, ctx, batch = dev
+    rng = np.random.default_rng(31337)
+    n_docs = 50000
+    probs = [0.5, 0.3, 0.1, 0.02]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=20)
+    hi = m.index_from_hits(W, R, H, n_terms=len(probs), total_docs=n_docs, n_fields=3)
+    dead = np.zeros((n_docs + 31) // 32, np.uint32)
+    killed = rng.choice(n_docs, size=n_docs // 3, replace=False)
+    np.bitwise_or.at(dead, killed >> 5, (np.uint32(1) << (killed & 31).astype(np.uint32)))
+    a, b, c = kw(m, 0, 1), kw(m, 1, 2), kw(m, 2, 3)
+    roots = [a, m.XQNode.AND(a, b), m.XQNode.AND(a, b, c)]
+    rankers = [m.SPH_RANK_BM25, m.SPH_RANK_NONE]
+    if ctx_path(ctx) == 0:
+        roots += [OR(m, b, c), ANDNOT(m, a, c), PHRASE(m, a, b)]
+        rankers.append(m.SPH_RANK_PROXIMITY_BM25)
+    qs = [m.Query(r, ranker=rk, max_matches=k) for r in roots for rk in rankers for k in (10, 1000)]
+    seg = m.Segment(ctx, hi)
+    oi = orc_index_of(orc, hi)
+    try:
+        before = batch.search(seg, qs)
+        seg.set_dead_rows(dead)
+        oi.dead_rows = dead
+        after = batch.search(seg, qs)
+        for q, g0, g in zip(qs, before, after):
+            want = to_orc(orc, q).run(oi)
+            assert g.status == 0
+            assert g.total_found == want.total_found and g.total_found < g0.total_found
+            assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+            assert not ((dead[g.rowid >> 5] >> (g.rowid & 31)) & 1).any()
+        seg.set_dead_rows(None)  # an emptied map brings everything back
+        again = batch.search(seg, qs[:4])
+        for g0, g in zip(before, again):
+            assert g.total_found == g0.total_found and (g.rowid == g0.rowid).all()
+    finally:
+        seg.close()

@@ -163,3 +163,16 @@ def test_322_field_weights(orc, spam, expect):
     root = orc.op(orc.OP_AND, orc.term(v["program"], 1), orc.term(v["flow"], 2))
     got, _ = run(orc, idx, root, orc.RANK_PROXIMITY_BM25, T322_IDS, field_weights=[1, 2, spam])
     assert got == expect
+
+
+def test_dead_rows_skip_the_sorter(orc):
+    """MatchExtended (sphinx.cpp:12213-12217): a dead row is neither ranked into the queue nor counted."""
+    idx, v = t019(orc)
+    root = orc.op(orc.OP_OR, orc.term(v["basic"], 1), orc.term(v["china"], 2))
+    got, r = run(orc, idx, root, orc.RANK_PROXIMITY_BM25, T019_IDS)
+    assert got == [(444, 1610), (111, 1577), (555, 1577)] and r.total_found == 3
+    dead = np.zeros(1, np.uint32)
+    dead[0] |= 1 << T019_IDS.index(111)
+    idx.dead_rows = dead
+    got, r = run(orc, idx, root, orc.RANK_PROXIMITY_BM25, T019_IDS)
+    assert got == [(444, 1610), (555, 1577)] and r.total_found == 2
