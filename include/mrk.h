@@ -143,6 +143,7 @@ typedef struct {
   uint64_t dev_bytes;     /* the same sum over the format the kernel actually read (packed or .spd) */
   uint32_t packed;        /* 1 = packed-doclist path, 0 = VLB-direct path */
   uint64_t n_cands;       /* packed path: candidates that survived in-scan pruning (all queries) */
+  uint64_t n_items_bm;    /* of n_items: work items of the two-bitmap AND kernel (dense keywords) */
 } mrk_batch_stats;
 
 const char* mrk_last_error(void);
@@ -151,6 +152,9 @@ int mrk_ctx_create(int device, mrk_ctx** out);
 void mrk_ctx_destroy(mrk_ctx* ctx);
 /* tunables: "item_bytes" (work-item size target); "pack" (1 = build packed doclists at segment
    load, default); "path" (0 = packed when present, 1 = VLB-direct, 2 = packed only);
+   "bitmap_inv" (keywords found in >= 1/bitmap_inv of a segment's docs also get a doc-set bitmap,
+   used by the two-bitmap AND kernel; default 64, 0 = off; read at segment load and at submit);
+   "bm_target_items" (work items per launch the bitmap kernel's window ranges are cut into, default 6144);
    returns MRK_E_INVAL for unknown keys */
 int mrk_ctx_set(mrk_ctx* ctx, const char* key, int64_t value);
 

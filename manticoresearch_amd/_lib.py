@@ -57,7 +57,8 @@ class Result(C.Structure):
 
 class BatchStats(C.Structure):
     _fields_ = [("scan_ms", C.c_float), ("merge_ms", C.c_float), ("algo_bytes", C.c_uint64), ("n_items", C.c_uint64),
-                ("dev_bytes", C.c_uint64), ("packed", C.c_uint32), ("n_cands", C.c_uint64)]
+                ("dev_bytes", C.c_uint64), ("packed", C.c_uint32), ("n_cands", C.c_uint64),
+                ("n_items_bm", C.c_uint64)]
 
 
 class SynthParams(C.Structure):

@@ -37,8 +37,13 @@ struct DevSegment {
   const uint32_t* pk_attr;  // per block 64 words: tf[l] | tf[l+64]<<8 | fields[l]<<16 | fields[l+64]<<24
   const uint64_t* pk_exc;   // tf exceptions (tf >= 255): rowid<<32 | tf, sorted per term
   const uint32_t* pk_hit;   // per doc slot (block*128 + i): inlined hit, or hitlist offset from pk_hbase[block]
-  const uint64_t* pk_hbase; // per block: hitlist base position in .spp
-  const uint32_t* dead;     // dead-row bitmap (DeadRowMap_c layout) or NULL
+  const uint64_t* pk_hbase; // per block: .spp position of the block's first hitlist
+  const uint32_t* dead;     // dead-row bitmap (DeadRowMap_c layout, padded to whole windows) or NULL
+  // dense terms: doc-set bitmaps (one 2048-rowid window = 64 words) + rank directory (docs before each
+  // 256-rowid group); a doc's rank is its slot in the packed arrays (pk_attr / pk_hit)
+  const uint32_t* bm;
+  const uint32_t* bm_dir;
+  uint32_t n_windows;       // windows per bitmap = ceil(total_docs / 2048)
 };
 
 __device__ __forceinline__ bool row_is_dead(const DevSegment& seg, uint32_t rowid) {
@@ -50,6 +55,7 @@ constexpr int NBINS = 1024; // pruning histogram bins per query
 constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
 constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4; // prog[] opcodes
 constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
+constexpr uint32_t TF_BITMAP = 4;   // 2-keyword AND answered by the bitmap kernel (items are window ranges)
 constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[] = atom positions in phrase order
 constexpr int PHRASE_STATES = 8;    // live FSMphrase_c states per doc (>= phrase span + 1)
 constexpr int TREE_STACK = 4;       // evaluation stack depth of the tree program
@@ -68,6 +74,8 @@ struct DevTerm {
   uint64_t spd_end;   // doclist_off + doclist_len
   uint32_t exc_first; // tf exceptions of this term in pk_exc
   uint32_t exc_n;
+  uint64_t bm_off;    // word offset of the term's bitmap in DevSegment::bm (~0 = none)
+  uint64_t dir_off;   // word offset of its rank directory in DevSegment::bm_dir
 };
 
 struct DevQuery {
@@ -154,6 +162,7 @@ struct MergeArgs {
 void launch_scan(const ScanArgs& a, void* stream);
 void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, void* stream);
 constexpr int MAX_PROX_TERMS = MAX_PROX_TERMS_; // keywords whose hit streams the hit kernel merges per doc
+void launch_scan_bm(const ScanArgs& a, void* stream); // a.items: (query, window range) work items
 void launch_select(const SelectArgs& a, void* stream);
 void launch_merge(const MergeArgs& a, void* stream);
 

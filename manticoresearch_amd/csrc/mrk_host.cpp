@@ -50,6 +50,8 @@ struct mrk_ctx {
   int64_t item_bytes = 128 << 10; // target doclist bytes per work item
   int path = 0;                   // 0 = packed doclists when the segment has them, 1 = VLB (.spd) direct, 2 = packed only
   int pack = 1;                   // build packed doclists at segment load
+  int bitmap_inv = 64;            // terms in >= 1/bitmap_inv of the docs also get a bitmap (0 = never)
+  int bm_target_items = 6144;     // bitmap kernel: work items per launch the window ranges are cut into
 };
 
 struct HostTerm {
@@ -57,6 +59,7 @@ struct HostTerm {
   uint64_t packed_bytes = 0;
   uint32_t blk_first = 0, nblocks = 0, docs = 0, hits = 0;
   uint32_t exc_first = 0, exc_n = 0;
+  uint64_t bm_off = ~0ull, dir_off = ~0ull; // word offsets of the term's bitmap / rank directory, ~0 = none
 };
 
 struct mrk_segment {
@@ -81,6 +84,8 @@ struct mrk_segment {
   void* d_pk_hit = nullptr;
   void* d_pk_hbase = nullptr;
   void* d_dead = nullptr;
+  void* d_bm = nullptr;
+  void* d_bm_dir = nullptr;
 };
 
 template <typename T>
@@ -218,6 +223,16 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
     c->pack = value != 0;
     return MRK_OK;
   }
+  if (!strcmp(key, "bm_target_items")) {
+    if (value < 1 || value > (1 << 20)) return mrk_fail(MRK_E_INVAL, "bm_target_items must be 1 .. 2^20");
+    c->bm_target_items = (int)value;
+    return MRK_OK;
+  }
+  if (!strcmp(key, "bitmap_inv")) {
+    if (value < 0 || value > 4096) return mrk_fail(MRK_E_INVAL, "bitmap_inv must be 0 (off) .. 4096");
+    c->bitmap_inv = (int)value;
+    return MRK_OK;
+  }
   return mrk_fail(MRK_E_INVAL, "mrk_ctx_set: unknown key '%s'", key);
 }
 
@@ -256,6 +271,8 @@ extern "C" void mrk_segment_destroy(mrk_segment* s) {
   if (s->d_pk_hit) (void)hipFree(s->d_pk_hit);
   if (s->d_pk_hbase) (void)hipFree(s->d_pk_hbase);
   if (s->d_dead) (void)hipFree(s->d_dead);
+  if (s->d_bm) (void)hipFree(s->d_bm);
+  if (s->d_bm_dir) (void)hipFree(s->d_bm_dir);
   delete s;
 }
 
@@ -269,9 +286,11 @@ extern "C" int mrk_segment_set_dead_rows(mrk_segment* s, const uint32_t* bitmap,
   const size_t words = bitmap ? (size_t)((n_rows + 31) / 32) : 0;
   void* fresh = nullptr;
   if (words) {
-    // rowids the doclists may name: [0, total_docs); one spare word keeps a stray read in bounds
-    HIP_TRY(hipMalloc(&fresh, (words + 1) * 4));
-    HIP_TRY(hipMemset(fresh, 0, (words + 1) * 4));
+    // rowids the doclists may name: [0, total_docs); zero-padded to whole 2048-rowid windows (the bitmap
+    // kernel reads it window by window) plus a spare word
+    const size_t alloc = std::max<size_t>((words + 63) / 64, (size_t)s->dev.n_windows) * 64 + 1;
+    HIP_TRY(hipMalloc(&fresh, alloc * 4));
+    HIP_TRY(hipMemset(fresh, 0, alloc * 4));
     HIP_TRY(hipMemcpy(fresh, bitmap, words * 4, hipMemcpyHostToDevice));
   }
   if (s->d_dead) (void)hipFree(s->d_dead);
@@ -372,6 +391,7 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
   std::vector<uint64_t> pk_hbase;
   std::vector<uint8_t> pk_w;
   std::vector<uint64_t> pk_exc;
+  std::vector<uint32_t> bm_words, bm_dir;
   bool packed = ctx->pack && d->n_fields <= 8;
   if (packed) {
     std::vector<PackedTerm> pt(d->n_terms);
@@ -385,7 +405,10 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
       for (;;) {
         const size_t t = next.fetch_add(1);
         if (t >= d->n_terms) break;
-        if (!pack_term(d->spd, d->spd_len, d->dict[t], inl, pt[t], errs[t])) bad = true;
+        // dense terms also get a bitmap of their doc set (the two-bitmap AND kernel, mrk_scan_bm.hip)
+        const bool dense = ctx->bitmap_inv > 0 && d->total_docs > 0 && d->total_docs < (1ull << 32) &&
+                           (uint64_t)d->dict[t].docs * (uint64_t)ctx->bitmap_inv >= d->total_docs;
+        if (!pack_term(d->spd, d->spd_len, d->dict[t], inl, dense ? d->total_docs : 0, pt[t], errs[t])) bad = true;
       }
     };
     std::vector<std::thread> th;
@@ -395,11 +418,18 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
     if (bad) {
       // e.g. field masks wider than 8 bits: this segment is served by the VLB path only
       packed = false;
+      for (uint32_t t = 0; t < d->n_terms; ++t)
+        if (!errs[t].empty()) {
+          fprintf(stderr, "mrk: segment stays on the VLB path: term %u: %s\n", t, errs[t].c_str());
+          break;
+        }
     } else {
       size_t nd = 0, ne = 0, nblk = 0;
       for (auto& x : pt) nd += x.delta.size(), ne += x.exc.size(), nblk += x.base.size();
       if (nblk != blk_base.size() || nd + 64 > 0xFFFFFFFFull) {
         packed = false;
+        fprintf(stderr, "mrk: segment stays on the VLB path: %zu blocks vs %zu in the skiplists, %zu delta words\n", nblk,
+                blk_base.size(), nd);
       } else {
         pk_base.reserve(nblk), pk_doff.reserve(nblk), pk_w.reserve(nblk);
         pk_delta.reserve(nd + 64), pk_attr.reserve(nblk * 64), pk_exc.reserve(ne + 1);
@@ -419,6 +449,12 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
           pk_exc.insert(pk_exc.end(), x.exc.begin(), x.exc.end());
           pk_hit.insert(pk_hit.end(), x.hit.begin(), x.hit.end());
           pk_hbase.insert(pk_hbase.end(), x.hbase.begin(), x.hbase.end());
+          if (!x.bm.empty()) {
+            h.bm_off = bm_words.size();
+            h.dir_off = bm_dir.size();
+            bm_words.insert(bm_words.end(), x.bm.begin(), x.bm.end());
+            bm_dir.insert(bm_dir.end(), x.bm_dir.begin(), x.bm_dir.end());
+          }
           x = PackedTerm();
         }
       }
@@ -438,6 +474,14 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
         (rc = upload(&s->d_pk_hbase, pk_hbase.data(), pk_hbase.size() * 8, 64, ctx->stream)) != MRK_OK) {
       mrk_segment_destroy(s);
       return rc;
+    }
+    if (!bm_words.empty()) {
+      if ((rc = upload(&s->d_bm, bm_words.data(), bm_words.size() * 4, 1024, ctx->stream)) != MRK_OK ||
+          (rc = upload(&s->d_bm_dir, bm_dir.data(), bm_dir.size() * 4, 64, ctx->stream)) != MRK_OK) {
+        mrk_segment_destroy(s);
+        return rc;
+      }
+      s->device_bytes += bm_words.size() * 4 + bm_dir.size() * 4;
     }
     s->has_packed = true;
     s->device_bytes += pk_base.size() * 17 + pk_delta.size() * 4 + pk_attr.size() * 4 + pk_exc.size() * 8 + pk_hit.size() * 4;
@@ -464,6 +508,9 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
   s->dev.pk_exc = (const uint64_t*)s->d_pk_exc;
   s->dev.pk_hit = (const uint32_t*)s->d_pk_hit;
   s->dev.pk_hbase = (const uint64_t*)s->d_pk_hbase;
+  s->dev.bm = (const uint32_t*)s->d_bm;
+  s->dev.bm_dir = (const uint32_t*)s->d_bm_dir;
+  s->dev.n_windows = (uint32_t)((d->total_docs + 2047) / 2048);
   s->dev.spd = (const uint8_t*)s->d_spd;
   s->dev.spp = (const uint8_t*)s->d_spp;
   s->dev.blk_base = (const uint32_t*)s->d_blk_base;
@@ -662,12 +709,15 @@ static void fill_term(const mrk_segment* seg, const PlanKw& k, DevTerm& dt) {
   dt.spd_end = h.doclist_off + h.doclist_len;
   dt.exc_first = h.exc_first;
   dt.exc_n = h.exc_n;
+  dt.bm_off = h.bm_off;
+  dt.dir_off = h.dir_off;
 }
 
 // returns MRK_OK, or MRK_E_UNSUPPORTED / MRK_E_INVAL with the message set.  dq = the query's head pass
 // (index qi); further passes go to `extra` and get pass indices n_queries + position.
 static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
-                      std::vector<DevQuery>& extra, uint32_t n_queries, std::vector<DevItem>& items, uint32_t qi,
+                      std::vector<DevQuery>& extra, uint32_t n_queries, std::vector<DevItem>& items,
+                      std::vector<DevItem>& items_bm, uint32_t qi,
                       uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out) {
   memset(&dq, 0, sizeof dq);
   dq.item_first = (uint32_t)items.size();
@@ -860,6 +910,27 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   prox_out = prox_out || prox || T.phrase;
   tree_out = tree_out || !pure_and;
 
+  // two dense keywords: the bitmap kernel (mrk_scan_bm.hip) walks 2048-rowid windows instead of blocks
+  if (use_packed && pure_and && !T.phrase && n == 2 && (ranker == MRK_RANK_NONE || ranker == MRK_RANK_BM25) && seg->dev.bm &&
+      seg->ctx->bitmap_inv > 0 && seg->terms[T.kws[0].term_id].bm_off != ~0ull && seg->terms[T.kws[1].term_id].bm_off != ~0ull) {
+    dq.n_terms = 2;
+    for (int i = 0; i < 2; ++i) fill_term(seg, T.kws[i], dq.t[i]);
+    dq.tree_flags = TF_MULTIAND | TF_BITMAP;
+    dq.item_first = (uint32_t)items_bm.size();
+    const uint64_t nwin = seg->dev.n_windows;
+    const uint64_t bm_bytes = 2 * nwin * 256 + ((uint64_t)dq.t[0].nblocks + dq.t[1].nblocks) * 256; // bitmaps + attr words
+    dev_bytes += bm_bytes - pbytes; // (pbytes was added above)
+    // one entry for the whole window range; mrk_batch_submit cuts it once the batch's total is known (a wave's
+    // fixed costs -- tables, final publish, atomics on the query's counters -- want long runs of windows)
+    DevItem it{};
+    it.query = qi;
+    it.blk_begin = 0;
+    it.blk_end = (uint32_t)nwin;
+    items_bm.push_back(it);
+    dq.n_items = 1;
+    return MRK_OK;
+  }
+
   const DevQuery base = dq;
   for (size_t p = 0; p < cover.size(); ++p) {
     DevQuery* P = &dq;
@@ -1008,7 +1079,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   if (!n) return MRK_OK;
 
   // ---- plan
-  std::vector<DevItem> items;
+  std::vector<DevItem> items, items_bm;
   items.reserve(n * 4);
   uint64_t algo_bytes = 0, dev_bytes = 0, cand_total = 0;
   uint32_t max_terms = 1;
@@ -1017,13 +1088,14 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   const bool use_packed = seg->has_packed && b->ctx->path != 1;
   std::vector<DevQuery> extra; // passes beyond the first of tree queries; pass index = n + position
   for (uint32_t i = 0; i < n; ++i) {
-    const size_t extra0 = extra.size(), items0 = items.size();
-    int rc = plan_query(seg, queries[i], b->ctx->item_bytes, use_packed, b->h_queries.p[i], extra, n, items, i, algo_bytes,
+    const size_t extra0 = extra.size(), items0 = items.size(), items_bm0 = items_bm.size();
+    int rc = plan_query(seg, queries[i], b->ctx->item_bytes, use_packed, b->h_queries.p[i], extra, n, items, items_bm, i, algo_bytes,
                         dev_bytes, cand_total, any_prox, any_tree);
     b->status[i] = rc;
     if (rc == MRK_E_INVAL) return rc;
     if (rc != MRK_OK) { // unsupported: reported per query, runs no device work
       items.resize(items0);
+      items_bm.resize(items_bm0);
       extra.resize(extra0);
       b->h_queries.p[i].n_items = 0;
       b->h_queries.p[i].n_terms = 0;
@@ -1033,11 +1105,28 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;
   }
+  const size_t n_items_pk = items.size();
+  if (!items_bm.empty()) { // bitmap work items ride behind the block work items
+    uint64_t total_win = 0;
+    for (const DevItem& it : items_bm) total_win += it.blk_end - it.blk_begin;
+    const uint64_t unit = 4 * WAVES; // one burst per wave
+    uint64_t wpi = (total_win / (uint64_t)b->ctx->bm_target_items / unit) * unit;
+    wpi = std::min<uint64_t>(std::max<uint64_t>(wpi, 4 * unit), 4096);
+    for (const DevItem& whole : items_bm)
+      for (uint64_t w = whole.blk_begin; w < whole.blk_end; w += wpi) {
+        DevItem it = whole;
+        it.blk_begin = (uint32_t)w;
+        it.blk_end = (uint32_t)std::min<uint64_t>(whole.blk_end, w + wpi);
+        items.push_back(it);
+      }
+  }
+  const size_t n_items_bm = items.size() - n_items_pk;
   const size_t n_items = items.size();
   b->stats.algo_bytes = algo_bytes;
   b->stats.dev_bytes = dev_bytes;
   b->stats.packed = use_packed ? 1 : 0;
   b->stats.n_items = n_items;
+  b->stats.n_items_bm = n_items_bm;
   int rc;
   if ((rc = b->h_items.reserve(n_items + 1)) || (rc = b->d_items.reserve(n_items + 1)) ||
       (rc = b->d_item_cand.reserve((n_items + 1) * KCAP)) || (rc = b->d_item_cnt.reserve(n_items + 1)))
@@ -1071,16 +1160,22 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   sa.item_cnt = b->d_item_cnt.p;
   sa.q_total = b->d_q_total.p;
   sa.q_tau = b->d_q_tau.p;
-  sa.n_items = (uint32_t)n_items;
+  sa.n_items = (uint32_t)(use_packed ? n_items_pk : n_items);
   sa.q_hist = b->d_q_hist.p;
   sa.q_cand_n = b->d_q_cand_n.p;
   sa.q_flags = b->d_q_flags.p;
   sa.q_tau_bin = b->d_q_tau_bin.p;
   sa.cand = b->d_cand.p;
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
-  if (use_packed)
+  if (use_packed) {
     launch_scan_pk(sa, max_terms, any_prox, any_tree, st);
-  else
+    if (n_items_bm) {
+      ScanArgs sb = sa;
+      sb.items = b->d_items.p + n_items_pk;
+      sb.n_items = (uint32_t)n_items_bm;
+      launch_scan_bm(sb, st);
+    }
+  } else
     launch_scan(sa, st);
   HIP_TRY(hipEventRecord(b->ev_scan1, st));
 

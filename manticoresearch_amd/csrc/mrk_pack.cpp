@@ -39,8 +39,8 @@ struct Rd {
 };
 } // namespace
 
-bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, PackedTerm& out,
-               std::string& err) {
+bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, uint64_t bitmap_rows,
+               PackedTerm& out, std::string& err) {
   out = PackedTerm();
   if (!e.docs) return true;
   if (e.doclist_off == 0 || e.doclist_off + e.doclist_len > spd_len) {
@@ -59,14 +59,22 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
   uint64_t hit_position = 0; // m_uHitPosition / m_iHitlistPos (sphinx.cpp:534, 542)
   out.delta.reserve((size_t)nblk * 32 + 8);
 
+  bool want_bm = bitmap_rows != 0;
+  if (want_bm) {
+    const uint64_t windows = (bitmap_rows + BM_WINDOW - 1) / BM_WINDOW;
+    out.bm.assign((size_t)windows * (BM_WINDOW / 32), 0u);
+  }
   uint32_t rowid = 0xFFFFFFFFu; // decoder starts at INVALID_ROWID (sphinx.cpp:12947)
   uint32_t d[128], tf[128], fl[128], rows[128];
   for (uint32_t b = 0; b < nblk; ++b) {
     const uint32_t n = nd_total - b * 128 < 128 ? nd_total - b * 128 : 128;
     const uint32_t base = rowid + 1u;
     uint32_t dmax = 0;
-    const uint64_t hb = hit_position;
-    out.hbase.push_back(hb);
+    // hit references are relative to the block's first hitlist (a term's first delta is an absolute .spp
+    // position, sphinx.cpp:534/542, so the running position at the block start may be far below it)
+    uint64_t hb = hit_position;
+    bool hb_set = false;
+    out.hbase.push_back(0);
     uint32_t* hitref = out.hit.data() + (size_t)b * 128;
     for (uint32_t i = 0; i < n; ++i) {
       const uint32_t delta = (uint32_t)rd.vlb();
@@ -92,6 +100,7 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
         } else {
           fields = first;
           hit_position += rd.vlb(); // hitlist offset delta
+          if (!hb_set) hb = hit_position, hb_set = true;
           if (hit_position - hb > 0xFFFFFFFFull) {
             err = "hitlists of one block span more than 4 GiB";
             return false;
@@ -100,6 +109,7 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
         }
       } else {
         hit_position += rd.vlb();
+        if (!hb_set) hb = hit_position, hb_set = true;
         if (hit_position - hb > 0xFFFFFFFFull) {
           err = "hitlists of one block span more than 4 GiB";
           return false;
@@ -117,12 +127,19 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
         return false;
       }
       rows[i] = rowid;
+      if (want_bm) {
+        if (rowid < bitmap_rows)
+          out.bm[rowid >> 5] |= 1u << (rowid & 31u);
+        else
+          want_bm = false; // a rowid beyond the segment's row count: no bitmap for this term
+      }
       d[i] = rowid - base;
       if (d[i] > dmax) dmax = d[i];
       tf[i] = hits;
       fl[i] = fields;
       if (hits >= 255) out.exc.push_back(((uint64_t)rowid << 32) | hits);
     }
+    out.hbase[b] = hb;
     for (uint32_t i = n; i < 128; ++i) d[i] = 0, tf[i] = 0, fl[i] = 0;
     uint32_t w = 0;
     while (w < 32 && (dmax >> w)) ++w;
@@ -158,6 +175,18 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
     return false;
   }
   out.packed_bytes = out.delta.size() * 4 + out.attr.size() * 4 + (uint64_t)nblk * 9;
+  if (!want_bm)
+    out.bm.clear();
+  else {
+    const size_t groups = out.bm.size() / (BM_GROUP / 32);
+    out.bm_dir.resize(groups + 1);
+    uint32_t run = 0;
+    for (size_t g = 0; g < groups; ++g) {
+      out.bm_dir[g] = run;
+      for (uint32_t i = 0; i < BM_GROUP / 32; ++i) run += (uint32_t)__builtin_popcount(out.bm[g * (BM_GROUP / 32) + i]);
+    }
+    out.bm_dir[groups] = run;
+  }
   return true;
 }
 

@@ -18,12 +18,21 @@ struct PackedTerm {
   std::vector<uint64_t> exc;   // rowid<<32 | tf for tf >= 255
   std::vector<uint32_t> hit;   // 128 per block: the inlined Hitpos_t (inline format, tf == 1) or the doc's
                                // hitlist offset in .spp relative to hbase[block]
-  std::vector<uint64_t> hbase; // per block: SkiplistEntry_t::m_iBaseHitlistPos
+  std::vector<uint64_t> hbase; // per block: .spp position of the block's first hitlist
   uint64_t packed_bytes = 0;   // bytes a scan of the whole term reads (deltas + attrs + block index)
+  // dense terms only (bitmap_rows != 0): the doc set as a bitmap over [0, bitmap_rows), one 2048-rowid
+  // window = 64 words, plus a rank directory (docs before each group of 8 words = 256 rowids).
+  // A doc's rank is its slot in the packed arrays above (block = rank >> 7, slot = rank & 127).
+  std::vector<uint32_t> bm;
+  std::vector<uint32_t> bm_dir;
 };
 
+constexpr uint32_t BM_WINDOW = 2048; // rowids per bitmap window (64 lanes x 32 bits)
+constexpr uint32_t BM_GROUP = 256;   // rowids per rank-directory entry
+
 // returns false and sets err on malformed input
-bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, PackedTerm& out,
-               std::string& err);
+// bitmap_rows: 0 = no bitmap; else the segment's row count (every rowid of the term must be below it)
+bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, uint64_t bitmap_rows,
+               PackedTerm& out, std::string& err);
 
 } // namespace mrk

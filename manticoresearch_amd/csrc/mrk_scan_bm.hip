@@ -1,0 +1,248 @@
+// mrk_scan_bm.hip -- 2-keyword AND over doc-set BITMAPS (dense keywords), gfx950 / wave64.
+//
+// A keyword found in >= 1/bitmap_inv of a segment's docs carries, next to its packed doclist, a
+// bitmap of its doc set (mrk_pack.cpp).  ExtMultiAnd_T's leap-frog over two such keywords
+// (searchnode.cpp:2836-2981) then collapses to one AND per 32 rowids:
+//
+//   window = 2048 rowids: lane l holds word l of both bitmaps (two coalesced 256 B loads),
+//   m = a & b (& ~dead) are the window's matches.  A match's slot in each keyword's packed arrays
+//   is its RANK in that keyword's doc set: rank at the window start (running count, seeded from the
+//   rank directory) + popcounts of the lower lanes' words (one packed wave prefix sum for both
+//   keywords) + popcount of the lower bits of the lane's own word.
+//
+// Matches are queued per wave in LDS (rowid, rankA, rankB) and scored 64 at a time with every lane
+// busy: tf / field bytes come from the packed attr words (pk_attr, gathered by rank), BM25 and the
+// field-weight sum from the same per-workgroup tables and with the same fp32 operation order as the
+// packed scan kernel, then the pruning histogram / candidate list shared with it (mrk_kprune.h).
+// Field-limited keywords are honoured at scoring time (a doc counts for a keyword only if
+// fields & queried != 0, searchnode.cpp:1925-1939), so totals are counted there too.
+#include "mrk_kcommon.h"
+#include "mrk_kprune.h"
+
+#ifndef MRK_BMEXP
+#define MRK_BMEXP 0 // ablations for profiling: 1 no per-burst threshold load, 2 no scoring, 3 no match extraction
+#endif
+
+namespace mrk {
+
+constexpr int BM_CBUF = 128; // candidates a wave collects before it publishes them
+constexpr int BM_QCAP = 128; // match queue entries per wave (scored in batches of 64)
+constexpr int BM_WORDS = 64; // words per window
+
+struct __align__(16) BmWaveLds {
+  uint64_t cbuf[BM_CBUF];
+  uint32_t hist[NBINS]; // publishing scratch
+  uint32_t qrow[BM_QCAP];
+  uint32_t qra[BM_QCAP];
+  uint32_t qrb[BM_QCAP];
+};
+
+struct __align__(16) BmSmem {
+  BmWaveLds w[WAVES];
+  uint32_t rank[256];
+  float tfidf[2][256];
+};
+
+__global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
+  __shared__ BmSmem s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (blockIdx.x >= a.n_items) return;
+  const DevItem item = a.items[blockIdx.x];
+  const DevQuery* __restrict__ Q = a.queries + item.query;
+  const uint32_t K = Q->k, ranker = Q->ranker, oq = Q->out_q;
+  const uint32_t nw = Q->n_weights < 8u ? Q->n_weights : 8u;
+  const uint32_t index_weight = Q->index_weight;
+  const DevTerm TA = Q->t[0], TB = Q->t[1]; // ExtMultiAnd_T node order: tfidf = 0 + A + B
+  BmWaveLds& L = s.w[wave];
+  s.tfidf[0][tid] = term_tfidf(tid, TA.idf);
+  s.tfidf[1][tid] = term_tfidf(tid, TB.idf);
+  {
+    uint32_t rk = 0;
+    if (!tid)
+      rk = 1; // empty mask: "just fake it" (sphinxsearch.cpp:1114-1118)
+    else
+      for (uint32_t f = 0; f < nw; ++f)
+        if (tid & (1u << f)) rk += (uint32_t)Q->weights[f];
+    s.rank[tid] = rk;
+  }
+  const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
+  const int32_t bin_lo = Q->bin_lo;
+  const uint32_t cand_cap = Q->cand_cap;
+  uint64_t* __restrict__ cand = a.cand + Q->cand_off;
+  uint32_t* __restrict__ ghist = a.q_hist + (uint64_t)oq * NBINS;
+  uint32_t* __restrict__ gcount = a.q_cand_n + oq;
+  uint32_t* __restrict__ gtaubin = a.q_tau_bin + oq;
+  const uint32_t* __restrict__ bmA = a.seg.bm + TA.bm_off;
+  const uint32_t* __restrict__ bmB = a.seg.bm + TB.bm_off;
+  const uint32_t* __restrict__ dead = a.seg.dead;
+  const uint32_t* __restrict__ attr = a.seg.pk_attr;
+
+  const uint32_t nwin = item.blk_end - item.blk_begin;
+  const uint32_t per = (nwin + WAVES - 1) / WAVES;
+  const uint32_t w0 = item.blk_begin + wave * per;
+  const uint32_t w1 = w0 + per < item.blk_end ? w0 + per : item.blk_end;
+  __syncthreads(); // tables ready; the waves never meet again
+
+  uint32_t total = 0, tau_bin = 0, cn = 0, qn = 0;
+  // running ranks at the start of the next window (uniform)
+  uint32_t baseA = 0, baseB = 0;
+  if (w0 < w1) {
+    baseA = a.seg.bm_dir[TA.dir_off + (uint64_t)w0 * (BM_WORDS / 8)];
+    baseB = a.seg.bm_dir[TB.dir_off + (uint64_t)w0 * (BM_WORDS / 8)];
+  }
+
+  auto publish = [&]() {
+    if (cn) {
+      uint32_t basep = 0;
+      if (lane == 0) basep = atomicAdd(gcount, cn);
+      basep = rdlane(basep, 0);
+      const bool fits = basep + cn <= cand_cap;
+      const uint32_t npub = cn;
+      for (uint32_t i = lane; i < (uint32_t)NBINS; i += 64) L.hist[i] = 0;
+      wave_lds_fence();
+      for (uint32_t i = lane; i < cn; i += 64) {
+        const uint64_t key = L.cbuf[i];
+        if (fits) cand[basep + i] = key;
+        atomicAdd(&L.hist[bin_of(bin_mode, bin_lo, bin_shift, key_weight(key), key_rowid(key))], 1u);
+      }
+      if (!fits && lane == 0) atomicOr(a.q_flags + oq, QF_OVERFLOW);
+      wave_lds_fence();
+      flush_hist(L.hist, ghist);
+      cn = 0;
+      // only the publisher whose slice crosses a 2048-candidate boundary recomputes the threshold
+      if ((basep >> 11) != ((basep + npub) >> 11) || basep == 0) {
+        const uint32_t tb = threshold_bin(ghist, K);
+        if (tb > tau_bin) {
+          tau_bin = tb;
+          if (lane == 0) atomicMax(gtaubin, tb);
+        }
+      }
+    }
+    const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gt > tau_bin) tau_bin = gt;
+  };
+
+  // score the queue entries [from, from + n), n <= 64, one per lane
+  auto score = [&](uint32_t from, uint32_t n) {
+    wave_lds_fence();
+    const bool valid = lane < n;
+    const uint32_t e = from + (valid ? lane : 0u);
+    const uint32_t row = L.qrow[e], ra = L.qra[e], rb = L.qrb[e];
+    // packed attr word of slot r: block r >> 7, word r & 63, byte pair (r >> 6) & 1
+    const uint32_t wa = attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)];
+    const uint32_t wb = attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)];
+    const uint32_t sa = ((ra >> 6) & 1u) * 8u, sb = ((rb >> 6) & 1u) * 8u;
+    const uint32_t tfa = (wa >> sa) & 0xffu, tfb = (wb >> sb) & 0xffu;
+    const uint32_t fa = (wa >> (16u + sa)) & 0xffu & TA.queried32, fb = (wb >> (16u + sb)) & 0xffu & TB.queried32; // FitsFields
+    const bool live = valid && fa != 0 && fb != 0;
+    float ta = s.tfidf[0][tfa], tb = s.tfidf[1][tfb];
+    if (tfa == 255u && live) ta = term_tfidf(exc_tf(a.seg, TA, row), TA.idf);
+    if (tfb == 255u && live) tb = term_tfidf(exc_tf(a.seg, TB, row), TB.idf);
+    float acc = 0.0f + ta; // ExtMultiAnd_T::GetTFIDF: nodes in ascending-docs order
+    acc = acc + tb;
+    bool push = false;
+    uint64_t key = 0;
+    if (live) {
+      ++total;
+      uint32_t weight;
+      if (ranker == MRK_RANK_NONE)
+        weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
+      else {
+        // ExtRanker_WeightSum_c<BM25>, sphinxsearch.cpp:1070, 1112-1129
+        const int32_t bm = (int32_t)((acc + 0.5f) * 1000.0f);
+        weight = (uint32_t)bm + s.rank[fa | fb] * 1000u;
+      }
+      weight *= index_weight; // MatchExtended, sphinx.cpp:12220
+      const uint32_t grow = a.seg.rowid_base + row;
+      if (bin_of(bin_mode, bin_lo, bin_shift, (int32_t)weight, grow) >= tau_bin) {
+        push = true;
+        key = make_key((int32_t)weight, grow);
+      }
+    }
+    const uint64_t bal = __ballot(push);
+    if (bal) {
+      const uint32_t np = (uint32_t)__popcll(bal);
+      if (cn + np > (uint32_t)BM_CBUF) publish();
+      if (push) L.cbuf[cn + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+      cn += np;
+      if (cn >= (uint32_t)BM_CBUF - 64u) publish();
+    }
+  };
+
+  for (uint32_t wb = w0; wb < w1; wb += 4) {
+    // four windows requested back to back (one memory round trip per burst)
+    const uint32_t nb = w1 - wb < 4u ? w1 - wb : 4u;
+    uint32_t av[4], bv[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      av[i] = bv[i] = dv[i] = 0;
+      if ((uint32_t)i < nb) {
+        const uint64_t o = (uint64_t)(wb + i) * BM_WORDS + lane;
+        av[i] = bmA[o];
+        bv[i] = bmB[o];
+        if (dead) dv[i] = dead[o];
+      }
+    }
+#if MRK_BMEXP != 1
+    { // the query's shared pruning threshold rides along with the burst
+      const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (gt > tau_bin) tau_bin = gt;
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if ((uint32_t)i < nb) {
+        const uint32_t aw = av[i], bw = bv[i];
+        uint32_t m = aw & bw & ~dv[i];
+        // ranks of the lane's first bit: one prefix sum carries both keywords' popcounts
+        const uint32_t pc = (uint32_t)__popc(aw) | ((uint32_t)__popc(bw) << 16);
+        const uint32_t incl = wave_incl_scan(pc);
+        const uint32_t excl = incl - pc;
+        const uint32_t ra0 = baseA + (excl & 0xFFFFu), rb0 = baseB + (excl >> 16);
+        const uint32_t tot = rdlane(incl, 63);
+        baseA += tot & 0xFFFFu;
+        baseB += tot >> 16;
+        const uint32_t rowbase = (wb + i) * 2048u + lane * 32u;
+        uint64_t bal;
+#if MRK_BMEXP == 3
+        total += __popc(m);
+        m = 0;
+#endif
+        while ((bal = __ballot(m != 0)) != 0) {
+          const bool has = m != 0;
+          const uint32_t bit = has ? (uint32_t)__builtin_ctz(m) : 0u;
+          const uint32_t below = (1u << bit) - 1u;
+          const uint32_t pos = qn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+          if (has) {
+            L.qrow[pos] = rowbase + bit;
+            L.qra[pos] = ra0 + (uint32_t)__popc(aw & below);
+            L.qrb[pos] = rb0 + (uint32_t)__popc(bw & below);
+          }
+          qn += (uint32_t)__popcll(bal);
+          m &= m - 1u;
+          if (qn >= 64u) {
+#if MRK_BMEXP != 2
+            score(qn - 64u, 64u);
+#endif
+            qn -= 64u;
+            wave_lds_fence(); // the scored entries' slots may be rewritten
+          }
+        }
+      }
+    }
+  }
+  if (qn) score(0, qn);
+  if (cn) publish();
+  {
+    uint32_t t = total;
+    for (int dlt = 32; dlt; dlt >>= 1) t += __shfl_down(t, dlt, 64);
+    if (lane == 0 && t) atomicAdd((unsigned long long*)(a.q_total + oq), (unsigned long long)t);
+  }
+}
+
+void launch_scan_bm(const ScanArgs& a, void* stream) {
+  if (!a.n_items) return;
+  hipLaunchKernelGGL(scan_bm_kernel, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
+}
+
+} // namespace mrk

@@ -568,3 +568,65 @@ def test_dead_rows_are_dropped_before_the_sorter(orc, dev):
             assert g.total_found == g0.total_found and (g.rowid == g0.rowid).all()
     finally:
         seg.close()
+
+
+# ------------------------------------------------------------------ two dense keywords: the bitmap AND kernel
+def test_bitmap_and_kernel(orc, dev):
+    """Dense x dense 2-keyword ANDs run on doc-set bitmaps; same results as the oracle, with field limits,
+    saturated tf (>= 255 hits), a dead-row map, a row count that is no multiple of the 2048-rowid window."""
+    _tree_only(dev)
+    m, ctx, batch = dev
+    rng = np.random.default_rng(2048)
+    n_docs = 70001
+    probs = [0.5, 0.31, 0.3, 0.12, 0.05, 0.02, 0.9, 0.004]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=40, end_markers=True)
+    # a few docs of keyword 1 with 300 hits: tf saturates the packed byte -> exception list
+    fat = rng.choice(n_docs, 40, replace=False).astype(np.uint32)
+    keep = ~((W == 2) & np.isin(R, fat))
+    W, R, H = W[keep], R[keep], H[keep]
+    W = np.concatenate([W, np.full(fat.size * 300, 2, np.uint64)])
+    R = np.concatenate([R, np.repeat(fat, 300)])
+    H = np.concatenate([H, np.tile((np.uint32(1) << 24) | np.arange(1, 301, dtype=np.uint32), fat.size)])
+    o = np.lexsort((H, R, W))
+    W, R, H = W[o], R[o], H[o]
+    hi = m.index_from_hits(W, R, H, n_terms=len(probs), total_docs=n_docs, n_fields=3)
+    qs = []
+    for a_ in range(7):
+        for b_ in range(7):
+            if a_ == b_:
+                continue
+            for rk in (m.SPH_RANK_BM25, m.SPH_RANK_NONE):
+                mk = [0xFFFFFFFF if rng.random() < 0.6 else int(rng.integers(1, 8)) for _ in range(2)]
+                qs.append(m.Query(m.XQNode.AND(kw(m, a_, 1, mk[0]), kw(m, b_, 2, mk[1])), ranker=rk,
+                                  max_matches=int(rng.choice([3, 100, 1000, 1024])),
+                                  field_weights=[int(x) for x in rng.integers(-3, 12, 3)] if rng.random() < 0.5 else None,
+                                  index_weight=int(rng.choice([1, 2]))))
+    qs.append(m.Query(m.XQNode.AND(kw(m, 6, 1), kw(m, 6, 2)), ranker=m.SPH_RANK_BM25))  # the same keyword twice
+    qs.append(m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 7, 2)), ranker=m.SPH_RANK_BM25))  # dense x sparse: block path
+    ctx.set("item_bytes", 16 << 10)  # several work items per query
+    try:
+        check_batch(orc, dev, hi, qs)
+        seg = m.Segment(ctx, hi)
+        batch.search(seg, qs[:8])
+        assert batch.stats()["n_items_bm"] > 0  # the bitmap kernel did run
+        # dead rows are masked out of the match words
+        dead = np.zeros((n_docs + 31) // 32, np.uint32)
+        killed = rng.choice(n_docs, size=n_docs // 4, replace=False)
+        np.bitwise_or.at(dead, killed >> 5, (np.uint32(1) << (killed & 31).astype(np.uint32)))
+        seg.set_dead_rows(dead)
+        oi = orc_index_of(orc, hi)
+        oi.dead_rows = dead
+        for q, g in zip(qs[:40], batch.search(seg, qs[:40])):
+            want = to_orc(orc, q).run(oi)
+            assert g.status == 0 and g.total_found == want.total_found
+            assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+        seg.close()
+        # bitmaps off: the block kernel answers the same queries
+        ctx.set("bitmap_inv", 0)
+        seg = m.Segment(ctx, hi)
+        batch.search(seg, qs[:8])
+        assert batch.stats()["n_items_bm"] == 0
+        seg.close()
+    finally:
+        ctx.set("bitmap_inv", 64)
+        ctx.set("item_bytes", 128 << 10)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# tools/prof.sh TAG DOCS [STRATA] -- rocprofv3 passes over one bench configuration (run on the GPU box).
+#   pass 1: --kernel-trace --stats          -> gpurun_out/prof_TAG/stats
+#   pass 2,3: --pmc (own runs, no trace domains) -> gpurun_out/prof_TAG/pmc{1,2}
+set -e
+TAG=$1; DOCS=$2; STRATA=${3:-cc}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="$ROOT/bench.py --docs $DOCS --steps 2 --warmup 1 --no-cpu-baseline --latency-samples 0 --strata $STRATA"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $ARGS > $OUT/stats.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $OUT/pmc1 -o p -- python3 $ARGS > $OUT/pmc1.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $OUT/pmc2 -o p -- python3 $ARGS > $OUT/pmc2.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+for f in glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True):
+    print(open(f).read()[:1500])
+for d in ("pmc1", "pmc2"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % d, recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"][:40]
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] in ("SQ_WAVES", "GRBM_GUI_ACTIVE"): cnt[k] += 1
+    for k, v in acc.items():
+        print(d, k, "dispatches", cnt[k], {a: round(b / max(cnt[k], 1)) for a, b in v.items()})
+PY
