@@ -168,6 +168,7 @@ def main() -> None:
                 per[s]["packed"] = st["packed"]
                 per[s]["n_items"] = st["n_items"]
                 per[s]["n_cands"] = st["n_cands"]
+                per[s]["n_items_bm"] = st["n_items_bm"]
                 per[s]["n"] += 1
 
     def sync() -> None:
@@ -230,11 +231,19 @@ def main() -> None:
     algo = min(cc["algo_bytes"], cc.get("dev_bytes", cc["algo_bytes"])) + out_bytes
     achieved = algo / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
+    # which kernel carried the cc launch: the two-bitmap AND kernel (dense keywords) or the block scan
+    bm_share = cc.get("n_items_bm", 0) / max(1, cc.get("n_items", 1))
+    kernel_tag = "bm" if bm_share > 0.5 else ("pk" if cc.get("packed") else "vlb")
+    kernel_name = {"bm": "mrk::scan_bm_kernel", "pk": "mrk::scan_pk_kernel", "vlb": "mrk::scan_kernel"}[kernel_tag]
+    device_format = {"bm": "doc-set bitmaps (2048-rowid windows) + packed tf/field bytes gathered by rank",
+                     "pk": "packed 128-doc blocks (bit-packed rowid offsets + tf/field bytes)",
+                     "vlb": "reference .spd VLB"}[kernel_tag]
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_path):
         try:
             tj = json.load(open(tr_path))
-            if tj.get("docs") == args.docs and tj.get("queries") == nq and tj.get("skiplist_block") == args.skiplist_block:
+            if (tj.get("docs") == args.docs and tj.get("queries") == nq and tj.get("skiplist_block") == args.skiplist_block
+                    and tj.get("kernel_tag") == kernel_tag):
                 traffic = tj.get("traffic_bytes_per_launch")
         except Exception:
             traffic = None
@@ -268,11 +277,11 @@ def main() -> None:
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "kernel": "scan_kernel (common x common stratum launch)",
+            "kernel": f"{kernel_name} (common x common stratum launch)",
             "algo_bytes_per_launch": int(algo),
             "ref_format_bytes_per_launch": int(cc["algo_bytes"]),
             "device_format_bytes_per_launch": int(cc.get("dev_bytes", 0)),
-            "device_format": "packed 128-doc blocks (bit-packed rowid deltas + tf/field bytes)" if cc.get("packed") else "reference .spd VLB",
+            "device_format": device_format,
             "launch_ms": round(scan_ms, 4),
         },
         "strata": {

@@ -352,158 +352,220 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         }
         bool done[2] = {!live[0], !live[1]};
         bool hit[2] = {false, false};
-        if (cj_term != j) {
-          cj_term = j;
-          kj = 0;
-          cj.first = NOBLK;
-          bq_n = 0;
-          last_dec = NOBLK;
-        }
-        for (;;) {
-          // smallest driver rowid still waiting for this term (docs are in rowid order lane by lane)
-          const uint64_t p0 = __ballot(!done[0]), p1 = __ballot(!done[1]);
-          if (!(p0 | p1)) break;
-          const uint32_t r_min = p0 ? rdlane(row[0], (uint32_t)__builtin_ctzll(p0)) : rdlane(row[1], (uint32_t)__builtin_ctzll(p1));
-          // its block: the last one whose base <= r_min (HintRowID's FindSpan), never behind the cursor
-          if (cj.first == NOBLK || kj < cj.first || kj - cj.first >= (uint32_t)CHUNK) load_pk_chunk(cj, a.seg, Tj, kj);
-          {
-            const uint64_t le = __ballot(cj.bp1 <= r_min);
-            uint32_t p = le ? 63u - (uint32_t)__builtin_clzll(le) : 0u;
-            if (p >= (uint32_t)CHUNK) { // beyond this chunk: wave-wide 64-ary search, then reload
-              kj = wave_find_block(a.seg.pk_base + Tj.blk_first, cj.first + CHUNK - 1, Tj.nblocks, r_min);
-              load_pk_chunk(cj, a.seg, Tj, kj);
-              p = 0;
-            }
-            const uint32_t k_new = cj.first + p;
-            if (k_new > kj) kj = k_new;
+        if (Tj.bm_off != ~0ull) {
+          // Dense keyword: instead of decoding its blocks, test each waiting doc's bit in the keyword's doc-set
+          // bitmap; a set bit's RANK (directory count of the 256-rowid group + popcounts inside it) is the doc's
+          // slot in the keyword's packed arrays (block = rank >> 7, slot = rank & 127).
+          const uint32_t* __restrict__ bmj = a.seg.bm + Tj.bm_off;
+          const uint32_t* __restrict__ dirj = a.seg.bm_dir + Tj.dir_off;
+          const uint32_t row_end = a.seg.n_windows * 2048u;
+          uint4 g0[2], g1[2];
+          uint32_t db[2];
+          bool inb[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            inb[r] = !done[r] && row[r] < row_end;
+            const uint32_t grp = inb[r] ? row[r] >> 8 : 0u;
+            const uint4* __restrict__ gp = reinterpret_cast<const uint4*>(bmj + (uint64_t)grp * 8);
+            g0[r] = gp[0];
+            g1[r] = gp[1];
+            db[r] = dirj[grp];
           }
-          const uint32_t ci = kj - cj.first;
-          const uint32_t bp1_k = rdlane(cj.bp1, ci), bp1_n = rdlane(cj.bp1, ci + 1);
-          if (slot_blk != kj || slot_term != j) {
-            if (!(bq_n && kj >= bq_first && kj - bq_first < bq_n)) {
-              // sequential access bets on 8 blocks, a jump on 2
-              const uint32_t want = (last_dec == NOBLK || last_dec + 1 == kj) ? (uint32_t)MRK_BURST : 2u;
-              uint32_t nbq = Tj.nblocks - kj;
-              if (nbq > want) nbq = want;
-              if (nbq > (uint32_t)CHUNK - ci) nbq = (uint32_t)CHUNK - ci;
-              bq_first = kj;
-              bq_n = nbq;
-              q0r = issue_pk(a.seg, Tj, cj, ci);
-              if (nbq > 1) q1r = issue_pk(a.seg, Tj, cj, ci + 1);
-              if (nbq > 2) q2r = issue_pk(a.seg, Tj, cj, ci + 2);
-              if (nbq > 3) q3r = issue_pk(a.seg, Tj, cj, ci + 3);
-#if MRK_BURST > 4
-              if (nbq > 4) q4r = issue_pk(a.seg, Tj, cj, ci + 4);
-              if (nbq > 5) q5r = issue_pk(a.seg, Tj, cj, ci + 5);
-              if (nbq > 6) q6r = issue_pk(a.seg, Tj, cj, ci + 6);
-              if (nbq > 7) q7r = issue_pk(a.seg, Tj, cj, ci + 7);
-#endif
-              // the shared threshold word rides along with the burst
-              gt_new = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          uint32_t rk[2];
+          bool present[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const uint32_t wi = (row[r] >> 5) & 7u, bit = row[r] & 31u;
+            const uint32_t w[8] = {g0[r].x, g0[r].y, g0[r].z, g0[r].w, g1[r].x, g1[r].y, g1[r].z, g1[r].w};
+            uint32_t word = w[0], cnt = db[r];
+#pragma unroll
+            for (uint32_t i = 0; i < 7; ++i) {
+              if (i < wi) cnt += (uint32_t)__popc(w[i]);
+              if (i + 1 == wi) word = w[i + 1];
             }
-            last_dec = kj;
-            PkRaw rj;
-            switch (kj - bq_first) {
-              case 0: rj = q0r; break;
-              case 1: rj = q1r; break;
-              case 2: rj = q2r; break;
-#if MRK_BURST > 4
-              case 3: rj = q3r; break;
-              case 4: rj = q4r; break;
-              case 5: rj = q5r; break;
-              case 6: rj = q6r; break;
-              default: rj = q7r; break;
-#else
-              default: rj = q3r; break;
-#endif
-            }
-            const uint32_t wj = rdlane(cj.w, ci);
-            const uint32_t leftj = Tj.docs - kj * DEVBLK;
-            const uint32_t ndj = leftj < (uint32_t)DEVBLK ? leftj : (uint32_t)DEVBLK;
-            uint32_t e0, e1, f0, f1;
-            bool k0, k1;
-            decode_pk(rj, wj, bp1_k, ndj, e0, e1, f0, f1, k0, k1);
-            // offsets of a w-bit block stay below 2^w: small enough => direct map
-            slot_map = wj != PK_WIDE && (1u << wj) <= (uint32_t)MAPCAP;
-            L.tj_rowid[lane] = k0 ? e0 : INF_ROWID;
-            L.tj_rowid[lane + 64] = k1 ? e1 : INF_ROWID;
-            L.tj_attr[lane] = rj.attr;
-            if (slot_map) {
-              if (k0) L.map[f0] = (uint8_t)lane;
-              if (k1) L.map[f1] = (uint8_t)(lane + 64);
-            }
-            slot_blk = kj;
-            slot_term = j;
-            wave_lds_fence();
+            if (wi == 0) word = w[0];
+            present[r] = inb[r] && ((word >> bit) & 1u);
+            rk[r] = cnt + (uint32_t)__popc(word & ((1u << bit) - 1u));
           }
-          // probe: driver docs that fall into [bp1_k, bp1_n).  Both docs of a lane go through the
-          // dependent LDS reads side by side (map -> {rowid, attr} -> tfidf) instead of one after the other.
-          {
-            bool inr[2];
-            uint32_t pos[2];
+          uint32_t aw[2];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              inr[r] = !done[r] && row[r] >= bp1_k && row[r] < bp1_n;
-              done[r] = done[r] || inr[r];
-            }
-            if (slot_map) {
-              uint32_t mb[2];
+          for (int r = 0; r < 2; ++r) {
+            const uint32_t q = present[r] ? rk[r] : 0u;
+            aw[r] = a.seg.pk_attr[(uint64_t)(Tj.blk_first + (q >> 7)) * 64 + (q & 63u)];
+          }
 #pragma unroll
-              for (int r = 0; r < 2; ++r) {
-                const uint32_t o = row[r] - bp1_k;
-                mb[r] = L.map[inr[r] && o < (uint32_t)MAPCAP ? o : 0u]; // stale bytes are caught by the rowid check
+          for (int r = 0; r < 2; ++r) {
+            const uint32_t sh = ((rk[r] >> 6) & 1u) * 8u;
+            const uint32_t tfq = (aw[r] >> sh) & 0xffu;
+            const uint32_t fq = (aw[r] >> (16u + sh)) & 0xffu & Tj.queried32;
+            if (present[r] && fq != 0) {
+              hit[r] = true;
+              const float tvx = tfq == 255u ? term_tfidf(exc_tf(a.seg, Tj, row[r]), Tj.idf) : s.tfidf[j][tfq];
+              if (TREE) {
+                L.kv[j][lane + 64 * r] = tvx;
+                L.kf[j][lane + 64 * r] = (uint8_t)fq;
+              } else {
+                acc[r] = acc[r] + tvx;
+                fld[r] |= fq;
               }
-#pragma unroll
-              for (int r = 0; r < 2; ++r) pos[r] = mb[r] & 127u;
-            } else {
-#pragma unroll
-              for (int r = 0; r < 2; ++r) {
-                uint32_t p = 0;
-                const uint32_t rowid = inr[r] ? row[r] : 0u;
-#pragma unroll
-                for (uint32_t step = DEVBLK / 2; step; step >>= 1)
-                  if (L.tj_rowid[p + step - 1] < rowid) p += step;
-                pos[r] = p;
+              if (PROX && j < (uint32_t)MAX_PROX_TERMS)
+                L.href[j - 1][lane + 64 * r] = ((inline_hits && tfq == 1u) ? 0x80000000u : 0u) | rk[r];
+            }
+          }
+        } else {
+          if (cj_term != j) {
+            cj_term = j;
+            kj = 0;
+            cj.first = NOBLK;
+            bq_n = 0;
+            last_dec = NOBLK;
+          }
+          for (;;) {
+            // smallest driver rowid still waiting for this term (docs are in rowid order lane by lane)
+            const uint64_t p0 = __ballot(!done[0]), p1 = __ballot(!done[1]);
+            if (!(p0 | p1)) break;
+            const uint32_t r_min = p0 ? rdlane(row[0], (uint32_t)__builtin_ctzll(p0)) : rdlane(row[1], (uint32_t)__builtin_ctzll(p1));
+            // its block: the last one whose base <= r_min (HintRowID's FindSpan), never behind the cursor
+            if (cj.first == NOBLK || kj < cj.first || kj - cj.first >= (uint32_t)CHUNK) load_pk_chunk(cj, a.seg, Tj, kj);
+            {
+              const uint64_t le = __ballot(cj.bp1 <= r_min);
+              uint32_t p = le ? 63u - (uint32_t)__builtin_clzll(le) : 0u;
+              if (p >= (uint32_t)CHUNK) { // beyond this chunk: wave-wide 64-ary search, then reload
+                kj = wave_find_block(a.seg.pk_base + Tj.blk_first, cj.first + CHUNK - 1, Tj.nblocks, r_min);
+                load_pk_chunk(cj, a.seg, Tj, kj);
+                p = 0;
               }
+              const uint32_t k_new = cj.first + p;
+              if (k_new > kj) kj = k_new;
             }
-            uint32_t rid[2], aw[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              rid[r] = L.tj_rowid[pos[r]];
-              aw[r] = L.tj_attr[pos[r] & 63u];
+            const uint32_t ci = kj - cj.first;
+            const uint32_t bp1_k = rdlane(cj.bp1, ci), bp1_n = rdlane(cj.bp1, ci + 1);
+            if (slot_blk != kj || slot_term != j) {
+              if (!(bq_n && kj >= bq_first && kj - bq_first < bq_n)) {
+                // sequential access bets on 8 blocks, a jump on 2
+                const uint32_t want = (last_dec == NOBLK || last_dec + 1 == kj) ? (uint32_t)MRK_BURST : 2u;
+                uint32_t nbq = Tj.nblocks - kj;
+                if (nbq > want) nbq = want;
+                if (nbq > (uint32_t)CHUNK - ci) nbq = (uint32_t)CHUNK - ci;
+                bq_first = kj;
+                bq_n = nbq;
+                q0r = issue_pk(a.seg, Tj, cj, ci);
+                if (nbq > 1) q1r = issue_pk(a.seg, Tj, cj, ci + 1);
+                if (nbq > 2) q2r = issue_pk(a.seg, Tj, cj, ci + 2);
+                if (nbq > 3) q3r = issue_pk(a.seg, Tj, cj, ci + 3);
+  #if MRK_BURST > 4
+                if (nbq > 4) q4r = issue_pk(a.seg, Tj, cj, ci + 4);
+                if (nbq > 5) q5r = issue_pk(a.seg, Tj, cj, ci + 5);
+                if (nbq > 6) q6r = issue_pk(a.seg, Tj, cj, ci + 6);
+                if (nbq > 7) q7r = issue_pk(a.seg, Tj, cj, ci + 7);
+  #endif
+                // the shared threshold word rides along with the burst
+                gt_new = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              last_dec = kj;
+              PkRaw rj;
+              switch (kj - bq_first) {
+                case 0: rj = q0r; break;
+                case 1: rj = q1r; break;
+                case 2: rj = q2r; break;
+  #if MRK_BURST > 4
+                case 3: rj = q3r; break;
+                case 4: rj = q4r; break;
+                case 5: rj = q5r; break;
+                case 6: rj = q6r; break;
+                default: rj = q7r; break;
+  #else
+                default: rj = q3r; break;
+  #endif
+              }
+              const uint32_t wj = rdlane(cj.w, ci);
+              const uint32_t leftj = Tj.docs - kj * DEVBLK;
+              const uint32_t ndj = leftj < (uint32_t)DEVBLK ? leftj : (uint32_t)DEVBLK;
+              uint32_t e0, e1, f0, f1;
+              bool k0, k1;
+              decode_pk(rj, wj, bp1_k, ndj, e0, e1, f0, f1, k0, k1);
+              // offsets of a w-bit block stay below 2^w: small enough => direct map
+              slot_map = wj != PK_WIDE && (1u << wj) <= (uint32_t)MAPCAP;
+              L.tj_rowid[lane] = k0 ? e0 : INF_ROWID;
+              L.tj_rowid[lane + 64] = k1 ? e1 : INF_ROWID;
+              L.tj_attr[lane] = rj.attr;
+              if (slot_map) {
+                if (k0) L.map[f0] = (uint8_t)lane;
+                if (k1) L.map[f1] = (uint8_t)(lane + 64);
+              }
+              slot_blk = kj;
+              slot_term = j;
+              wave_lds_fence();
             }
-            uint32_t tfj[2], fj[2];
-            bool hp[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              const uint32_t sh = (pos[r] >> 6) * 8;
-              tfj[r] = (aw[r] >> sh) & 0xffu;
-              fj[r] = (aw[r] >> (16 + sh)) & 0xffu & Tj.queried32;
-              hp[r] = inr[r] && rid[r] == row[r] && fj[r] != 0;
-            }
-            float tv[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) tv[r] = s.tfidf[j][tfj[r]];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              if (hp[r]) {
-                hit[r] = true;
-                const float tvx = tfj[r] == 255u ? term_tfidf(exc_tf(a.seg, Tj, row[r]), Tj.idf) : tv[r];
-                if (TREE) {
-                  L.kv[j][lane + 64 * r] = tvx;
-                  L.kf[j][lane + 64 * r] = (uint8_t)fj[r];
-                } else {
-                  acc[r] = acc[r] + tvx;
-                  fld[r] |= fj[r];
+            // probe: driver docs that fall into [bp1_k, bp1_n).  Both docs of a lane go through the
+            // dependent LDS reads side by side (map -> {rowid, attr} -> tfidf) instead of one after the other.
+            {
+              bool inr[2];
+              uint32_t pos[2];
+  #pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                inr[r] = !done[r] && row[r] >= bp1_k && row[r] < bp1_n;
+                done[r] = done[r] || inr[r];
+              }
+              if (slot_map) {
+                uint32_t mb[2];
+  #pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                  const uint32_t o = row[r] - bp1_k;
+                  mb[r] = L.map[inr[r] && o < (uint32_t)MAPCAP ? o : 0u]; // stale bytes are caught by the rowid check
                 }
-                if (PROX && j < (uint32_t)MAX_PROX_TERMS)
-                  L.href[j - 1][lane + 64 * r] = ((inline_hits && tfj[r] == 1u) ? 0x80000000u : 0u) | (kj << 7) | pos[r];
+  #pragma unroll
+                for (int r = 0; r < 2; ++r) pos[r] = mb[r] & 127u;
+              } else {
+  #pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                  uint32_t p = 0;
+                  const uint32_t rowid = inr[r] ? row[r] : 0u;
+  #pragma unroll
+                  for (uint32_t step = DEVBLK / 2; step; step >>= 1)
+                    if (L.tj_rowid[p + step - 1] < rowid) p += step;
+                  pos[r] = p;
+                }
+              }
+              uint32_t rid[2], aw[2];
+  #pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                rid[r] = L.tj_rowid[pos[r]];
+                aw[r] = L.tj_attr[pos[r] & 63u];
+              }
+              uint32_t tfj[2], fj[2];
+              bool hp[2];
+  #pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                const uint32_t sh = (pos[r] >> 6) * 8;
+                tfj[r] = (aw[r] >> sh) & 0xffu;
+                fj[r] = (aw[r] >> (16 + sh)) & 0xffu & Tj.queried32;
+                hp[r] = inr[r] && rid[r] == row[r] && fj[r] != 0;
+              }
+              float tv[2];
+  #pragma unroll
+              for (int r = 0; r < 2; ++r) tv[r] = s.tfidf[j][tfj[r]];
+  #pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                if (hp[r]) {
+                  hit[r] = true;
+                  const float tvx = tfj[r] == 255u ? term_tfidf(exc_tf(a.seg, Tj, row[r]), Tj.idf) : tv[r];
+                  if (TREE) {
+                    L.kv[j][lane + 64 * r] = tvx;
+                    L.kf[j][lane + 64 * r] = (uint8_t)fj[r];
+                  } else {
+                    acc[r] = acc[r] + tvx;
+                    fld[r] |= fj[r];
+                  }
+                  if (PROX && j < (uint32_t)MAX_PROX_TERMS)
+                    L.href[j - 1][lane + 64 * r] = ((inline_hits && tfj[r] == 1u) ? 0x80000000u : 0u) | (kj << 7) | pos[r];
+                }
               }
             }
+  #pragma unroll
+            for (int r = 0; r < 2; ++r)
+              if (!done[r] && row[r] < bp1_k) done[r] = true; // cannot happen (cursor only moves forward)
           }
-#pragma unroll
-          for (int r = 0; r < 2; ++r)
-            if (!done[r] && row[r] < bp1_k) done[r] = true; // cannot happen (cursor only moves forward)
         }
         if (TREE) {
           const bool rq = ((req_mask >> j) & 1u) != 0, ex = ((excl_mask >> j) & 1u) != 0;
