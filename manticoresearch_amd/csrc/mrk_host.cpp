@@ -144,6 +144,7 @@ struct PinBuf {
 
 struct mrk_batch {
   mrk_ctx* ctx = nullptr;
+  hipStream_t stream = nullptr; // every batch runs on its own stream: batches of one context overlap on the device
   uint32_t max_queries = 0;
   uint32_t n_queries = 0; // of the last submit
   bool in_flight = false;
@@ -282,7 +283,7 @@ extern "C" int mrk_segment_set_dead_rows(mrk_segment* s, const uint32_t* bitmap,
     return mrk_fail(MRK_E_INVAL, "mrk_segment_set_dead_rows: map covers %llu rows, segment has %llu", (unsigned long long)n_rows,
                     (unsigned long long)s->total_docs);
   HIP_TRY(hipSetDevice(s->ctx->device));
-  HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+  HIP_TRY(hipDeviceSynchronize()); // batches of this context run on their own streams
   const size_t words = bitmap ? (size_t)((n_rows + 31) / 32) : 0;
   void* fresh = nullptr;
   if (words) {
@@ -1000,7 +1001,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
 extern "C" void mrk_batch_destroy(mrk_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
-  if (b->in_flight) (void)hipStreamSynchronize(b->ctx->stream);
+  if (b->in_flight && b->stream) (void)hipStreamSynchronize(b->stream);
   b->h_queries.release();
   b->h_items.release();
   b->h_list_first.release();
@@ -1027,6 +1028,7 @@ extern "C" void mrk_batch_destroy(mrk_batch* b) {
   b->h_cand_n.release();
   b->d_cand.release();
   b->h_flags.release();
+  if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
   if (b->ev_scan1) (void)hipEventDestroy(b->ev_scan1);
   if (b->ev_merge1) (void)hipEventDestroy(b->ev_merge1);
@@ -1053,6 +1055,7 @@ extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** 
     return rc;
   }
   hipError_t e1 = hipEventCreate(&b->ev_scan0), e2 = hipEventCreate(&b->ev_scan1), e3 = hipEventCreate(&b->ev_merge1);
+  if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     mrk_batch_destroy(b);
     return mrk_fail(MRK_E_HIP, "hipEventCreate failed");
@@ -1069,8 +1072,11 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   if (n > b->max_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: %u queries > batch capacity %u", n, b->max_queries);
   if (seg->ctx != b->ctx) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: segment and batch belong to different contexts");
   HIP_TRY(hipSetDevice(b->ctx->device));
-  hipStream_t st = b->ctx->stream;
-  if (b->in_flight) HIP_TRY(hipStreamSynchronize(st)); // pinned staging is about to be rewritten
+  // descriptors + scan kernels go down the context's stream (scans of different batches run back to back, each
+  // with the whole chip); the top-K selection and the result copies follow on the batch's own stream, so they
+  // overlap the next batch's scan
+  hipStream_t st = b->ctx->stream, st2 = b->stream;
+  if (b->in_flight) HIP_TRY(hipStreamSynchronize(st2)); // pinned staging is about to be rewritten
   b->in_flight = false;
   b->decoded = false;
   b->n_queries = n;
@@ -1178,6 +1184,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   } else
     launch_scan(sa, st);
   HIP_TRY(hipEventRecord(b->ev_scan1, st));
+  HIP_TRY(hipStreamWaitEvent(st2, b->ev_scan1, 0));
 
   MergeArgs ma{};
   ma.in_keys = b->d_item_cand.p;
@@ -1200,21 +1207,21 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
     se.rowid_base = seg->dev.rowid_base;
     se.out_keys = b->d_out_keys.p;
     se.out_cnt = b->d_out_cnt.p;
-    launch_select(se, st);
+    launch_select(se, st2);
   } else
-    launch_merge(ma, st);
-  HIP_TRY(hipEventRecord(b->ev_merge1, st));
+    launch_merge(ma, st2);
+  HIP_TRY(hipEventRecord(b->ev_merge1, st2));
   HIP_TRY(hipGetLastError());
   b->packed_run = use_packed;
   if (use_packed) {
-    HIP_TRY(hipMemcpyAsync(b->h_flags.p, b->d_q_flags.p, n * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(b->h_cand_n.p, b->d_q_cand_n.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b->h_flags.p, b->d_q_flags.p, n * 4, hipMemcpyDeviceToHost, st2));
+    HIP_TRY(hipMemcpyAsync(b->h_cand_n.p, b->d_q_cand_n.p, n * 4, hipMemcpyDeviceToHost, st2));
   }
 
   // ---- results to pinned host memory
-  HIP_TRY(hipMemcpyAsync(b->h_cnt.p, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(b->h_total.p, b->d_q_total.p, n * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(b->h_keys.p, b->d_out_keys.p, (size_t)n * KCAP * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_cnt.p, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToHost, st2));
+  HIP_TRY(hipMemcpyAsync(b->h_total.p, b->d_q_total.p, n * 8, hipMemcpyDeviceToHost, st2));
+  HIP_TRY(hipMemcpyAsync(b->h_keys.p, b->d_out_keys.p, (size_t)n * KCAP * 8, hipMemcpyDeviceToHost, st2));
   b->in_flight = true;
   return MRK_OK;
 }
@@ -1223,7 +1230,7 @@ extern "C" int mrk_batch_wait(mrk_batch* b) {
   if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_wait: NULL batch");
   if (!b->in_flight) return MRK_OK;
   HIP_TRY(hipSetDevice(b->ctx->device));
-  HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
   b->in_flight = false;
   float ms = 0;
   if (hipEventElapsedTime(&ms, b->ev_scan0, b->ev_scan1) == hipSuccess) b->stats.scan_ms = ms;
@@ -1282,7 +1289,7 @@ extern "C" int mrk_batch_device_results(mrk_batch* b, const uint64_t** keys, con
 extern "C" int mrk_batch_export_device(mrk_batch* b, uint64_t* keys_dst, uint32_t* counts_dst, uint64_t* totals_dst) {
   if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_export_device: NULL batch");
   HIP_TRY(hipSetDevice(b->ctx->device));
-  hipStream_t st = b->ctx->stream;
+  hipStream_t st = b->stream;
   const size_t n = b->n_queries;
   if (keys_dst) HIP_TRY(hipMemcpyAsync(keys_dst, b->d_out_keys.p, n * KCAP * 8, hipMemcpyDeviceToDevice, st));
   if (counts_dst) HIP_TRY(hipMemcpyAsync(counts_dst, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToDevice, st));
