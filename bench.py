@@ -123,9 +123,13 @@ def main() -> None:
     ctx.set("path", args.path)
     seg = m.Segment(ctx, hi, rowid_base=rank * shard_docs)
     batch = m.Batch(ctx, args.queries)
-    # one batch object per stratum: all three are submitted before the first wait, so host-side
-    # planning and result copies of one overlap the kernels of another
-    batches = {"cc": batch, "sc": m.Batch(ctx, args.queries), "ss": m.Batch(ctx, args.queries)}
+    # one batch object per stratum and two such sets used alternately: a step submits its three batches and only
+    # then collects the previous step's results, so host-side planning of one step overlaps the kernels of the other
+    # (what concurrent searchd workers do); every step's results still land in host memory inside the timed region
+    sets = [{"cc": batch, "sc": m.Batch(ctx, args.queries), "ss": m.Batch(ctx, args.queries)},
+            {"cc": m.Batch(ctx, args.queries), "sc": m.Batch(ctx, args.queries), "ss": m.Batch(ctx, args.queries)}]
+    batches = sets[0]
+    state = {"i": 0, "pending": None}
 
     # global DF / N so that every shard ranks with the same IDF (local_df, sphinxrt.cpp:6501-6521)
     local_docs = hi.dict["docs"].astype(np.int64)
@@ -148,19 +152,11 @@ def main() -> None:
 
     per = {s: {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0} for s in ["cc", "sc", "ss"]}
 
-    def step(record: bool) -> None:
-        if merger is None:
-            for s in names:
-                batches[s].submit_prepared(seg, prepared[s], nq)
+    def collect(cur, record: bool) -> None:
         for s in names:
-            if merger is not None:
-                batch.submit_prepared(seg, prepared[s], nq)
-                batch.wait()
-                merger.merge()
-            else:
-                batches[s].wait()
+            cur[s].wait()
             if record:
-                st = (batch if merger is not None else batches[s]).stats()
+                st = cur[s].stats()
                 per[s]["scan_ms"] += st["scan_ms"]
                 per[s]["merge_ms"] += st["merge_ms"]
                 per[s]["algo_bytes"] = st["algo_bytes"]
@@ -171,9 +167,35 @@ def main() -> None:
                 per[s]["n_items_bm"] = st["n_items_bm"]
                 per[s]["n"] += 1
 
+    def step(record: bool) -> None:
+        if merger is not None:  # sharded: scan, exchange partial top-K over RCCL, merge -- one stratum at a time
+            for s in names:
+                batch.submit_prepared(seg, prepared[s], nq)
+                batch.wait()
+                merger.merge()
+                if record:
+                    st = batch.stats()
+                    for k_ in ("scan_ms", "merge_ms"):
+                        per[s][k_] += st[k_]
+                    per[s].update(algo_bytes=st["algo_bytes"], dev_bytes=st["dev_bytes"], packed=st["packed"],
+                                  n_items=st["n_items"], n_cands=st["n_cands"], n_items_bm=st["n_items_bm"])
+                    per[s]["n"] += 1
+            return
+        cur = sets[state["i"] % 2]
+        state["i"] += 1
+        for s in names:
+            cur[s].submit_prepared(seg, prepared[s], nq)
+        if state["pending"] is not None:
+            collect(*state["pending"])
+        state["pending"] = (cur, record)
+
     def sync() -> None:
-        for bb in batches.values():
-            bb.wait()
+        if state["pending"] is not None:
+            collect(*state["pending"])
+            state["pending"] = None
+        for st_ in sets:
+            for bb in st_.values():
+                bb.wait()
         if world > 1:
             import torch
 
@@ -299,8 +321,9 @@ def main() -> None:
     elif rank == 0:
         out["cpu_baseline"] = None
 
-    for bb in batches.values():
-        bb.close()
+    for st_ in sets:
+        for bb in st_.values():
+            bb.close()
     seg.close()
     ctx.close()
     if world > 1 or force_dist:

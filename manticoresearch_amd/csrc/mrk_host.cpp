@@ -161,12 +161,19 @@ struct mrk_batch {
   DevBuf<DevItem> d_items;
   DevBuf<uint64_t> d_item_cand;
   DevBuf<uint32_t> d_item_cnt;
-  DevBuf<uint64_t> d_q_total, d_q_tau;
+  // per-query scan state lives in ONE allocation (q_total | q_tau | q_cand_n | q_flags | q_tau_bin | q_hist) so
+  // that a submit clears it with a single memset
+  DevBuf<uint8_t> d_state;
+  template <typename T>
+  struct View {
+    T* p = nullptr;
+  };
+  View<uint64_t> d_q_total, d_q_tau;
   DevBuf<uint32_t> d_list_first, d_list_n, d_kq;
   DevBuf<uint64_t> d_out_keys;
   DevBuf<uint32_t> d_out_cnt;
   // packed path: pruning histograms, candidate lists
-  DevBuf<uint32_t> d_q_hist, d_q_cand_n, d_q_flags, d_q_tau_bin;
+  View<uint32_t> d_q_hist, d_q_cand_n, d_q_flags, d_q_tau_bin;
   PinBuf<uint32_t> h_cand_n;
   DevBuf<uint64_t> d_cand;
   PinBuf<uint32_t> h_flags;
@@ -1014,17 +1021,13 @@ extern "C" void mrk_batch_destroy(mrk_batch* b) {
   b->d_items.release();
   b->d_item_cand.release();
   b->d_item_cnt.release();
-  b->d_q_total.release();
-  b->d_q_tau.release();
+  b->d_state.release();
   b->d_list_first.release();
   b->d_list_n.release();
   b->d_kq.release();
   b->d_out_keys.release();
   b->d_out_cnt.release();
-  b->d_q_hist.release();
-  b->d_q_cand_n.release();
-  b->d_q_flags.release();
-  b->d_q_tau_bin.release();
+
   b->h_cand_n.release();
   b->d_cand.release();
   b->h_flags.release();
@@ -1046,13 +1049,21 @@ extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** 
   const size_t nq = max_queries;
   if ((rc = b->h_queries.reserve(nq)) || (rc = b->h_list_first.reserve(nq)) || (rc = b->h_list_n.reserve(nq)) ||
       (rc = b->h_kq.reserve(nq)) || (rc = b->h_keys.reserve(nq * KCAP)) || (rc = b->h_cnt.reserve(nq)) ||
-      (rc = b->h_total.reserve(nq)) || (rc = b->d_queries.reserve(nq)) || (rc = b->d_q_total.reserve(nq)) ||
-      (rc = b->d_q_tau.reserve(nq)) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
+      (rc = b->h_total.reserve(nq)) || (rc = b->d_queries.reserve(nq)) ||
+      (rc = b->d_state.reserve(nq * (8 + 8 + 4 + 4 + 4 + (size_t)NBINS * 4))) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
       (rc = b->d_kq.reserve(nq)) || (rc = b->d_out_keys.reserve(nq * KCAP)) || (rc = b->d_out_cnt.reserve(nq)) ||
-      (rc = b->d_q_hist.reserve(nq * NBINS)) || (rc = b->d_q_cand_n.reserve(nq)) || (rc = b->d_q_flags.reserve(nq)) ||
-      (rc = b->h_flags.reserve(nq)) || (rc = b->d_q_tau_bin.reserve(nq)) || (rc = b->h_cand_n.reserve(nq))) {
+      (rc = b->h_flags.reserve(nq)) || (rc = b->h_cand_n.reserve(nq))) {
     mrk_batch_destroy(b);
     return rc;
+  }
+  {
+    uint8_t* base = b->d_state.p;
+    b->d_q_total.p = (uint64_t*)base;
+    b->d_q_tau.p = (uint64_t*)(base + nq * 8);
+    b->d_q_cand_n.p = (uint32_t*)(base + nq * 16);
+    b->d_q_flags.p = (uint32_t*)(base + nq * 20);
+    b->d_q_tau_bin.p = (uint32_t*)(base + nq * 24);
+    b->d_q_hist.p = (uint32_t*)(base + nq * 28);
   }
   hipError_t e1 = hipEventCreate(&b->ev_scan0), e2 = hipEventCreate(&b->ev_scan1), e3 = hipEventCreate(&b->ev_merge1);
   if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
@@ -1146,17 +1157,13 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   // ---- copy descriptors, launch
   HIP_TRY(hipMemcpyAsync(b->d_queries.p, b->h_queries.p, n_pass * sizeof(DevQuery), hipMemcpyHostToDevice, st));
   if (n_items) HIP_TRY(hipMemcpyAsync(b->d_items.p, b->h_items.p, n_items * sizeof(DevItem), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(b->d_list_first.p, b->h_list_first.p, n * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(b->d_list_n.p, b->h_list_n.p, n * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(b->d_kq.p, b->h_kq.p, n * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(b->d_q_total.p, 0, n * 8, st));
-  HIP_TRY(hipMemsetAsync(b->d_q_tau.p, 0, n * 8, st));
-  if (use_packed) {
-    HIP_TRY(hipMemsetAsync(b->d_q_hist.p, 0, (size_t)n * NBINS * 4, st));
-    HIP_TRY(hipMemsetAsync(b->d_q_cand_n.p, 0, n * 4, st));
-    HIP_TRY(hipMemsetAsync(b->d_q_flags.p, 0, n * 4, st));
-    HIP_TRY(hipMemsetAsync(b->d_q_tau_bin.p, 0, n * 4, st));
+  if (!use_packed) { // the VLB path's merge kernel reads per-query list ranges
+    HIP_TRY(hipMemcpyAsync(b->d_list_first.p, b->h_list_first.p, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_list_n.p, b->h_list_n.p, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_kq.p, b->h_kq.p, n * 4, hipMemcpyHostToDevice, st));
   }
+  // totals, thresholds, counters (+ the pruning histograms of the queries in use): one memset
+  HIP_TRY(hipMemsetAsync(b->d_state.p, 0, (size_t)b->max_queries * 28 + (use_packed ? (size_t)n * NBINS * 4 : 0), st));
 
   ScanArgs sa{};
   sa.seg = seg->dev;

@@ -1,0 +1,103 @@
+"""GPU parity at bench scale (BASELINE.json configs 2 and 3 shapes): 10 M docs by default, MRK_SCALE_DOCS=100000000
+for the full size.  The three device paths (bitmap AND kernel / packed block scan / VLB-direct) must agree with each
+other bit for bit and with the oracle; results obey the sorter's order; a second run returns the same bytes."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import ANDNOT, OR, kw, orc_index_of, to_orc
+
+pytestmark = pytest.mark.gpu
+
+N_DOCS = int(os.environ.get("MRK_SCALE_DOCS", 10_000_000))
+# document probabilities: four common keywords, two in between, four selective ones
+PROBS = [0.3, 0.12, 0.06, 0.031, 0.012, 0.004, 0.0011, 0.0004, 0.00013, 0.00005]
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    import manticoresearch_amd as m
+
+    return m, m.synth_index(N_DOCS, PROBS, seed=20261004, n_fields=3, max_pos=64, end_markers=True)
+
+
+def run_path(m, hi, qs, path, bitmap_inv):
+    ctx = m.Context(0)
+    ctx.set("path", path)
+    ctx.set("bitmap_inv", bitmap_inv)
+    batch = m.Batch(ctx, len(qs))
+    seg = m.Segment(ctx, hi)
+    try:
+        r1 = batch.search(seg, qs)
+        st = batch.stats()
+        r2 = batch.search(seg, qs)
+    finally:
+        seg.close()
+        batch.close()
+        ctx.close()
+    for a, b in zip(r1, r2):  # idempotence
+        assert a.total_found == b.total_found and (a.rowid == b.rowid).all() and (a.weight == b.weight).all()
+    return r1, st
+
+
+def check_order(r):
+    w, d = r.weight.astype(np.int64), r.rowid.astype(np.int64)
+    assert ((w[:-1] > w[1:]) | ((w[:-1] == w[1:]) & (d[:-1] < d[1:]))).all()  # MatchRelevanceLt_fn
+    assert r.total_found >= len(d) and len(np.unique(d)) == len(d)
+
+
+def test_two_term_and_paths_agree(orc, corpus):
+    m, hi = corpus
+    rng = np.random.default_rng(5)
+    qs = []
+    for a in range(len(PROBS)):
+        for b in range(len(PROBS)):
+            if a < b and rng.random() < 0.7:
+                pair = (a, b) if rng.random() < 0.5 else (b, a)
+                qs.append(m.Query(m.XQNode.AND(kw(m, pair[0], 1), kw(m, pair[1], 2)),
+                                  ranker=m.SPH_RANK_BM25 if rng.random() < 0.8 else m.SPH_RANK_NONE, max_matches=1000,
+                                  field_weights=[3, 1, 2] if rng.random() < 0.5 else None))
+    bm, st_bm = run_path(m, hi, qs, 0, 64)
+    pk, st_pk = run_path(m, hi, qs, 0, 0)
+    vl, st_vl = run_path(m, hi, qs, 1, 0)
+    assert st_bm["n_items_bm"] > 0 and st_pk["n_items_bm"] == 0 and st_pk["packed"] == 1 and st_vl["packed"] == 0
+    oi = orc_index_of(orc, hi)
+    for i, q in enumerate(qs):
+        for other in (pk[i], vl[i]):
+            assert bm[i].status == 0 and other.status == 0
+            assert bm[i].total_found == other.total_found
+            assert (bm[i].rowid == other.rowid).all() and (bm[i].weight == other.weight).all()
+        check_order(bm[i])
+        if i % 3 == 0 or N_DOCS <= 10_000_000:
+            want = to_orc(orc, q).run(oi)
+            assert bm[i].total_found == want.total_found
+            assert (bm[i].rowid == want.rowid).all() and (bm[i].weight == want.weight).all()
+
+
+def test_three_term_mixes_proximity_bm25(orc, corpus):
+    """BASELINE config 3: a b c, (a|b) c, a (b|c), a b -c under SPH_RANK_PROXIMITY_BM25 (hitlist decode)."""
+    m, hi = corpus
+    rng = np.random.default_rng(6)
+    qs = []
+    for _ in range(10):
+        a, b, c = (int(x) for x in rng.choice(np.arange(2, len(PROBS)), 3, replace=False))
+        ka, kb, kc = kw(m, a, 1), kw(m, b, 2), kw(m, c, 3)
+        for root in (m.XQNode.AND(ka, kb, kc), m.XQNode.AND(OR(m, ka, kb), kc), m.XQNode.AND(ka, OR(m, kb, kc)),
+                     ANDNOT(m, m.XQNode.AND(ka, kb), kc)):
+            qs.append(m.Query(root, ranker=m.SPH_RANK_PROXIMITY_BM25, max_matches=1000))
+    got, _ = run_path(m, hi, qs, 0, 64)
+    plain, _ = run_path(m, hi, qs, 0, 0)
+    oi = orc_index_of(orc, hi)
+    n_ok = 0
+    for q, g, p in zip(qs, got, plain):
+        assert g.status == p.status
+        if g.status != 0:
+            continue
+        assert g.total_found == p.total_found and (g.rowid == p.rowid).all() and (g.weight == p.weight).all()
+        check_order(g)
+        want = to_orc(orc, q).run(oi)
+        assert g.total_found == want.total_found
+        assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+        n_ok += 1
+    assert n_ok >= 30
