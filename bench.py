@@ -123,13 +123,8 @@ def main() -> None:
     ctx.set("path", args.path)
     seg = m.Segment(ctx, hi, rowid_base=rank * shard_docs)
     batch = m.Batch(ctx, args.queries)
-    # one batch object per stratum and two such sets used alternately: a step submits its three batches and only
-    # then collects the previous step's results, so host-side planning of one step overlaps the kernels of the other
-    # (what concurrent searchd workers do); every step's results still land in host memory inside the timed region
-    sets = [{"cc": batch, "sc": m.Batch(ctx, args.queries), "ss": m.Batch(ctx, args.queries)},
-            {"cc": m.Batch(ctx, args.queries), "sc": m.Batch(ctx, args.queries), "ss": m.Batch(ctx, args.queries)}]
-    batches = sets[0]
-    state = {"i": 0, "pending": None}
+    sharded = world > 1 or force_dist
+    state = {"i": 0, "pending": [], "rec": [False] * 8}
 
     # global DF / N so that every shard ranks with the same IDF (local_df, sphinxrt.cpp:6501-6521)
     local_docs = hi.dict["docs"].astype(np.int64)
@@ -148,55 +143,97 @@ def main() -> None:
     names = [x for x in ["cc", "sc", "ss"] if x in args.strata.split(",")]
     prepared = {s: m.prepare([mkq(a, b) for a, b in strata[s]]) for s in names}
     nq = args.queries
-    merger = mdist.ShardMerger(ctx, batch, nq, K, world, local_rank) if (world > 1 or force_dist) else None
+    # Work groups of a step.  One GPU: one batch per stratum (the cc launch is timed on its own for the roofline).
+    # Sharded: the step's queries go down as ONE batch per rank, so a step costs one scan launch, one selection,
+    # one RCCL all-gather of result rows and one merge.
+    if sharded:
+        prepared["all"] = m.prepare([mkq(a, b) for s in names for a, b in strata[s]])
+        groups = [("all", len(names) * nq)]
+    else:
+        groups = [(s, nq) for s in names]
+    # two sets of batches used alternately: a step submits its batches and only then collects the previous step's
+    # results, so host-side planning of one step overlaps the kernels of the other (what concurrent searchd workers
+    # do); every step's results still land in host memory inside the timed region
+    n_sets = 4 if sharded else 2  # the sharded chain (scan, selection, exchange, merge) is longer: keep 4 steps in flight
+    sets = [{g: (batch if (i == 0 and g == "cc") else m.Batch(ctx, n)) for g, n in groups} for i in range(n_sets)]
+    merger = None
+    if sharded:
+        merger = mdist.ShardMerger(ctx, batch, len(names) * nq, K, world, local_rank, n_batches=1, n_sets=n_sets)
+        for i in range(n_sets):
+            merger.attach([sets[i]["all"]], set_index=i)
 
-    per = {s: {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0} for s in ["cc", "sc", "ss"]}
+    per = {s: {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0} for s in ["cc", "sc", "ss", "all"]}
 
-    def collect(cur, record: bool) -> None:
-        for s in names:
-            cur[s].wait()
-            if record:
-                st = cur[s].stats()
-                per[s]["scan_ms"] += st["scan_ms"]
-                per[s]["merge_ms"] += st["merge_ms"]
-                per[s]["algo_bytes"] = st["algo_bytes"]
-                per[s]["dev_bytes"] = st["dev_bytes"]
-                per[s]["packed"] = st["packed"]
-                per[s]["n_items"] = st["n_items"]
-                per[s]["n_cands"] = st["n_cands"]
-                per[s]["n_items_bm"] = st["n_items_bm"]
-                per[s]["n"] += 1
+    host_ms = {"submit": 0.0, "wait": 0.0, "merge": 0.0, "n": 0}
+
+    def record_stats(s, st) -> None:
+        per[s]["scan_ms"] += st["scan_ms"]
+        per[s]["merge_ms"] += st["merge_ms"]
+        per[s].update(algo_bytes=st["algo_bytes"], dev_bytes=st["dev_bytes"], packed=st["packed"], n_items=st["n_items"],
+                      n_cands=st["n_cands"], n_items_bm=st["n_items_bm"])
+        per[s]["plan_ms"] = per[s].get("plan_ms", 0.0) + st["plan_ms"]
+        per[s]["submit_ms"] = per[s].get("submit_ms", 0.0) + st["submit_ms"]
+        per[s]["n"] += 1
+
+    def collect(idx: int, record: bool) -> None:
+        cur = sets[idx]
+        t_w = time.perf_counter()
+        for g, _ in groups:
+            cur[g].wait()
+        host_ms["wait"] += (time.perf_counter() - t_w) * 1e3
+        if record:
+            for g, _ in groups:
+                record_stats(g, cur[g].stats())
+
+    used = [False] * 8
 
     def step(record: bool) -> None:
-        if merger is not None:  # sharded: scan, exchange partial top-K over RCCL, merge -- one stratum at a time
-            for s in names:
-                batch.submit_prepared(seg, prepared[s], nq)
-                batch.wait()
-                merger.merge()
-                if record:
-                    st = batch.stats()
-                    for k_ in ("scan_ms", "merge_ms"):
-                        per[s][k_] += st[k_]
-                    per[s].update(algo_bytes=st["algo_bytes"], dev_bytes=st["dev_bytes"], packed=st["packed"],
-                                  n_items=st["n_items"], n_cands=st["n_cands"], n_items_bm=st["n_items_bm"])
-                    per[s]["n"] += 1
-            return
-        cur = sets[state["i"] % 2]
+        idx = state["i"] % n_sets
         state["i"] += 1
-        for s in names:
-            cur[s].submit_prepared(seg, prepared[s], nq)
-        if state["pending"] is not None:
-            collect(*state["pending"])
-        state["pending"] = (cur, record)
+        t_s = time.perf_counter()
+        if merger is not None:
+            # sharded: submit -> (event) -> all-gather -> merge -> host copy is ONE stream-ordered chain queued right
+            # here; the host only waits when a set comes round again, n_sets steps later
+            t_w = time.perf_counter()
+            merger.wait(idx)
+            if used[idx]:
+                sets[idx]["all"].wait()
+                if state["rec"][idx]:
+                    record_stats("all", sets[idx]["all"].stats())
+            host_ms["wait"] += (time.perf_counter() - t_w) * 1e3
+            t_s = time.perf_counter()
+            sets[idx]["all"].submit_prepared(seg, prepared["all"], len(names) * nq)
+            host_ms["submit"] += (time.perf_counter() - t_s) * 1e3
+            t_m = time.perf_counter()
+            merger.merge_attached(1, set_index=idx, to_host=True, after_submit=True)
+            host_ms["merge"] += (time.perf_counter() - t_m) * 1e3
+            host_ms["n"] += 1
+            used[idx] = True
+            state["rec"][idx] = record
+            return
+        for g, n in groups:
+            sets[idx][g].submit_prepared(seg, prepared[g], n)
+        host_ms["submit"] += (time.perf_counter() - t_s) * 1e3
+        host_ms["n"] += 1
+        state["pending"].append((idx, record))
+        while len(state["pending"]) >= n_sets:  # the set the next step reuses must be collected by then
+            collect(*state["pending"].pop(0))
 
     def sync() -> None:
-        if state["pending"] is not None:
-            collect(*state["pending"])
-            state["pending"] = None
+        while state["pending"]:
+            collect(*state["pending"].pop(0))
+        if merger is not None:
+            for i in range(n_sets):
+                merger.wait(i)
+                if used[i]:
+                    sets[i]["all"].wait()
+                    if state["rec"][i]:
+                        record_stats("all", sets[i]["all"].stats())
+                    used[i] = False
         for st_ in sets:
             for bb in st_.values():
                 bb.wait()
-        if world > 1:
+        if sharded:
             import torch
 
             torch.cuda.synchronize()
@@ -206,6 +243,10 @@ def main() -> None:
     for _ in range(args.warmup):
         step(False)
     sync()
+    for k_ in host_ms:
+        host_ms[k_] = 0
+    if merger is not None and merger.timing is not None:
+        merger.timing.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -218,6 +259,13 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # sharded runs scan all strata in one launch: time the cc launch on its own (outside the timed region) for the
+    # roofline fields
+    if sharded and "cc" in names:
+        for _ in range(3):
+            batch.submit_prepared(seg, prepared["cc"], nq)
+            batch.wait()
+            record_stats("cc", batch.stats())
     # output bytes of the cc stratum: 8 B per returned match
     if "cc" not in names:
         names_backup = names
@@ -305,17 +353,24 @@ def main() -> None:
             "device_format_bytes_per_launch": int(cc.get("dev_bytes", 0)),
             "device_format": device_format,
             "launch_ms": round(scan_ms, 4),
+            "timed": ("cc launch timed after the loop: the sharded loop scans all strata in one launch per rank" if sharded
+                      else "cc launches inside the timed region (HIP events on the scan stream)"),
         },
         "strata": {
             s: {"scan_ms": round(per[s]["scan_ms"] / max(1, per[s]["n"]), 4),
                 "merge_ms": round(per[s]["merge_ms"] / max(1, per[s]["n"]), 4),
-                "algo_MB": round(per[s]["algo_bytes"] / 1e6, 2), "dev_MB": round(per[s].get("dev_bytes", 0) / 1e6, 2), "items": per[s].get("n_items", 0), "cands": per[s].get("n_cands", 0)} for s in names},
+                "algo_MB": round(per[s]["algo_bytes"] / 1e6, 2), "dev_MB": round(per[s].get("dev_bytes", 0) / 1e6, 2), "items": per[s].get("n_items", 0), "cands": per[s].get("n_cands", 0),
+                "host_plan_ms": round(per[s].get("plan_ms", 0.0) / max(1, per[s]["n"]), 4),
+                "host_submit_ms": round(per[s].get("submit_ms", 0.0) / max(1, per[s]["n"]), 4)} for s in (names + ["all"]) if per[s]["n"]},
         "strata_run": names,
         "p50_latency_ms": round(float(np.percentile(lat, 50)), 4) if lat else None,
         "p95_latency_ms": round(float(np.percentile(lat, 95)), 4) if lat else None,
         "setup_s": {"generate": round(t_gen, 1), "index_MB": round((hi.spd.size + hi.spp.size + hi.spe.size) / 1e6, 1)},
     }
 
+    out["host_ms_per_step"] = {k_: round(v / max(1, host_ms["n"]), 4) for k_, v in host_ms.items() if k_ != "n"}
+    if merger is not None and merger.timing:
+        out["dist_timing_ms_per_call"] = {k_: round(v / max(1, merger.timing["calls"]), 4) for k_, v in merger.timing.items() if k_ != "calls"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(hi, strata, total_docs, K, args.cpu_seconds)
     elif rank == 0:

@@ -144,6 +144,8 @@ typedef struct {
   uint32_t packed;        /* 1 = packed-doclist path, 0 = VLB-direct path */
   uint64_t n_cands;       /* packed path: candidates that survived in-scan pruning (all queries) */
   uint64_t n_items_bm;    /* of n_items: work items of the two-bitmap AND kernel (dense keywords) */
+  float plan_ms;          /* host: query planning inside mrk_batch_submit */
+  float submit_ms;        /* host: whole mrk_batch_submit call */
 } mrk_batch_stats;
 
 const char* mrk_last_error(void);
@@ -184,6 +186,35 @@ int mrk_batch_device_results(mrk_batch* b, const uint64_t** keys, const uint32_t
 /* copy those three arrays into caller-owned device buffers (e.g. tensors handed to RCCL);
    any pointer may be NULL; synchronous */
 int mrk_batch_export_device(mrk_batch* b, uint64_t* keys_dst, uint32_t* counts_dst, uint64_t* totals_dst);
+
+/* Shard exchange in one buffer: a row of MRK_ROW_WORDS u64 per query = MRK_MAX_K keys (as above, zero
+   padded) | count | total_found.  mrk_batch_export_rows writes the last submit's results as rows into a
+   caller-owned DEVICE buffer [n_queries][MRK_ROW_WORDS] (e.g. the tensor handed to one RCCL all-gather) and
+   returns when the copy is done; mrk_topk_merge_rows merges rows_all[n_lists][n_queries][MRK_ROW_WORDS]
+   (device) into out_rows[n_queries][MRK_ROW_WORDS]: best k keys per query, totals added up
+   (CSphMatchQueue::MoveTo, sphinxsort.cpp:681-710). */
+#define MRK_ROW_WORDS (MRK_MAX_K + 2)
+int mrk_batch_export_rows(mrk_batch* b, uint64_t* rows_dst);
+/* standing order: every later submit also writes its rows to rows_dst (device, [max_queries][MRK_ROW_WORDS]) on the
+   batch's own stream right behind the selection kernel -- valid after mrk_batch_wait, no device work at collection
+   time.  NULL cancels it. */
+int mrk_batch_set_rows_dst(mrk_batch* b, uint64_t* rows_dst);
+/* record a caller-owned hipEvent_t on the batch's stream, i.e. behind everything the last submit queued there
+   (selection, standing rows export, result copies): lets another stream (RCCL's) wait for the rows without the host */
+int mrk_batch_record_event(mrk_batch* b, void* hip_event);
+int mrk_topk_merge_rows(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                        uint64_t* out_rows);
+
+/* Stream-ordered form for pipelined shard merges (nothing blocks the host): the merge is queued on the context's
+   merge stream behind `wait_event` (a hipEvent_t recorded by the producer of rows_all, e.g. on the RCCL stream;
+   NULL = none) and completion is marked in `slot` (0..MRK_MERGE_SLOTS-1); mrk_merge_wait blocks until that slot's
+   work is done.  out_rows may be device memory or PINNED HOST memory (hipHostMalloc / a pinned torch tensor): the
+   merge kernel then writes the merged rows straight into host memory (multi-MiB device-to-host hipMemcpyAsync calls
+   were seen to block the calling thread for 0.1-0.5 ms; a kernel writing over PCIe does not). */
+#define MRK_MERGE_SLOTS 8
+int mrk_topk_merge_rows_async(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                              uint64_t* out_rows, void* wait_event, uint32_t slot);
+int mrk_merge_wait(mrk_ctx* ctx, uint32_t slot);
 
 /* merge n_lists sorted partial top-K lists per query (device pointers):
    in_keys[(l*n_queries + q)*MRK_MAX_K + i], in_counts[l*n_queries + q] -> out_keys[q*MRK_MAX_K + i],

@@ -58,7 +58,7 @@ class Result(C.Structure):
 class BatchStats(C.Structure):
     _fields_ = [("scan_ms", C.c_float), ("merge_ms", C.c_float), ("algo_bytes", C.c_uint64), ("n_items", C.c_uint64),
                 ("dev_bytes", C.c_uint64), ("packed", C.c_uint32), ("n_cands", C.c_uint64),
-                ("n_items_bm", C.c_uint64)]
+                ("n_items_bm", C.c_uint64), ("plan_ms", C.c_float), ("submit_ms", C.c_float)]
 
 
 class SynthParams(C.Structure):
@@ -77,6 +77,13 @@ SYMBOLS = [
     ("mrk_segment_create", C.c_int, [C.c_void_p, C.POINTER(SegmentDesc), C.POINTER(C.c_void_p)]),
     ("mrk_segment_destroy", None, [C.c_void_p]),
     ("mrk_segment_device_bytes", C.c_uint64, [C.c_void_p]),
+    ("mrk_batch_export_rows", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mrk_batch_set_rows_dst", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mrk_topk_merge_rows_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                           C.c_uint32]),
+    ("mrk_merge_wait", C.c_int, [C.c_void_p, C.c_uint32]),
+    ("mrk_batch_record_event", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mrk_topk_merge_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("mrk_segment_set_dead_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("mrk_batch_create", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("mrk_batch_destroy", None, [C.c_void_p]),

@@ -308,7 +308,7 @@ class Batch:
         check(lib().mrk_batch_stats_get(self._h, C.byref(s)))
         return {"scan_ms": s.scan_ms, "merge_ms": s.merge_ms, "algo_bytes": int(s.algo_bytes), "n_items": int(s.n_items),
                 "dev_bytes": int(s.dev_bytes), "packed": int(s.packed), "n_cands": int(s.n_cands),
-                "n_items_bm": int(s.n_items_bm)}
+                "n_items_bm": int(s.n_items_bm), "plan_ms": float(s.plan_ms), "submit_ms": float(s.submit_ms)}
 
     def device_results(self):
         """(keys_ptr, counts_ptr, totals_ptr) of the last finished submit, HBM addresses."""

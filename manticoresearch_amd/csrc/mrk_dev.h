@@ -157,7 +157,21 @@ struct MergeArgs {
   uint32_t k;
   uint64_t* out_keys;          // [n_queries][KCAP], sorted descending
   uint32_t* out_cnt;
+  // row layout (shard exchange): one row of ROW_WORDS u64 per list = KCAP keys | count | total_found;
+  // in_rows replaces in_keys / in_cnt, out_rows replaces out_keys / out_cnt (totals are summed)
+  const uint64_t* in_rows;
+  uint64_t* out_rows;
 };
+constexpr int ROW_WORDS = MRK_ROW_WORDS;
+
+struct PackRowsArgs {
+  const uint64_t* keys;   // [n][KCAP]
+  const uint32_t* cnt;    // [n]
+  const uint64_t* total;  // [n]
+  uint64_t* rows;         // [n][ROW_WORDS]
+  uint32_t n;
+};
+void launch_pack_rows(const PackRowsArgs& a, void* stream);
 
 void launch_scan(const ScanArgs& a, void* stream);
 void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, void* stream);

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <new>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -47,6 +48,9 @@ int mrk_fail(int code, const char* fmt, ...) {
 struct mrk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t merge_stream = nullptr; // mrk_topk_merge: never queued behind the scans of a following batch
+  hipEvent_t merge_done[MRK_MERGE_SLOTS] = {};
+  bool merge_used[MRK_MERGE_SLOTS] = {};
   int64_t item_bytes = 128 << 10; // target doclist bytes per work item
   int path = 0;                   // 0 = packed doclists when the segment has them, 1 = VLB (.spd) direct, 2 = packed only
   int pack = 1;                   // build packed doclists at segment load
@@ -144,6 +148,8 @@ struct PinBuf {
 
 struct mrk_batch {
   mrk_ctx* ctx = nullptr;
+  uint64_t* rows_dst = nullptr; // mrk_batch_set_rows_dst
+  bool host_copied = true;      // per-query keys / counts / totals of the last submit are in pinned host memory
   hipStream_t stream = nullptr; // every batch runs on its own stream: batches of one context overlap on the device
   uint32_t max_queries = 0;
   uint32_t n_queries = 0; // of the last submit
@@ -199,8 +205,12 @@ extern "C" int mrk_ctx_create(int device, mrk_ctx** out) {
   mrk_ctx* c = new (std::nothrow) mrk_ctx();
   if (!c) return mrk_fail(MRK_E_NOMEM, "out of memory");
   c->device = device;
+  // (stream priorities were tried -- scans low, selection / merges high -- and cost 10-35 % of the throughput on
+  // MI355X: the scan launches stalled around every high-priority kernel; all streams stay at the default priority)
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->merge_stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return mrk_fail(MRK_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
@@ -212,6 +222,9 @@ extern "C" void mrk_ctx_destroy(mrk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->merge_stream) (void)hipStreamDestroy(c->merge_stream);
+  for (hipEvent_t e : c->merge_done)
+    if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -1096,6 +1109,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   if (!n) return MRK_OK;
 
   // ---- plan
+  const auto t_submit0 = std::chrono::steady_clock::now();
   std::vector<DevItem> items, items_bm;
   items.reserve(n * 4);
   uint64_t algo_bytes = 0, dev_bytes = 0, cand_total = 0;
@@ -1122,6 +1136,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;
   }
+  const float plan_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count();
   const size_t n_items_pk = items.size();
   if (!items_bm.empty()) { // bitmap work items ride behind the block work items
     uint64_t total_win = 0;
@@ -1154,6 +1169,13 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   if (!extra.empty()) memcpy(b->h_queries.p + n, extra.data(), extra.size() * sizeof(DevQuery));
   if (use_packed && (rc = b->d_cand.reserve(cand_total + 64))) return rc;
 
+  static const bool phase_timing = getenv("MRK_SUBMIT_TIMING") != nullptr;
+  auto lap = [&](const char* what) {
+    if (phase_timing)
+      fprintf(stderr, "mrk submit n=%u %s @%.3f ms\n", n, what,
+              std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count());
+  };
+  lap("planned+staged");
   // ---- copy descriptors, launch
   HIP_TRY(hipMemcpyAsync(b->d_queries.p, b->h_queries.p, n_pass * sizeof(DevQuery), hipMemcpyHostToDevice, st));
   if (n_items) HIP_TRY(hipMemcpyAsync(b->d_items.p, b->h_items.p, n_items * sizeof(DevItem), hipMemcpyHostToDevice, st));
@@ -1179,6 +1201,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   sa.q_flags = b->d_q_flags.p;
   sa.q_tau_bin = b->d_q_tau_bin.p;
   sa.cand = b->d_cand.p;
+  lap("h2d+memset");
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
   if (use_packed) {
     launch_scan_pk(sa, max_terms, any_prox, any_tree, st);
@@ -1191,6 +1214,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   } else
     launch_scan(sa, st);
   HIP_TRY(hipEventRecord(b->ev_scan1, st));
+  lap("scan launched");
   HIP_TRY(hipStreamWaitEvent(st2, b->ev_scan1, 0));
 
   MergeArgs ma{};
@@ -1218,6 +1242,15 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   } else
     launch_merge(ma, st2);
   HIP_TRY(hipEventRecord(b->ev_merge1, st2));
+  if (b->rows_dst) { // standing export for the shard exchange
+    PackRowsArgs pa{};
+    pa.keys = b->d_out_keys.p;
+    pa.cnt = b->d_out_cnt.p;
+    pa.total = b->d_q_total.p;
+    pa.rows = b->rows_dst;
+    pa.n = n;
+    launch_pack_rows(pa, st2);
+  }
   HIP_TRY(hipGetLastError());
   b->packed_run = use_packed;
   if (use_packed) {
@@ -1225,11 +1258,19 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
     HIP_TRY(hipMemcpyAsync(b->h_cand_n.p, b->d_q_cand_n.p, n * 4, hipMemcpyDeviceToHost, st2));
   }
 
-  // ---- results to pinned host memory
-  HIP_TRY(hipMemcpyAsync(b->h_cnt.p, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToHost, st2));
-  HIP_TRY(hipMemcpyAsync(b->h_total.p, b->d_q_total.p, n * 8, hipMemcpyDeviceToHost, st2));
-  HIP_TRY(hipMemcpyAsync(b->h_keys.p, b->d_out_keys.p, (size_t)n * KCAP * 8, hipMemcpyDeviceToHost, st2));
+  lap("select launched");
+  // ---- results to pinned host memory (a batch with a standing rows destination feeds a shard merge: its own
+  // lists are only copied if mrk_batch_result asks for them)
+  b->host_copied = b->rows_dst == nullptr;
+  if (b->host_copied) {
+    HIP_TRY(hipMemcpyAsync(b->h_cnt.p, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToHost, st2));
+    HIP_TRY(hipMemcpyAsync(b->h_total.p, b->d_q_total.p, n * 8, hipMemcpyDeviceToHost, st2));
+    HIP_TRY(hipMemcpyAsync(b->h_keys.p, b->d_out_keys.p, (size_t)n * KCAP * 8, hipMemcpyDeviceToHost, st2));
+  }
+  lap("d2h queued");
   b->in_flight = true;
+  b->stats.plan_ms = plan_ms;
+  b->stats.submit_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count();
   return MRK_OK;
 }
 
@@ -1258,6 +1299,15 @@ extern "C" int mrk_batch_result(mrk_batch* b, uint32_t q, mrk_result* out) {
   if (!b || !out) return mrk_fail(MRK_E_INVAL, "mrk_batch_result: NULL argument");
   if (b->in_flight) return mrk_fail(MRK_E_INVAL, "mrk_batch_result: call mrk_batch_wait first");
   if (q >= b->n_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_result: query %u of %u", q, b->n_queries);
+  if (!b->host_copied) {
+    const size_t n = b->n_queries;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipMemcpyAsync(b->h_cnt.p, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_total.p, b->d_q_total.p, n * 8, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_keys.p, b->d_out_keys.p, n * KCAP * 8, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->host_copied = true;
+  }
   if (!b->decoded) {
     for (uint32_t i = 0; i < b->n_queries; ++i) {
       const uint32_t cnt = b->status[i] == MRK_OK ? std::min<uint32_t>(b->h_cnt.p[i], KCAP) : 0;
@@ -1306,6 +1356,82 @@ extern "C" int mrk_batch_export_device(mrk_batch* b, uint64_t* keys_dst, uint32_
   return MRK_OK;
 }
 
+extern "C" int mrk_batch_set_rows_dst(mrk_batch* b, uint64_t* rows_dst) {
+  if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_set_rows_dst: NULL batch");
+  b->rows_dst = rows_dst;
+  return MRK_OK;
+}
+
+extern "C" int mrk_batch_record_event(mrk_batch* b, void* hip_event) {
+  if (!b || !hip_event) return mrk_fail(MRK_E_INVAL, "mrk_batch_record_event: NULL argument");
+  HIP_TRY(hipSetDevice(b->ctx->device));
+  HIP_TRY(hipEventRecord((hipEvent_t)hip_event, b->stream));
+  return MRK_OK;
+}
+
+extern "C" int mrk_batch_export_rows(mrk_batch* b, uint64_t* rows_dst) {
+  if (!b || !rows_dst) return mrk_fail(MRK_E_INVAL, "mrk_batch_export_rows: NULL argument");
+  HIP_TRY(hipSetDevice(b->ctx->device));
+  PackRowsArgs pa{};
+  pa.keys = b->d_out_keys.p;
+  pa.cnt = b->d_out_cnt.p;
+  pa.total = b->d_q_total.p;
+  pa.rows = rows_dst;
+  pa.n = b->n_queries;
+  launch_pack_rows(pa, b->stream); // behind the batch's selection kernel
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->in_flight = false;
+  return MRK_OK;
+}
+
+extern "C" int mrk_topk_merge_rows(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                                   uint64_t* out_rows) {
+  if (!ctx || !rows_all || !out_rows) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows: NULL argument");
+  if (k == 0 || k > MRK_MAX_K) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows: k %u outside 1..%d", k, MRK_MAX_K);
+  HIP_TRY(hipSetDevice(ctx->device));
+  MergeArgs ma{};
+  ma.in_rows = rows_all;
+  ma.out_rows = out_rows;
+  ma.n_lists = n_lists;
+  ma.n_queries = n_queries;
+  ma.k = k;
+  launch_merge(ma, ctx->merge_stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->merge_stream));
+  return MRK_OK;
+}
+
+extern "C" int mrk_topk_merge_rows_async(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                                         uint64_t* out_rows, void* wait_event, uint32_t slot) {
+  if (!ctx || !rows_all || !out_rows) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows_async: NULL argument");
+  if (k == 0 || k > MRK_MAX_K) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows_async: k %u outside 1..%d", k, MRK_MAX_K);
+  if (slot >= MRK_MERGE_SLOTS) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows_async: slot %u of %d", slot, MRK_MERGE_SLOTS);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->merge_done[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->merge_done[slot], hipEventDisableTiming));
+  if (wait_event) HIP_TRY(hipStreamWaitEvent(ctx->merge_stream, (hipEvent_t)wait_event, 0));
+  MergeArgs ma{};
+  ma.in_rows = rows_all;
+  ma.out_rows = out_rows;
+  ma.n_lists = n_lists;
+  ma.n_queries = n_queries;
+  ma.k = k;
+  launch_merge(ma, ctx->merge_stream);
+  HIP_TRY(hipGetLastError());
+
+  HIP_TRY(hipEventRecord(ctx->merge_done[slot], ctx->merge_stream));
+  ctx->merge_used[slot] = true;
+  return MRK_OK;
+}
+
+extern "C" int mrk_merge_wait(mrk_ctx* ctx, uint32_t slot) {
+  if (!ctx || slot >= MRK_MERGE_SLOTS) return mrk_fail(MRK_E_INVAL, "mrk_merge_wait: bad argument");
+  if (!ctx->merge_used[slot]) return MRK_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipEventSynchronize(ctx->merge_done[slot]));
+  return MRK_OK;
+}
+
 extern "C" int mrk_topk_merge(mrk_ctx* ctx, const uint64_t* in_keys, const uint32_t* in_counts, uint32_t n_lists,
                               uint32_t n_queries, uint32_t k, uint64_t* out_keys, uint32_t* out_counts) {
   if (!ctx || !in_keys || !in_counts || !out_keys || !out_counts) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge: NULL argument");
@@ -1322,8 +1448,8 @@ extern "C" int mrk_topk_merge(mrk_ctx* ctx, const uint64_t* in_keys, const uint3
   ma.k = k;
   ma.out_keys = out_keys;
   ma.out_cnt = out_counts;
-  launch_merge(ma, ctx->stream);
+  launch_merge(ma, ctx->merge_stream);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->merge_stream));
   return MRK_OK;
 }

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(MergeArgs a) {
       uint32_t cnt = 0;
       if (l < nlc) {
         const uint32_t li = a.list_first ? a.list_first[q] + lbase + l : (lbase + l) * a.n_queries + q;
-        cnt = a.in_cnt[li];
+        cnt = a.in_rows ? (uint32_t)a.in_rows[(uint64_t)li * ROW_WORDS + KCAP] : a.in_cnt[li];
         if (cnt > (uint32_t)KCAP) cnt = KCAP;
       }
       sum += cnt;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(MergeArgs a) {
           }
           const uint32_t idx = f - (lo ? s.lpre[lo - 1] : 0u);
           const uint32_t li = a.list_first ? a.list_first[q] + lbase + lo : (lbase + lo) * a.n_queries + q;
-          key = a.in_keys[(uint64_t)li * KCAP + idx];
+          key = a.in_rows ? a.in_rows[(uint64_t)li * ROW_WORDS + idx] : a.in_keys[(uint64_t)li * KCAP + idx];
           push = key >= tau && key != 0;
         }
         const uint64_t bal = __ballot(push);
@@ -562,8 +562,37 @@ __global__ __launch_bounds__(WG) void merge_kernel(MergeArgs a) {
     __syncthreads();
   }
   const uint32_t n = merge_compact(s, k);
+  if (a.out_rows) {
+    uint64_t* __restrict__ row = a.out_rows + (uint64_t)q * ROW_WORDS;
+    for (uint32_t i = tid; i < (uint32_t)KCAP; i += WG) row[i] = i < n ? s.cand[i] : 0ull;
+    if (tid == 0) {
+      uint64_t total = 0; // CSphMatchQueue::MoveTo adds the totals up (sphinxsort.cpp:681-710)
+      for (uint32_t l = 0; l < nl; ++l) total += a.in_rows[((uint64_t)l * a.n_queries + q) * ROW_WORDS + KCAP + 1];
+      row[KCAP] = n;
+      row[KCAP + 1] = total;
+    }
+    return;
+  }
   for (uint32_t i = tid; i < n; i += WG) a.out_keys[(uint64_t)q * KCAP + i] = s.cand[i];
   if (tid == 0) a.out_cnt[q] = n;
+}
+
+// a batch's results as exchange rows: KCAP keys | count | total_found
+__global__ __launch_bounds__(WG) void pack_rows_kernel(PackRowsArgs a) {
+  const uint32_t q = blockIdx.x;
+  if (q >= a.n) return;
+  uint64_t* __restrict__ row = a.rows + (uint64_t)q * ROW_WORDS;
+  const uint32_t n = a.cnt[q] < (uint32_t)KCAP ? a.cnt[q] : (uint32_t)KCAP;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)KCAP; i += WG) row[i] = i < n ? a.keys[(uint64_t)q * KCAP + i] : 0ull;
+  if (threadIdx.x == 0) {
+    row[KCAP] = n;
+    row[KCAP + 1] = a.total[q];
+  }
+}
+
+void launch_pack_rows(const PackRowsArgs& a, void* stream) {
+  if (!a.n) return;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(a.n), dim3(WG), 0, (hipStream_t)stream, a);
 }
 
 void launch_scan(const ScanArgs& a, void* stream) {

@@ -44,40 +44,112 @@ def exchange_partial_topk(keys, counts, totals):
     return keys_all, counts_all, totals
 
 
-class ShardMerger:
-    """Device-side merge of the per-shard results of the batch's last submit."""
+ROW_WORDS = MRK_MAX_K + 2  # MRK_ROW_WORDS: keys | count | total_found
 
-    def __init__(self, ctx, batch, n_queries: int, k: int, world: int, device: int):
+
+def exchange_rows(rows):
+    """ONE all-gather of [nq, ROW_WORDS] result rows -> [world, nq, ROW_WORDS] (gloo on CPU tensors, RCCL on device)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    rows_all = torch.empty((world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
+    dist.all_gather([rows_all[i] for i in range(world)], rows.contiguous())
+    return rows_all
+
+
+class ShardMerger:
+    """Device-side merge of per-shard results.  One row per query carries the partial top-K keys, their count and
+    total_found, so a step costs one collective and one merge launch.  attach() gives each batch a standing slice
+    of an exchange buffer that its submits fill on their own stream; merge_attached() then queues all-gather ->
+    merge -> host copy as a stream-ordered chain (RCCL stream -> event -> the library's merge stream) and returns
+    without blocking; wait(set) blocks until that set's merged rows are in host memory.  merge() is the simple
+    synchronous form for one batch."""
+
+    def __init__(self, ctx, batch, n_queries: int, k: int, world: int, device: int, n_batches: int = 1, n_sets: int = 1):
         import torch
 
+        assert n_sets <= 8  # MRK_MERGE_SLOTS
         self.torch = torch
-        self.ctx, self.batch, self.nq, self.k, self.world = ctx, batch, n_queries, k, world
+        self.ctx, self.batch, self.k, self.world = ctx, batch, k, world
+        self.per_batch = n_queries
+        self.nq = n_queries * n_batches
         dev = f"cuda:{device}"
-        self.keys = torch.zeros((n_queries, MRK_MAX_K), dtype=torch.int64, device=dev)
-        self.counts = torch.zeros((n_queries,), dtype=torch.int32, device=dev)
-        self.totals = torch.zeros((n_queries,), dtype=torch.int64, device=dev)
-        self.out_keys = torch.zeros((n_queries, MRK_MAX_K), dtype=torch.int64, device=dev)
-        self.out_counts = torch.zeros((n_queries,), dtype=torch.int32, device=dev)
+
+        def z(*shape):
+            return torch.zeros(shape, dtype=torch.int64, device=dev)
+
+        self.rows = [z(self.nq, ROW_WORDS) for _ in range(n_sets)]
+        self.rows_all = [z(world, self.nq, ROW_WORDS) for _ in range(n_sets)]
+        self.out_rows = [z(self.nq, ROW_WORDS) for _ in range(n_sets)]
+        self.host_rows = [torch.zeros((self.nq, ROW_WORDS), dtype=torch.int64).pin_memory() for _ in range(n_sets)]
+        self.gathered = [torch.cuda.Event() for _ in range(n_sets)]
+        self.ready = [torch.cuda.Event() for _ in range(n_sets)]
+        for ev in self.ready:  # created by their first record; the library re-records them on the batch streams
+            ev.record()
+        self.attached = [[] for _ in range(n_sets)]
+        self.on_host = [False] * n_sets  # where the set's last merge wrote: pinned host rows or device rows
+        self.timing = {} if __import__("os").environ.get("MRK_DIST_TIMING") else None  # host ms per phase, summed
+
+    def attach(self, batches, set_index: int = 0):
+        """Every later submit of batches[i] writes its rows into slice i of exchange buffer `set_index`."""
+        n = self.per_batch
+        assert len(batches) * n <= self.nq
+        for i, b in enumerate(batches):
+            check(lib().mrk_batch_set_rows_dst(b._h, self.rows[set_index][i * n:].data_ptr()))
+        self.attached[set_index] = list(batches)
 
     def merge(self):
-        torch = self.torch
-        check(lib().mrk_batch_export_device(self.batch._h, self.keys.data_ptr(), self.counts.data_ptr(),
-                                            self.totals.data_ptr()))
-        keys_all, counts_all, _ = exchange_partial_topk(self.keys, self.counts, self.totals)
-        torch.cuda.synchronize()
-        check(lib().mrk_topk_merge(self.ctx._h, keys_all.data_ptr(), counts_all.data_ptr(), self.world, self.nq, self.k,
-                                   self.out_keys.data_ptr(), self.out_counts.data_ptr()))
-        return self.out_keys, self.out_counts, self.totals
+        check(lib().mrk_batch_export_rows(self.batch._h, self.rows[0].data_ptr()))
+        self.merge_attached(1, 0)
+        self.wait(0)
+        return self.out_rows[0][: self.per_batch]
 
-    def results(self):
+
+    def merge_attached(self, n_batches: int, set_index: int = 0, to_host: bool = False, after_submit: bool = False):
+        """Rows of the attached batches of one set -> all-gather over RCCL -> merge (-> pinned host rows), queued
+        back to back; call wait(set_index) before reading or before reusing the set.  after_submit=True: the
+        batches were only submitted, not waited for -- the collective is ordered behind their streams by events,
+        so the host blocks nowhere (single attached batch per set)."""
+        import time
+        import torch.distributed as dist
+
+        nq = n_batches * self.per_batch
+        assert nq == self.nq, "merge_attached merges the whole attached set"
+        t0 = time.perf_counter()
+        rows_all = self.rows_all[set_index]
+        if after_submit:
+            assert len(self.attached[set_index]) == 1
+            ready = self.ready[set_index]
+            check(lib().mrk_batch_record_event(self.attached[set_index][0]._h, ready.cuda_event))
+            self.torch.cuda.current_stream().wait_event(ready)
+        # list-of-views form: identical on gloo and nccl (RCCL gathers straight into the slices)
+        dist.all_gather([rows_all[i] for i in range(self.world)], self.rows[set_index])
+        ev = self.gathered[set_index]
+        ev.record()  # on torch's current stream, behind the collective's completion
+        t1 = time.perf_counter()
+        check(lib().mrk_topk_merge_rows_async(self.ctx._h, rows_all.data_ptr(), self.world, nq, self.k,
+                                              (self.host_rows if to_host else self.out_rows)[set_index].data_ptr(),
+                                              ev.cuda_event, set_index))
+        self.on_host[set_index] = to_host
+        t2 = time.perf_counter()
+        if self.timing is not None:
+            for k_, v in zip(("exchange", "merge"), (t1 - t0, t2 - t1)):
+                self.timing[k_] = self.timing.get(k_, 0.0) + v * 1e3
+            self.timing["calls"] = self.timing.get("calls", 0) + 1
+
+    def wait(self, set_index: int = 0):
+        check(lib().mrk_merge_wait(self.ctx._h, set_index))
+
+    def results(self, set_index: int = 0, nq=None):
         """Decoded (global docid, weight) lists per query + total_found."""
-        ok = self.out_keys.cpu().numpy().view(np.uint64)
-        oc = self.out_counts.cpu().numpy()
-        tot = self.totals.cpu().numpy()
+        self.wait(set_index)
+        rows = (self.host_rows[set_index] if self.on_host[set_index] else self.out_rows[set_index].cpu()).numpy().view(np.uint64)
         out = []
-        for q in range(self.nq):
-            k = ok[q, : oc[q]]
+        for q in range(nq if nq is not None else self.nq):
+            cnt, tot = int(rows[q, MRK_MAX_K]), int(rows[q, MRK_MAX_K + 1])
+            k = rows[q, :cnt]
             weight = ((k >> np.uint64(32)).astype(np.uint32) ^ np.uint32(0x80000000)).view(np.int32)
             docid = ~k.astype(np.uint32)
-            out.append((docid, weight, int(tot[q])))
+            out.append((docid, weight, tot))
         return out

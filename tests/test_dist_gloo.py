@@ -50,7 +50,17 @@ def _worker(rank, world, port, q):
         keys[qi, : len(k)] = torch.from_numpy(k.view(np.int64))
         counts[qi] = len(k)
         totals[qi] = r.total_found
+    local_totals = totals.clone()
     keys_all, counts_all, totals = mdist.exchange_partial_topk(keys, counts, totals)
+    # the one-collective form: a row per query = keys | count | total_found
+    rows = torch.zeros((len(pairs), mdist.ROW_WORDS), dtype=torch.int64)
+    rows[:, :1024] = keys
+    rows[:, 1024] = counts.to(torch.int64)
+    rows[:, 1025] = local_totals
+    rows_all = mdist.exchange_rows(rows)
+    assert rows_all.shape == (world, len(pairs), mdist.ROW_WORDS)
+    assert torch.equal(rows_all[:, :, :1024], keys_all) and torch.equal(rows_all[:, :, 1024], counts_all.to(torch.int64))
+    assert torch.equal(rows_all[:, :, 1025].sum(0), totals) and torch.equal(rows_all[rank], rows)
     if rank == 0:
         q.put((keys_all.numpy().view(np.uint64), counts_all.numpy(), totals.numpy(), gdocs, total))
     dist.barrier()

@@ -630,3 +630,49 @@ def test_bitmap_and_kernel(orc, dev):
     finally:
         ctx.set("bitmap_inv", 64)
         ctx.set("item_bytes", 128 << 10)
+
+
+def test_row_export_and_merge(orc, dev):
+    """mrk_batch_export_rows / mrk_topk_merge_rows (the one-collective shard exchange): rows of two shards merged
+    on the device == oracle top-K of the union with global docids, totals added up."""
+    import ctypes as C
+    m, ctx, batch = dev
+    from manticoresearch_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+
+    def dmalloc(n):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(n)) == 0
+        return p
+
+    probs = [0.3, 0.2, 0.05, 0.01]
+    n_docs, K, RW = 150000, 1000, 1026
+    his = [m.synth_index(n_docs, probs, seed=4242, shard=s) for s in range(2)]
+    qs = [m.Query(m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), ranker=m.SPH_RANK_BM25, total_docs=2 * n_docs, max_matches=K,
+                  local_docs={t: int(his[0].dict[t]["docs"]) + int(his[1].dict[t]["docs"]) for t in (a, b)})
+          for a in range(4) for b in range(4) if a != b]
+    nq = len(qs)
+    rows_all, out_rows = dmalloc(2 * nq * RW * 8), dmalloc(nq * RW * 8)
+    want = []
+    for s in range(2):
+        seg = m.Segment(ctx, his[s], rowid_base=s * n_docs)
+        batch.submit(seg, qs)
+        batch.wait()
+        _lib.check(_lib.lib().mrk_batch_export_rows(batch._h, C.c_void_p(rows_all.value + s * nq * RW * 8)))
+        seg.close()
+        oi = orc_index_of(orc, his[s])
+        want.append([to_orc(orc, q).run(oi) for q in qs])
+    _lib.check(_lib.lib().mrk_topk_merge_rows(ctx._h, rows_all, 2, nq, K, out_rows))
+    host = np.zeros((nq, RW), np.uint64)
+    assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), out_rows, C.c_size_t(host.nbytes), 2) == 0
+    for qi in range(nq):
+        exp = sorted([(-int(w), int(r) + s * n_docs) for s in range(2) for r, w in zip(want[s][qi].rowid, want[s][qi].weight)])[:K]
+        cnt = int(host[qi, 1024])
+        k = host[qi, :cnt]
+        weight = ((k >> np.uint64(32)).astype(np.uint32) ^ np.uint32(0x80000000)).view(np.int32)
+        docid = ~k.astype(np.uint32)
+        assert [(-int(w), int(d)) for w, d in zip(weight, docid)] == exp
+        assert int(host[qi, 1025]) == want[0][qi].total_found + want[1][qi].total_found
+        assert not host[qi, cnt:1024].any()
+    for p in (rows_all, out_rows):
+        hip.hipFree(p)
