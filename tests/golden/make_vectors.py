@@ -1,0 +1,87 @@
+"""Writes tests/golden/reference_vectors.json.
+
+The values below were copied by hand, as data, from the reference's own test directories and docs while
+reading them (nothing of the reference is imported or executed): corpora = the <db_insert> rows of
+test/test_0NN/test.xml, expected docid:weight lists = the rows of the tests' model.bin (PHP-serialised text),
+plus the byte examples of doc/internals-index-format.txt and the weight asserted by gtest RTN.WeightBoundary.
+Run:  python tests/golden/make_vectors.py
+"""
+import json
+import os
+
+ALL = 0xFFFFFFFF
+
+
+def T(word, pos, mask=ALL):
+    return {"word": word, "pos": pos, "mask": mask}
+
+
+def OP(op, *kids, mask=ALL):
+    return {"op": op, "kids": list(kids), "mask": mask}
+
+
+G = {
+    "_about": "Golden vectors of the reference for the match -> rank -> top-K path; data only, see README.md",
+    "vlb_bytes": {"source": "doc/internals-index-format.txt:44-60",
+                  "cases": [[0x12345, [0x84, 0xC6, 0x45]], [0, [0]], [127, [0x7F]], [128, [0x81, 0]],
+                            [0xFFFFFFFF, [0x8F, 0xFF, 0xFF, 0xFF, 0x7F]]]},
+    "hitlist_bytes": {"source": "doc/internals-index-format.txt (hitlist example)", "hits": [2, 16777224, 16777229],
+                      "spp": [1, 2, 0x88, 0x80, 0x80, 6, 5, 0]},
+    "corpora": {
+        "weight_boundary": {"source": "src/gtests/gtests_rtstuff.cpp:257-335 (RTN.WeightBoundary)", "min_word_len": 1,
+                            "ids": [1], "docs": [["If I were a cat...", "We are the greatest cat"]]},
+        "test_037": {"source": "test/test_037/test.xml + model.bin", "min_word_len": 1, "ids": list(range(1, 11)),
+                     "docs": [["зимние шины диски чего то тут зимние шины", ""],
+                              ["test doc two", "second stupid test document with random content"]] + [["filler", "filler"]] * 8},
+        "test_019": {"source": "test/test_019/test.xml + model.bin", "min_word_len": 2,
+                     "ids": [111, 222, 333, 444, 555, 666, 777, 888, 999, 901, 902, 903, 910],
+                     "docs": [["", "basic query"], ["", "phrase query on steroids"],
+                              ["sample program", 'this is a test program that prints out "hello world" to the console'],
+                              ["", "china 吐我"], ["sample program two", "something written in basic | canon ef 16-35 lens"],
+                              ["sample program three", "something written in perl"], ["", "77 lies multiplied by 77"],
+                              ["", "agent 0077"], ["", "1234567812345678"], ["aaa", "aaa"], ["aaa", ""], ["", "aaa"],
+                              ["", "wordbefore\u0000\u0000wordafter"]]},
+        "test_322": {"source": "test/test_322/test.xml + model.bin", "min_word_len": 1, "ids": [1, 2, 3, 100],
+                     "docs": [["|sample program", "|program flow direct", "|sample program flow"],
+                              ["|one sample program", "|program rev flow", "|one rev flow"],
+                              ["|sample two program", "|sub program flow", "|two sub program"], ["unsigned", "", ""]]},
+    },
+    "cases": [
+        {"name": "weight_boundary", "corpus": "weight_boundary", "query": T("cat", 1, 0b01), "ranker": "proximity_bm25",
+         "expect": [[1, 1500]]},
+        {"name": "037 phrase proximity_bm25", "corpus": "test_037", "query": OP("phrase", T("зимние", 1), T("шины", 2)),
+         "ranker": "proximity_bm25", "expect": [[1, 2800]], "total_found": 1},
+        {"name": "037 phrase bm25", "corpus": "test_037", "query": OP("phrase", T("зимние", 1), T("шины", 2)), "ranker": "bm25",
+         "expect": [[1, 1800]], "total_found": 1},
+        {"name": "037 phrase none", "corpus": "test_037", "query": OP("phrase", T("зимние", 1), T("шины", 2)), "ranker": "none",
+         "expect": [[1, 1]], "total_found": 1},
+        {"name": "037 @title test bm25", "corpus": "test_037", "query": T("test", 1, 0b01), "ranker": "bm25", "expect": [[2, 1800]]},
+        {"name": "019 basic query", "corpus": "test_019", "query": OP("and", T("basic", 1), T("query", 2)),
+         "ranker": "proximity_bm25", "expect": [[111, 2654]]},
+        {"name": "019 \"phrase query\"", "corpus": "test_019", "query": OP("phrase", T("phrase", 1), T("query", 2)),
+         "ranker": "proximity_bm25", "expect": [[222, 2687]]},
+        {"name": "019 @title sample @body world", "corpus": "test_019",
+         "query": OP("and", T("sample", 1, 0b01), T("world", 2, 0b10)), "ranker": "proximity_bm25", "expect": [[333, 2666]]},
+        {"name": "019 basic | china", "corpus": "test_019", "query": OP("or", T("basic", 1), T("china", 2)),
+         "ranker": "proximity_bm25", "expect": [[444, 1610], [111, 1577], [555, 1577]]},
+        {"name": "019 \"test program\" | basic", "corpus": "test_019",
+         "query": OP("or", OP("phrase", T("test", 1), T("program", 2)), T("basic", 3)), "ranker": "proximity_bm25",
+         "expect": [[333, 2624], [111, 1551], [555, 1551]]},
+        {"name": "019 @title sample @body -basic", "corpus": "test_019",
+         "query": OP("andnot", T("sample", 1, 0b01), T("basic", 2, 0b10)), "ranker": "proximity_bm25",
+         "expect": [[333, 1555], [666, 1555]]},
+        {"name": "019 77", "corpus": "test_019", "query": T("77", 1), "ranker": "proximity_bm25", "expect": [[777, 1803]]},
+    ],
+}
+for spam, exp in [(1, [[1, 7415], [3, 6426], [2, 4421]]), (10, [[1, 25415], [3, 15426], [2, 13421]]),
+                  (0, [[3, 5426], [1, 5415], [2, 3421]]), (-2, [[3, 3426], [2, 1421], [1, 1415]]),
+                  (-10, [[3, -4574], [2, -6579], [1, -14585]])]:
+    G["cases"].append({"name": f"322 program flow, field_weights 1,2,{spam}", "corpus": "test_322",
+                       "query": OP("and", T("program", 1), T("flow", 2)), "ranker": "proximity_bm25",
+                       "field_weights": [1, 2, spam], "expect": exp})
+
+if __name__ == "__main__":
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
+    with open(out, "w", encoding="utf-8") as f:
+        json.dump(G, f, ensure_ascii=True, indent=1)
+    print(f"{out}: {len(G['cases'])} cases")

@@ -676,3 +676,37 @@ def test_row_export_and_merge(orc, dev):
         assert not host[qi, cnt:1024].any()
     for p in (rows_all, out_rows):
         hip.hipFree(p)
+
+
+# ------------------------------------------------------------------ tests/golden/reference_vectors.json on the device
+def test_golden_vectors_on_device(dev):
+    """Every case of the committed golden fixture, straight from the device path (no oracle in the loop).
+    A case whose shape the path declines (phrase below an OR) must say so, not answer wrongly."""
+    from test_oracle_golden import GOLDEN
+    m, ctx, batch = dev
+    rankers = {"proximity_bm25": m.SPH_RANK_PROXIMITY_BM25, "bm25": m.SPH_RANK_BM25, "none": m.SPH_RANK_NONE}
+    ops = {"and": m.SPH_QUERY_AND, "or": m.SPH_QUERY_OR, "andnot": m.SPH_QUERY_ANDNOT, "phrase": m.SPH_QUERY_PHRASE}
+
+    def tree(v, q):
+        if "word" in q:
+            return kw(m, v[q["word"]], q["pos"], q["mask"])
+        return m.XQNode(ops[q["op"]], [tree(v, k) for k in q["kids"]], None, q["mask"])
+
+    n_ok = 0
+    for name, corpus in GOLDEN["corpora"].items():
+        W, R, H, v = make_hits(corpus["docs"], corpus["min_word_len"])
+        nf = max(len(d) for d in corpus["docs"])
+        seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(corpus["docs"]), n_fields=nf))
+        cases = [c for c in GOLDEN["cases"] if c["corpus"] == name]
+        qs = [m.Query(tree(v, c["query"]), ranker=rankers[c["ranker"]], field_weights=c.get("field_weights")) for c in cases]
+        for c, r in zip(cases, batch.search(seg, qs)):
+            if r.status == -2:
+                continue
+            assert r.status == 0
+            assert [(corpus["ids"][i], int(w)) for i, w in zip(r.rowid, r.weight)] == [tuple(x) for x in c["expect"]], c["name"]
+            if "total_found" in c:
+                assert r.total_found == c["total_found"]
+            n_ok += 1
+        seg.close()
+    # packed path: everything but the phrase-below-OR case; VLB path: keyword / AND cases under BM25 / NONE
+    assert n_ok >= (len(GOLDEN["cases"]) - 1 if ctx_path(ctx) == 0 else 1), n_ok

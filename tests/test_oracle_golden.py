@@ -10,10 +10,16 @@ read at run time):
 Corpora are the rows of those tests' <db_insert> blocks; expected docid:weight pairs are
 the values decoded from model.bin.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
 from helpers import mini_index
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json"),
+                        encoding="utf-8"))
 
 
 # ------------------------------------------------------------------ VLB bytes
@@ -176,3 +182,30 @@ def test_dead_rows_skip_the_sorter(orc):
     idx.dead_rows = dead
     got, r = run(orc, idx, root, orc.RANK_PROXIMITY_BM25, T019_IDS)
     assert got == [(444, 1610), (555, 1577)] and r.total_found == 2
+
+
+# ------------------------------------------------------------------ tests/golden/reference_vectors.json, every case
+def _golden_tree(orc, v, q):
+    if "word" in q:
+        return orc.term(v[q["word"]], q["pos"], field_mask=q["mask"])
+    return orc.op(getattr(orc, "OP_" + q["op"].upper()), *[_golden_tree(orc, v, k) for k in q["kids"]], field_mask=q["mask"])
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=[c["name"] for c in GOLDEN["cases"]])
+def test_reference_vectors(orc, case):
+    corpus = GOLDEN["corpora"][case["corpus"]]
+    idx, v = mini_index(orc, corpus["docs"], min_word_len=corpus["min_word_len"])
+    got, r = run(orc, idx, _golden_tree(orc, v, case["query"]), getattr(orc, "RANK_" + case["ranker"].upper()), corpus["ids"],
+                 **({"field_weights": case["field_weights"]} if "field_weights" in case else {}))
+    assert got == [tuple(x) for x in case["expect"]]
+    if "total_found" in case:
+        assert r.total_found == case["total_found"]
+
+
+def test_reference_byte_vectors(orc):
+    for value, enc in GOLDEN["vlb_bytes"]["cases"]:
+        assert orc.zip_bytes(value) == bytes(enc)
+    hits = GOLDEN["hitlist_bytes"]["hits"]
+    idx = orc.build_index(np.ones(len(hits), np.uint64), np.zeros(len(hits), np.uint32), np.array(hits, np.uint32),
+                          total_docs=1, n_terms=1)
+    assert bytes(idx.spp) == bytes(GOLDEN["hitlist_bytes"]["spp"])
