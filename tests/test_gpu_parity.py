@@ -710,3 +710,68 @@ def test_golden_vectors_on_device(dev):
         seg.close()
     # packed path: everything but the phrase-below-OR case; VLB path: keyword / AND cases under BM25 / NONE
     assert n_ok >= (len(GOLDEN["cases"]) - 1 if ctx_path(ctx) == 0 else 1), n_ok
+
+
+# ------------------------------------------------------------------ many tiny corpora: boundaries of blocks / windows
+def test_fuzz_tiny_corpora_all_shapes(orc, dev):
+    """Corpora of 1 .. 5000 docs (below / around one 128-doc block and one 2048-rowid window), every query shape the
+    device accepts, dense and sparse keywords, dead rows, rowid bases: device == oracle."""
+    m, ctx, batch = dev
+    rng = np.random.default_rng(424242)
+    packed = ctx_path(ctx) == 0
+    n_checked = 0
+    for trial in range(28):
+        n_docs = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 257, 2047, 2048, 2049, 4097, 5000]))
+        nt = int(rng.integers(3, 7))
+        probs = [float(rng.choice([1.0, 0.7, 0.3, 0.1, 0.02, 0.6])) for _ in range(nt)]
+        W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=int(rng.choice([4, 30])), end_markers=True)
+        if len(W) == 0:
+            continue
+        block = int(rng.choice([32, 64, 128]))
+        fmt = int(rng.integers(0, 2))
+        hi = m.index_from_hits(W, R, H, n_terms=nt + 1, total_docs=n_docs, skiplist_block_size=block, hit_format=fmt, n_fields=3)
+        qs = []
+        for _ in range(14):
+            k = int(rng.integers(1, min(4, nt) + 1))
+            ts = [int(t) for t in rng.choice(nt + 1, size=k, replace=False)]
+            masks = [0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)) for _ in ts]
+            kws = [kw(m, t, i + 1, mk) for i, (t, mk) in enumerate(zip(ts, masks))]
+            shape = rng.choice(["and", "or", "andnot", "maybe", "phrase", "mixed"]) if (packed and k > 1) else "and"
+            if k == 1:
+                root = kws[0]
+            elif shape == "and":
+                root = m.XQNode.AND(*kws)
+            elif shape == "or":
+                root = OR(m, *kws)
+            elif shape == "andnot":
+                root = ANDNOT(m, kws[0], kws[1])
+            elif shape == "maybe":
+                root = MAYBE(m, kws[0], kws[1])
+            elif shape == "phrase":
+                root = PHRASE(m, *kws)
+            else:
+                root = m.XQNode.AND(OR(m, *kws[:2]), *kws[2:]) if k > 2 else OR(m, *kws)
+            rk = [m.SPH_RANK_BM25, m.SPH_RANK_NONE] + ([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY] if packed else [])
+            qs.append(m.Query(root, ranker=int(rng.choice(rk)), max_matches=int(rng.choice([1, 3, 1000, 1024])),
+                              field_weights=[int(x) for x in rng.integers(-2, 9, 3)] if rng.random() < 0.4 else None))
+        base = int(rng.choice([0, 7, 1 << 20]))
+        seg = m.Segment(ctx, hi, rowid_base=base)
+        oi = orc_index_of(orc, hi)
+        if rng.random() < 0.5:
+            dead = np.zeros((n_docs + 31) // 32, np.uint32)
+            killed = rng.choice(n_docs, size=max(1, n_docs // 5), replace=False)
+            np.bitwise_or.at(dead, killed >> 5, (np.uint32(1) << (killed & 31).astype(np.uint32)))
+            seg.set_dead_rows(dead)
+            oi.dead_rows = dead
+        try:
+            for q, g in zip(qs, batch.search(seg, qs)):
+                if g.status == -2:
+                    continue
+                want = to_orc(orc, q).run(oi)
+                assert g.status == 0
+                assert g.total_found == want.total_found, (trial, n_docs, g.total_found, want.total_found)
+                assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all(), (trial, n_docs)
+                n_checked += 1
+        finally:
+            seg.close()
+    assert n_checked > 200
