@@ -53,9 +53,10 @@ __device__ __forceinline__ bool row_is_dead(const DevSegment& seg, uint32_t rowi
 constexpr uint32_t PK_WIDE = 0xFFu;
 constexpr int NBINS = 1024; // pruning histogram bins per query
 constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
-constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4; // prog[] opcodes
+constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4, PN_PHRASEFIX = 5; // prog[] opcodes
 constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
 constexpr uint32_t TF_BITMAP = 4;   // 2-keyword AND answered by the bitmap kernel (items are window ranges)
+constexpr uint32_t TF_PHRASE_LEAF = 8; // one PHRASE below other operators: ph_mask = its words' slots in t[]
 constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[] = atom positions in phrase order
 constexpr int PHRASE_STATES = 8;    // live FSMphrase_c states per doc (>= phrase span + 1)
 constexpr int TREE_STACK = 4;       // evaluation stack depth of the tree program
@@ -100,6 +101,7 @@ struct DevQuery {
   uint32_t tree_flags; // TF_*
   uint32_t prog[16];  // op | left node << 8 | right node << 16 | keyword << 24
   uint32_t ph_atoms[MAX_PROX_TERMS_]; // PHRASE: query positions of its words, in phrase order
+  uint32_t ph_mask;                   // TF_PHRASE_LEAF: keyword slots of the phrase's words
   int32_t weights[32];
   DevTerm t[MRK_MAX_AND_TERMS];
 };

@@ -587,6 +587,8 @@ struct PlanTree {
   std::vector<PlanNode> nodes; // post-order; root = last
   bool multiand3_inner = false; // a 3-keyword ExtMultiAnd_T below the root (MergeHits3 quirk not restated there)
   bool phrase = false;          // root is a PHRASE (ExtNWay_T<FSMphrase_c>)
+  bool ph_leaf = false;         // one PHRASE below other operators; its words are kws[ph_kw0 .. ph_kw0 + ph_n)
+  int ph_kw0 = 0, ph_n = 0;
   std::vector<int> atoms;       // its words' query positions, phrase order
 };
 
@@ -623,8 +625,8 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     return (int)T.nodes.size() - 1;
   };
   if (n.op == MRK_OP_TERM) return leaf(ni);
-  if (n.op == MRK_OP_PHRASE && !is_root)
-    return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE below another operator is not on the device path yet", qi), -1;
+  if (n.op == MRK_OP_PHRASE && (T.phrase || T.ph_leaf))
+    return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: more than one PHRASE (device path: one per query)", qi), -1;
   if (n.op != MRK_OP_PHRASE && n.op != MRK_OP_AND && n.op != MRK_OP_OR && n.op != MRK_OP_MAYBE && n.op != MRK_OP_ANDNOT)
     return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, n.op), -1;
   if (n.n_children < 1 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
@@ -641,7 +643,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     if (!all_terms || n.n_children < 2 || n.n_children > MAX_PROX_TERMS)
       return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE of %d nodes (device path: 2..%d plain keywords)", qi, n.n_children,
                             MAX_PROX_TERMS), -1;
-    T.phrase = true;
+    (is_root ? T.phrase : T.ph_leaf) = true;
     for (int i = 0; i < n.n_children; ++i) {
       T.atoms.push_back(q.nodes[kids[i]].atom_pos);
       if (i && T.atoms[i] <= T.atoms[i - 1]) return err = mrk_fail(MRK_E_INVAL, "query %u: phrase atom positions must ascend", qi), -1;
@@ -662,14 +664,25 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
         if (docs[ord[j - 1]] < docs[ord[j]]) break;
         std::swap(ord[j], ord[j - 1]);
       }
-    if (n.n_children == 3 && !is_root) T.multiand3_inner = true;
+    if (n.op == MRK_OP_AND && n.n_children == 3 && !is_root) T.multiand3_inner = true;
+    const int kw0 = (int)T.kws.size();
     int cur = leaf(kids[ord[0]]);
     for (int i = 1; i < n.n_children; ++i) {
       const int r = leaf(kids[ord[i]]);
       cur = join(PN_AND, cur, r);
     }
-    if (n.op == MRK_OP_PHRASE) // the words are created with the phrase node's field limit (searchnode.cpp:1020-1024)
-      for (PlanKw& k : T.kws) k.queried32 &= n.field_mask;
+    if (n.op == MRK_OP_PHRASE) { // the words are created with the phrase node's field limit (searchnode.cpp:1020-1024)
+      for (size_t k = (size_t)kw0; k < T.kws.size(); ++k) T.kws[k].queried32 &= n.field_mask;
+      if (!is_root) { // ExtNWay_T on top of the words' AND chain: keeps the docs where the words line up
+        T.ph_kw0 = kw0;
+        T.ph_n = n.n_children;
+        PlanNode pn;
+        pn.op = PN_PHRASEFIX;
+        pn.l = cur;
+        T.nodes.push_back(pn);
+        cur = (int)T.nodes.size() - 1;
+      }
+    }
     return cur;
   }
   const uint32_t op = n.op == MRK_OP_AND ? PN_AND : n.op == MRK_OP_OR ? PN_OR : n.op == MRK_OP_MAYBE ? PN_MAYBE : PN_ANDNOT;
@@ -705,7 +718,7 @@ static void cover_of(const PlanTree& T, int ni, std::vector<int>& out) {
     out.insert(out.end(), w.begin(), w.end());
     return;
   }
-  cover_of(T, n.l, out); // MAYBE, ANDNOT: the left side carries the docs
+  cover_of(T, n.l, out); // MAYBE, ANDNOT, PHRASEFIX: the left side carries the docs
 }
 
 // keywords that must be present for the subtree to match
@@ -764,7 +777,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   if (!pure_and) { // the device evaluates the program on a TREE_STACK-deep register stack
     int sp = 0, deep = 0;
     for (const PlanNode& pn : T.nodes) {
-      sp += pn.op == PN_TERM ? 1 : -1;
+      sp += pn.op == PN_TERM ? 1 : pn.op == PN_PHRASEFIX ? 0 : -1;
       deep = std::max(deep, sp);
     }
     if (deep > TREE_STACK) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree nests deeper than the device path evaluates", qi);
@@ -772,7 +785,9 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
 
   uint32_t ranker;
   bool prox = false;
-  if (T.phrase) {
+  if (T.ph_leaf && n > MAX_PROX_TERMS)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE in a tree of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+  if (T.phrase || T.ph_leaf) {
     if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE runs on the packed path only", qi);
     if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
   }
@@ -884,7 +899,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
       // sum_f LCS[f] * w[f] with 0 <= LCS[f] <= number of keywords (hit weight 1, unique keywords)
       // (a phrase occurrence weighs its word count; back-to-back occurrences can add up -- beyond 2n the bins clamp)
       rmin = rmax = 0;
-      const int64_t top = T.phrase ? 2 * n : n;
+      const int64_t top = (T.phrase || T.ph_leaf) ? 2 * n : n;
       for (uint32_t f = 0; f < nwf; ++f) {
         rmin += std::min<int64_t>(0, top * dq.weights[f]);
         rmax += std::max<int64_t>(0, top * dq.weights[f]);
@@ -928,7 +943,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   }
   algo_bytes += bytes;
   dev_bytes += use_packed ? pbytes : bytes;
-  prox_out = prox_out || prox || T.phrase;
+  prox_out = prox_out || prox || T.phrase || T.ph_leaf;
   tree_out = tree_out || !pure_and;
 
   // two dense keywords: the bitmap kernel (mrk_scan_bm.hip) walks 2048-rowid windows instead of blocks
@@ -983,7 +998,9 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
     P->n_terms = (uint32_t)n;
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
     P->req_mask = P->excl_mask = 0;
-    P->tree_flags = T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : 0;
+    P->tree_flags = T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0;
+    P->ph_mask = 0;
+    for (int k = 0; k < T.ph_n; ++k) P->ph_mask |= 1u << slot[T.ph_kw0 + k];
     for (size_t i = 0; i < T.atoms.size(); ++i) P->ph_atoms[i] = (uint32_t)T.atoms[i];
     {
       for (int k = 0; k < n; ++k)

@@ -154,6 +154,65 @@ __device__ __forceinline__ bool field_queried(uint32_t qmask, uint32_t hitpos) {
   return f < 32 ? ((qmask >> f) & 1u) != 0 : qmask == 0xFFFFFFFFu;
 }
 
+// the keywords' hit streams of one doc: .spp cursor (0 = inlined hit / exhausted), current Hitpos_t (0 = exhausted)
+struct HitStreams {
+  uint64_t sp[MAX_PROX_TERMS];
+  uint32_t sc[MAX_PROX_TERMS], sq[MAX_PROX_TERMS], sm[MAX_PROX_TERMS];
+};
+
+// FSMphrase_c (searchnode.cpp:3884-3947): live states = (index of the last word read, expected position of the
+// next one).  A first-word hit opens a state; states whose expected position was passed die; a state that reads
+// its last word completes an occurrence and resets the machine.
+struct PhraseFsm {
+  uint32_t fexp[PHRASE_STATES];
+  uint32_t ftag, fvalid;
+  bool over; // more live states than we keep: the query is failed loudly
+
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int i = 0; i < PHRASE_STATES; ++i) fexp[i] = 0;
+    ftag = 0, fvalid = 0, over = false;
+  }
+  // one hit (position with field, no end bit; query position) of the merged word streams; true = occurrence complete
+  __device__ __forceinline__ bool step(uint32_t hp, uint32_t hq, uint32_t nph, uint32_t ap0, uint32_t ap1, uint32_t ap2,
+                                       uint32_t ap3) {
+    bool emit = false;
+    if (hq == (ap0 & 0xFFFFu)) {
+      const uint32_t freeb = ~fvalid & ((1u << PHRASE_STATES) - 1u);
+      if (!freeb)
+        over = true;
+      else {
+        const uint32_t idx = (uint32_t)__builtin_ctz(freeb);
+#pragma unroll
+        for (int i = 0; i < PHRASE_STATES; ++i)
+          if ((uint32_t)i == idx) fexp[i] = hp + (ap1 - ap0);
+        ftag &= ~(3u << (2 * idx));
+        fvalid |= 1u << idx;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PHRASE_STATES; ++i) {
+      if (!emit && ((fvalid >> i) & 1u)) {
+        if (fexp[i] < hp)
+          fvalid &= ~(1u << i);
+        else {
+          uint32_t tg = (ftag >> (2 * i)) & 3u;
+          const uint32_t nextq = tg == 0 ? ap1 : tg == 1 ? ap2 : ap3;
+          if (fexp[i] == hp && tg + 1 < nph && (nextq & 0xFFFFu) == hq) {
+            ++tg;
+            const uint32_t cq = tg == 1 ? ap1 : tg == 2 ? ap2 : ap3, nq = tg == 1 ? ap2 : ap3;
+            fexp[i] = tg + 1 < nph ? hp + (nq - cq) : hp - 0x7FFFFFFFu; // FSMphrase_c: -INT_MAX past the last word
+            ftag = (ftag & ~(3u << (2 * i))) | (tg << (2 * i));
+          }
+          if (tg == nph - 1) emit = true;
+        }
+      }
+    }
+    if (emit) fvalid = 0; // ResetFSM
+    return emit;
+  }
+};
+
 // one value of the boolean-tree evaluation stack, for the two docs a lane owns
 struct TreeEnt {
   bool m[2];     // subtree matches the doc
@@ -181,7 +240,9 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const uint32_t oq = Q->out_q; // logical query: several passes (driver keywords) may feed one result
   const uint32_t req_mask = TREE ? Q->req_mask : 0u, excl_mask = TREE ? Q->excl_mask : 0u;
   const uint32_t n_nodes = TREE ? Q->n_nodes : 0u;
-  const bool phrase = PROX && (Q->tree_flags & TF_PHRASE) != 0;
+  const bool phrase = PROX && (Q->tree_flags & TF_PHRASE) != 0;                // the whole query is one PHRASE
+  const bool ph_leaf = TREE && PROX && (Q->tree_flags & TF_PHRASE_LEAF) != 0; // a PHRASE below other operators
+  const uint32_t ph_mask = ph_leaf ? Q->ph_mask : 0u;                         // its words' keyword slots
   const bool multi_and = (!TREE || (Q->tree_flags & TF_MULTIAND) != 0) && !phrase;
   // PHRASE: query positions of its words in phrase order (FSMphrase_c::m_dAtomPos, searchnode.cpp:3884-3899)
   const uint32_t ap0 = PROX ? Q->ph_atoms[0] : 0u, ap1 = PROX ? Q->ph_atoms[1] : 0u, ap2 = PROX ? Q->ph_atoms[2] : 0u,
@@ -581,6 +642,147 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         }
       }
 
+      // ---- one doc's hit pass.  smask = keyword slots whose hits take part, pmask = slots forming the phrase
+      // (0 = none), rank = feed RankerState_Proximity_fn (else: stop at the first phrase occurrence).
+      auto hit_pass = [&](int r, uint32_t smask, uint32_t pmask, bool rank, bool& ph_found, uint32_t& ph_field, int& rk_out) {
+        const uint8_t* __restrict__ spp = a.seg.spp;
+        HitStreams S;
+#pragma unroll
+        for (int t = 0; t < MAX_PROX_TERMS; ++t) {
+          S.sp[t] = 0, S.sc[t] = 0, S.sq[t] = 0, S.sm[t] = 0;
+          if ((uint32_t)t < nterms && ((smask >> t) & 1u)) {
+            const DevTerm& Tt = Q->t[t];
+            uint32_t gblk, idx;
+            bool lone;
+            if (t == 0) {
+              gblk = T0.blk_first + b;
+              idx = lane + 64 * r;
+              lone = inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u;
+            } else {
+              const uint32_t h = L.href[t - 1][lane + 64 * r];
+              gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu);
+              idx = h & 127u;
+              lone = (h >> 31) != 0;
+            }
+            S.sq[t] = Tt.qpos;
+            S.sm[t] = Tt.queried32;
+            const uint32_t hv = a.seg.pk_hit[(uint64_t)gblk * DEVBLK + idx];
+            if (lone) // the hit travelled in the doclist entry (SeekHitlist state 1, sphinx.cpp:461-464)
+              S.sc[t] = hv;
+            else {
+              S.sp[t] = a.seg.pk_hbase[gblk] + hv;
+              hit_advance(spp, S.sp[t], S.sc[t]);
+            }
+          }
+        }
+        // the phrase as a stream of folded hits: position = first word's, weight = word count, spanlen = span + 1
+        const uint32_t nph = (uint32_t)__popc(pmask);
+        const uint32_t span = (nph == 2 ? ap1 : nph == 3 ? ap2 : ap3) - ap0;
+        PhraseFsm F;
+        F.reset();
+        bool phave = false;
+        uint32_t pcur = 0, pfield = 0;
+        auto phrase_next = [&]() {
+          phave = false;
+          for (;;) {
+            int best = -1;
+            uint32_t bh = 0, bq = 0, bmask = 0;
+#pragma unroll
+            for (int t = 0; t < MAX_PROX_TERMS; ++t) // the phrase's top ExtAnd_c orders equal positions by DESCENDING qpos
+              if (((pmask >> t) & 1u) && S.sc[t] && (best < 0 || S.sc[t] < bh || (S.sc[t] == bh && S.sq[t] > bq)))
+                best = t, bh = S.sc[t], bq = S.sq[t], bmask = S.sm[t];
+            if (best < 0) return;
+            const uint32_t hp = bh & ~(1u << 23);
+            bool emit = false;
+            if (field_queried(bmask, bh)) emit = F.step(hp, bq & 0xFFFFu, nph, ap0, ap1, ap2, ap3);
+#pragma unroll
+            for (int t = 0; t < MAX_PROX_TERMS; ++t)
+              if (t == best) hit_advance(spp, S.sp[t], S.sc[t]);
+            if (emit) {
+              phave = true;
+              pcur = hp - span;
+              pfield = (bh >> 24) & 31u;
+              return;
+            }
+          }
+        };
+        if (pmask) {
+          phrase_next();
+          ph_found = phave;
+          ph_field = pfield;
+        }
+        if (rank) {
+          uint64_t lcs = 0; // m_uLCS[field], one byte per field (<= 8 fields on this path)
+          uint32_t cur_lcs = 0;
+          int exp_delta = -1, last_pwf = -1;
+          // RankerState_Proximity_fn<.., false>::Update; plain keyword: weight = spanlen = 1
+          auto update = [&](uint32_t hp, uint32_t hq, uint32_t hw, uint32_t hspan) {
+            const int pwf = (int)hp;
+            const int delta = pwf - (int)hq;
+            if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + hw) & 0xffu; // BYTE arithmetic
+            const uint32_t f = hp >> 24;
+            if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu))
+              lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
+            last_pwf = pwf;
+            exp_delta = delta + (int)hspan;
+          };
+          const uint32_t dmask = smask & ~pmask; // keywords whose hits reach the ranker as they are
+          // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
+          // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
+          int phase = (multi_and && !pmask && nterms == 3 && (S.sm[0] & S.sm[1] & S.sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
+          for (;;) {
+            if (phase == 0 && !(S.sc[0] && S.sc[1] && S.sc[2])) {
+              if (!S.sc[0])
+                tl = 1, tr = 2;
+              else if (!S.sc[1])
+                tl = 0, tr = 2;
+              else
+                tl = 0, tr = 1;
+              phase = 1;
+            }
+            if (phase == 1) {
+              const uint32_t cl = tl == 0 ? S.sc[0] : S.sc[1], cr = tr == 1 ? S.sc[1] : S.sc[2];
+              if (!(cl && cr)) phase = 2;
+            }
+            int best = -1;
+            uint32_t bh = 0, bq = 0, bmask = 0;
+#pragma unroll
+            for (int t = 0; t < MAX_PROX_TERMS; ++t)
+              if (((dmask >> t) & 1u) && S.sc[t] && (best < 0 || S.sc[t] < bh || (S.sc[t] == bh && S.sq[t] < bq)))
+                best = t, bh = S.sc[t], bq = S.sq[t], bmask = S.sm[t];
+            if (phave && (best < 0 || pcur < bh || (pcur == bh && (ap0 & 0xFFFFu) < (bq & 0xFFFFu)))) {
+              update(pcur, ap0 & 0xFFFFu, nph, span);
+              phrase_next();
+              continue;
+            }
+            if (best < 0) break;
+            if (phase == 1) bmask = best == tl ? S.sm[0] : S.sm[1];
+            // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
+            if (field_queried(bmask, bh)) update(bh & ~(1u << 23), bq & 0xFFFFu, 1u, 0u);
+#pragma unroll
+            for (int t = 0; t < MAX_PROX_TERMS; ++t)
+              if (t == best) hit_advance(spp, S.sp[t], S.sc[t]);
+          }
+          int rk = 0;
+          for (uint32_t f = 0; f < nw; ++f) rk += (int)((lcs >> (8 * f)) & 0xffu) * Q->weights[f];
+          rk_out = rk;
+        }
+        if (F.over) atomicOr(a.q_flags + oq, QF_OVERFLOW);
+      };
+
+      // ---- a PHRASE below other operators: whether it occurs has to be known before the tree is evaluated
+      bool ph_ok[2] = {false, false};
+      uint32_t ph_fld[2] = {0u, 0u};
+      if (TREE && PROX && ph_leaf && __ballot(live[0] || live[1])) {
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          if (live[r] && (pres[r] & ph_mask) == ph_mask) {
+            int unused = 0;
+            hit_pass(r, ph_mask, ph_mask, false, ph_ok[r], ph_fld[r], unused);
+          }
+      }
+
       // ---- boolean tree: post-order program over the keywords' presence bits.  Value rules restate
       // ExtAnd_c / ExtOr_c / ExtMaybe_c / ExtAndNot_c (searchnode.cpp:2585-2594, 3494-3540, 3587-3600,
       // 3650-3680): tfidf adds left + right where both sides hold the doc, fields OR together.
@@ -602,6 +804,17 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
               s0.v[r] = m ? v : 0.0f;
               s0.f[r] = m ? f : 0u;
               s0.a[r] = m ? 1u << kw : 0u;
+            }
+          } else if (op == PN_PHRASEFIX) {
+            // ExtNWay_T<FSMphrase_c> over the AND chain of its words just evaluated: the doc stays only if the
+            // words line up; its field mask is the field of the first occurrence (searchnode.cpp:3806-3848)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const bool m = s0.m[r] && ph_ok[r];
+              s0.m[r] = m;
+              s0.v[r] = m ? s0.v[r] : 0.0f;
+              s0.f[r] = m ? 1u << ph_fld[r] : 0u;
+              s0.a[r] = m ? s0.a[r] : 0u;
             }
           } else {
             TreeEnt o;
@@ -642,152 +855,25 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         for (int r = 0; r < 2; ++r)
           if (live[r] && row_is_dead(a.seg, row[r])) live[r] = false;
       }
-      // ---- proximity rankers: per matched doc merge the keywords' hit streams by (hitpos, qpos)
-      // (MergeHits2/3/N, searchnode.cpp:3047-3181) and run RankerState_Proximity_fn (sphinxsearch.cpp:1351-1437)
+      // ---- hit rankers / PHRASE: per matched doc merge the keywords' hit streams by (hitpos, qpos)
+      // (MergeHits2/3/N, searchnode.cpp:3047-3181; ExtAnd_c / ExtOr_c::CollectHits) and run
+      // RankerState_Proximity_fn (sphinxsearch.cpp:1351-1437).  The words of a PHRASE go through FSMphrase_c first:
+      // to the ranker the phrase is one more stream, of folded hits.
       int prank[2] = {0, 0};
       if (PROX && (prox_ranker || phrase)) {
         wave_lds_fence();
-        const uint8_t* __restrict__ spp = a.seg.spp;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           if (live[r]) {
-            uint64_t sp[MAX_PROX_TERMS];
-            uint32_t sc[MAX_PROX_TERMS], sq[MAX_PROX_TERMS], sm[MAX_PROX_TERMS];
-#pragma unroll
-            for (int t = 0; t < MAX_PROX_TERMS; ++t) {
-              sp[t] = 0, sc[t] = 0, sq[t] = 0, sm[t] = 0;
-              if ((uint32_t)t < nterms && (!TREE || ((act[r] >> t) & 1u))) {
-                const DevTerm& Tt = Q->t[t];
-                uint32_t gblk, idx;
-                bool lone;
-                if (t == 0) {
-                  gblk = T0.blk_first + b;
-                  idx = lane + 64 * r;
-                  lone = inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u;
-                } else {
-                  const uint32_t h = L.href[t - 1][lane + 64 * r];
-                  gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu);
-                  idx = h & 127u;
-                  lone = (h >> 31) != 0;
-                }
-                sq[t] = Tt.qpos;
-                sm[t] = Tt.queried32;
-                const uint32_t hv = a.seg.pk_hit[(uint64_t)gblk * DEVBLK + idx];
-                if (lone) // the hit travelled in the doclist entry (SeekHitlist state 1, sphinx.cpp:461-464)
-                  sc[t] = hv;
-                else {
-                  sp[t] = a.seg.pk_hbase[gblk] + hv;
-                  hit_advance(spp, sp[t], sc[t]);
-                }
-              }
-            }
-            uint64_t lcs = 0; // m_uLCS[field], one byte per field (<= 8 fields on this path)
-            uint32_t cur_lcs = 0;
-            int exp_delta = -1, last_pwf = -1;
-            // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
-            // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
-            int phase = (multi_and && nterms == 3 && (sm[0] & sm[1] & sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
-            // FSMphrase_c states (searchnode.cpp:3901-3947): expected hit position per live state, 2-bit word index
-            uint32_t fexp[PHRASE_STATES], ftag = 0, fvalid = 0, ffield = 0;
-#pragma unroll
-            for (int i = 0; i < PHRASE_STATES; ++i) fexp[i] = 0;
-            bool fmatched = false, fover = false;
-            const uint32_t span = (nterms == 2 ? ap1 : nterms == 3 ? ap2 : ap3) - ap0;
-            for (;;) {
-              if (phase == 0 && !(sc[0] && sc[1] && sc[2])) {
-                if (!sc[0])
-                  tl = 1, tr = 2;
-                else if (!sc[1])
-                  tl = 0, tr = 2;
-                else
-                  tl = 0, tr = 1;
-                phase = 1;
-              }
-              if (phase == 1) {
-                const uint32_t cl = tl == 0 ? sc[0] : sc[1], cr = tr == 1 ? sc[1] : sc[2];
-                if (!(cl && cr)) phase = 2;
-              }
-              int best = -1;
-              uint32_t bh = 0, bq = 0, bmask = 0;
-#pragma unroll
-              for (int t = 0; t < MAX_PROX_TERMS; ++t) // a phrase's top ExtAnd_c orders equal positions by DESCENDING qpos
-                if (sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && (phrase ? sq[t] > bq : sq[t] < bq))))
-                  best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
-              if (best < 0) break;
-              if (phase == 1) bmask = best == tl ? sm[0] : sm[1];
-              // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
-              if (field_queried(bmask, bh)) {
-                uint32_t hp = bh & ~(1u << 23), hq = bq & 0xFFFFu, hw = 1u, hspan = 0u; // what the ranker sees
-                bool emit = true;
-                if (phrase) {
-                  // HitFSM: a first-word hit opens a state; states whose expected position was passed die;
-                  // a state that reads its last word folds the occurrence into one hit and resets the FSM
-                  emit = false;
-                  if (hq == (ap0 & 0xFFFFu)) {
-                    const uint32_t freeb = ~fvalid & ((1u << PHRASE_STATES) - 1u);
-                    if (!freeb)
-                      fover = true;
-                    else {
-                      const uint32_t idx = (uint32_t)__builtin_ctz(freeb);
-#pragma unroll
-                      for (int i = 0; i < PHRASE_STATES; ++i)
-                        if ((uint32_t)i == idx) fexp[i] = hp + (ap1 - ap0);
-                      ftag &= ~(3u << (2 * idx));
-                      fvalid |= 1u << idx;
-                    }
-                  }
-#pragma unroll
-                  for (int i = 0; i < PHRASE_STATES; ++i) {
-                    if (!emit && ((fvalid >> i) & 1u)) {
-                      if (fexp[i] < hp)
-                        fvalid &= ~(1u << i);
-                      else {
-                        uint32_t tg = (ftag >> (2 * i)) & 3u;
-                        const uint32_t nextq = tg == 0 ? ap1 : tg == 1 ? ap2 : ap3;
-                        if (fexp[i] == hp && tg + 1 < nterms && (nextq & 0xFFFFu) == hq) {
-                          ++tg;
-                          const uint32_t cq = tg == 1 ? ap1 : tg == 2 ? ap2 : ap3, nq = tg == 1 ? ap2 : ap3;
-                          fexp[i] = tg + 1 < nterms ? hp + (nq - cq) : hp - 0x7FFFFFFFu; // FSMphrase_c: -INT_MAX past the last word
-                          ftag = (ftag & ~(3u << (2 * i))) | (tg << (2 * i));
-                        }
-                        if (tg == nterms - 1) emit = true;
-                      }
-                    }
-                  }
-                  if (emit) {
-                    fvalid = 0; // ResetFSM
-                    if (!fmatched) ffield = (bh >> 24) & 31u; // the doc's field mask comes from its first occurrence (:3836)
-                    fmatched = true;
-                    hp = hp - span;
-                    hq = ap0 & 0xFFFFu;
-                    hw = nterms;
-                    hspan = span;
-                  }
-                }
-                if (emit) {
-                  // RankerState_Proximity_fn<.., false>::Update; plain keyword: weight = spanlen = 1
-                  const int pwf = (int)hp;
-                  const int delta = pwf - (int)hq;
-                  if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + hw) & 0xffu; // BYTE arithmetic
-                  const uint32_t f = hp >> 24;
-                  if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu))
-                    lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
-                  last_pwf = pwf;
-                  exp_delta = delta + (int)hspan;
-                  if (phrase && !prox_ranker) break; // one occurrence settles the match
-                }
-              }
-#pragma unroll
-              for (int t = 0; t < MAX_PROX_TERMS; ++t)
-                if (t == best) hit_advance(spp, sp[t], sc[t]);
-            }
-            int rk = 0;
-            for (uint32_t f = 0; f < nw; ++f) rk += (int)((lcs >> (8 * f)) & 0xffu) * Q->weights[f];
-            prank[r] = rk;
+            const uint32_t all_slots = (1u << (nterms < (uint32_t)MAX_PROX_TERMS ? nterms : (uint32_t)MAX_PROX_TERMS)) - 1u;
+            const uint32_t smask = TREE ? act[r] & all_slots : all_slots;
+            const uint32_t pmask = phrase ? all_slots : (ph_leaf && (smask & ph_mask) == ph_mask) ? ph_mask : 0u;
+            bool found = false;
+            uint32_t ffield = 0;
+            hit_pass(r, smask, pmask, prox_ranker, found, ffield, prank[r]);
             if (phrase) {
-              if (fover) atomicOr(a.q_flags + oq, QF_OVERFLOW); // more live states than we keep: fail the query loudly
-              live[r] = fmatched;
-              fld[r] = 1u << ffield;
+              live[r] = found;
+              fld[r] = 1u << ffield; // the doc's field mask comes from its first occurrence (searchnode.cpp:3836)
             }
           }
         }
