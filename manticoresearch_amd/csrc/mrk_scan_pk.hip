@@ -154,12 +154,6 @@ __device__ __forceinline__ bool field_queried(uint32_t qmask, uint32_t hitpos) {
   return f < 32 ? ((qmask >> f) & 1u) != 0 : qmask == 0xFFFFFFFFu;
 }
 
-// the keywords' hit streams of one doc: .spp cursor (0 = inlined hit / exhausted), current Hitpos_t (0 = exhausted)
-struct HitStreams {
-  uint64_t sp[MAX_PROX_TERMS];
-  uint32_t sc[MAX_PROX_TERMS], sq[MAX_PROX_TERMS], sm[MAX_PROX_TERMS];
-};
-
 // FSMphrase_c (searchnode.cpp:3884-3947): live states = (index of the last word read, expected position of the
 // next one).  A first-word hit opens a state; states whose expected position was passed die; a state that reads
 // its last word completes an occurrence and resets the machine.
@@ -213,6 +207,25 @@ struct PhraseFsm {
   }
 };
 
+// RankerState_Proximity_fn<.., false> (sphinxsearch.cpp:1351-1437): m_uLCS[field] as one byte per field
+// (<= 8 fields on this path), BYTE arithmetic for the running LCS
+struct ProxState {
+  uint64_t lcs;
+  uint32_t cur_lcs;
+  int exp_delta, last_pwf;
+  __device__ __forceinline__ void reset() { lcs = 0, cur_lcs = 0, exp_delta = -1, last_pwf = -1; }
+  // Update(): plain keyword hit: weight = 1, spanlen = 1 (hspan = spanlen - 1 = 0); folded phrase hit: word count, span
+  __device__ __forceinline__ void update(uint32_t hp, uint32_t hq, uint32_t hw, uint32_t hspan) {
+    const int pwf = (int)hp;
+    const int delta = pwf - (int)hq;
+    if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + hw) & 0xffu;
+    const uint32_t f = hp >> 24;
+    if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu)) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
+    last_pwf = pwf;
+    exp_delta = delta + (int)hspan;
+  }
+};
+
 // one value of the boolean-tree evaluation stack, for the two docs a lane owns
 struct TreeEnt {
   bool m[2];     // subtree matches the doc
@@ -220,6 +233,142 @@ struct TreeEnt {
   uint32_t f[2]; // its matched-fields bits
   uint32_t a[2]; // keywords whose hits it emits
 };
+
+// what one doc's hit pass needs from the kernel (plain values: no reference to the kernel's locals survives)
+struct HitCtx {
+  const DevQuery* Q;
+  const uint8_t* spp;
+  const uint32_t* hit;    // DevSegment::pk_hit
+  const uint64_t* hbase;  // DevSegment::pk_hbase
+  const uint32_t* href;   // this wave's [MAX_PROX_TERMS - 1][DEVBLK] hit references of the non-driver keywords
+  uint32_t* flags;        // the query's flag word
+  uint32_t blk0;          // global index of the driver block
+  uint32_t attr0;         // the lane's driver attr word
+  uint32_t lane, nterms, nw;
+  uint32_t ap0, ap1, ap2, ap3;
+  uint32_t nph, span;     // the query's phrase: words, distance between its first and last query position
+  bool inline_hits, multi_and;
+};
+
+// One doc's hit pass.  smask = keyword slots whose hits take part, pmask = slots forming the phrase (0 = none),
+// rank = feed RankerState_Proximity_fn (else: stop at the first phrase occurrence).
+__device__ __forceinline__ void hit_pass(const HitCtx& C, int r, uint32_t smask, uint32_t pmask, bool rank, bool& ph_found,
+                                         uint32_t& ph_field, int& rk_out) {
+  // .spp cursor (0 = inlined hit / exhausted), current Hitpos_t (0 = exhausted), query position, field limit
+  uint64_t sp[MAX_PROX_TERMS];
+  uint32_t sc[MAX_PROX_TERMS], sq[MAX_PROX_TERMS], sm[MAX_PROX_TERMS];
+#pragma unroll
+  for (int t = 0; t < MAX_PROX_TERMS; ++t) {
+    sp[t] = 0, sc[t] = 0, sq[t] = 0, sm[t] = 0;
+    if ((uint32_t)t < C.nterms && ((smask >> t) & 1u)) {
+      const DevTerm& Tt = C.Q->t[t];
+      uint32_t gblk, idx;
+      bool lone;
+      if (t == 0) {
+        gblk = C.blk0;
+        idx = C.lane + 64 * r;
+        lone = C.inline_hits && ((C.attr0 >> (8 * r)) & 0xffu) == 1u;
+      } else {
+        const uint32_t h = C.href[(t - 1) * DEVBLK + C.lane + 64 * r];
+        gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu);
+        idx = h & 127u;
+        lone = (h >> 31) != 0;
+      }
+      sq[t] = Tt.qpos;
+      sm[t] = Tt.queried32;
+      const uint32_t hv = C.hit[(uint64_t)gblk * DEVBLK + idx];
+      if (lone) // the hit travelled in the doclist entry (SeekHitlist state 1, sphinx.cpp:461-464)
+        sc[t] = hv;
+      else {
+        sp[t] = C.hbase[gblk] + hv;
+        hit_advance(C.spp, sp[t], sc[t]);
+      }
+    }
+  }
+  // the phrase as a stream of folded hits: position = first word's, weight = word count, spanlen = span + 1
+  const uint32_t nph = C.nph, span = C.span; // the query's one phrase: word count, last - first query position
+  PhraseFsm F;
+  F.reset();
+  bool phave = false, pdone = pmask == 0, first = true;
+  uint32_t pcur = 0, pfield = 0;
+  ProxState X;
+  X.reset();
+  const uint32_t dmask = smask & ~pmask; // keywords whose hits reach the ranker as they are
+  // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
+  // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
+  int phase = (C.multi_and && !pmask && C.nterms == 3 && (sm[0] & sm[1] & sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
+  for (;;) {
+    if (!pdone && !phave) { // pull the next occurrence out of the phrase's word streams
+      for (;;) {
+        int best = -1;
+        uint32_t bh = 0, bq = 0, bmask = 0;
+#pragma unroll
+        for (int t = 0; t < MAX_PROX_TERMS; ++t) // the phrase's top ExtAnd_c orders equal positions by DESCENDING qpos
+          if (((pmask >> t) & 1u) && sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && sq[t] > bq)))
+            best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
+        if (best < 0) {
+          pdone = true;
+          break;
+        }
+        const uint32_t hp = bh & ~(1u << 23);
+        bool emit = false;
+        if (field_queried(bmask, bh)) emit = F.step(hp, bq & 0xFFFFu, nph, C.ap0, C.ap1, C.ap2, C.ap3);
+#pragma unroll
+        for (int t = 0; t < MAX_PROX_TERMS; ++t)
+          if (t == best) hit_advance(C.spp, sp[t], sc[t]);
+        if (emit) {
+          phave = true;
+          pcur = hp - span;
+          pfield = (bh >> 24) & 31u;
+          break;
+        }
+      }
+      if (first) {
+        ph_found = phave;
+        ph_field = pfield;
+        first = false;
+      }
+    }
+    if (!rank) break;
+    if (phase == 0 && !(sc[0] && sc[1] && sc[2])) {
+      if (!sc[0])
+        tl = 1, tr = 2;
+      else if (!sc[1])
+        tl = 0, tr = 2;
+      else
+        tl = 0, tr = 1;
+      phase = 1;
+    }
+    if (phase == 1) {
+      const uint32_t cl = tl == 0 ? sc[0] : sc[1], cr = tr == 1 ? sc[1] : sc[2];
+      if (!(cl && cr)) phase = 2;
+    }
+    int best = -1;
+    uint32_t bh = 0, bq = 0, bmask = 0;
+#pragma unroll
+    for (int t = 0; t < MAX_PROX_TERMS; ++t)
+      if (((dmask >> t) & 1u) && sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && sq[t] < bq)))
+        best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
+    if (phave && (best < 0 || pcur < bh || (pcur == bh && (C.ap0 & 0xFFFFu) < (bq & 0xFFFFu)))) {
+      X.update(pcur, C.ap0 & 0xFFFFu, nph, span);
+      phave = false;
+      continue;
+    }
+    if (best < 0) break;
+    if (phase == 1) bmask = best == tl ? sm[0] : sm[1];
+    // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
+    if (field_queried(bmask, bh)) X.update(bh & ~(1u << 23), bq & 0xFFFFu, 1u, 0u);
+#pragma unroll
+    for (int t = 0; t < MAX_PROX_TERMS; ++t)
+      if (t == best) hit_advance(C.spp, sp[t], sc[t]);
+  }
+  if (rank) {
+    int rk = 0;
+    for (uint32_t f = 0; f < C.nw; ++f) rk += (int)((X.lcs >> (8 * f)) & 0xffu) * C.Q->weights[f];
+    rk_out = rk;
+  }
+  if (F.over) atomicOr(C.flags, QF_OVERFLOW);
+}
 
 template <bool PROX, bool TREE>
 __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
@@ -243,6 +392,8 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const bool phrase = PROX && (Q->tree_flags & TF_PHRASE) != 0;                // the whole query is one PHRASE
   const bool ph_leaf = TREE && PROX && (Q->tree_flags & TF_PHRASE_LEAF) != 0; // a PHRASE below other operators
   const uint32_t ph_mask = ph_leaf ? Q->ph_mask : 0u;                         // its words' keyword slots
+  const uint32_t ph_n = !PROX ? 0u : phrase ? nterms : (uint32_t)__popc(ph_mask);
+  const uint32_t ph_span = !PROX || ph_n < 2 ? 0u : Q->ph_atoms[ph_n - 1] - Q->ph_atoms[0];
   const bool multi_and = (!TREE || (Q->tree_flags & TF_MULTIAND) != 0) && !phrase;
   // PHRASE: query positions of its words in phrase order (FSMphrase_c::m_dAtomPos, searchnode.cpp:3884-3899)
   const uint32_t ap0 = PROX ? Q->ph_atoms[0] : 0u, ap1 = PROX ? Q->ph_atoms[1] : 0u, ap2 = PROX ? Q->ph_atoms[2] : 0u,
@@ -644,131 +795,20 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
 
       // ---- one doc's hit pass.  smask = keyword slots whose hits take part, pmask = slots forming the phrase
       // (0 = none), rank = feed RankerState_Proximity_fn (else: stop at the first phrase occurrence).
-      auto hit_pass = [&](int r, uint32_t smask, uint32_t pmask, bool rank, bool& ph_found, uint32_t& ph_field, int& rk_out) {
-        const uint8_t* __restrict__ spp = a.seg.spp;
-        HitStreams S;
-#pragma unroll
-        for (int t = 0; t < MAX_PROX_TERMS; ++t) {
-          S.sp[t] = 0, S.sc[t] = 0, S.sq[t] = 0, S.sm[t] = 0;
-          if ((uint32_t)t < nterms && ((smask >> t) & 1u)) {
-            const DevTerm& Tt = Q->t[t];
-            uint32_t gblk, idx;
-            bool lone;
-            if (t == 0) {
-              gblk = T0.blk_first + b;
-              idx = lane + 64 * r;
-              lone = inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u;
-            } else {
-              const uint32_t h = L.href[t - 1][lane + 64 * r];
-              gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu);
-              idx = h & 127u;
-              lone = (h >> 31) != 0;
-            }
-            S.sq[t] = Tt.qpos;
-            S.sm[t] = Tt.queried32;
-            const uint32_t hv = a.seg.pk_hit[(uint64_t)gblk * DEVBLK + idx];
-            if (lone) // the hit travelled in the doclist entry (SeekHitlist state 1, sphinx.cpp:461-464)
-              S.sc[t] = hv;
-            else {
-              S.sp[t] = a.seg.pk_hbase[gblk] + hv;
-              hit_advance(spp, S.sp[t], S.sc[t]);
-            }
-          }
-        }
-        // the phrase as a stream of folded hits: position = first word's, weight = word count, spanlen = span + 1
-        const uint32_t nph = (uint32_t)__popc(pmask);
-        const uint32_t span = (nph == 2 ? ap1 : nph == 3 ? ap2 : ap3) - ap0;
-        PhraseFsm F;
-        F.reset();
-        bool phave = false;
-        uint32_t pcur = 0, pfield = 0;
-        auto phrase_next = [&]() {
-          phave = false;
-          for (;;) {
-            int best = -1;
-            uint32_t bh = 0, bq = 0, bmask = 0;
-#pragma unroll
-            for (int t = 0; t < MAX_PROX_TERMS; ++t) // the phrase's top ExtAnd_c orders equal positions by DESCENDING qpos
-              if (((pmask >> t) & 1u) && S.sc[t] && (best < 0 || S.sc[t] < bh || (S.sc[t] == bh && S.sq[t] > bq)))
-                best = t, bh = S.sc[t], bq = S.sq[t], bmask = S.sm[t];
-            if (best < 0) return;
-            const uint32_t hp = bh & ~(1u << 23);
-            bool emit = false;
-            if (field_queried(bmask, bh)) emit = F.step(hp, bq & 0xFFFFu, nph, ap0, ap1, ap2, ap3);
-#pragma unroll
-            for (int t = 0; t < MAX_PROX_TERMS; ++t)
-              if (t == best) hit_advance(spp, S.sp[t], S.sc[t]);
-            if (emit) {
-              phave = true;
-              pcur = hp - span;
-              pfield = (bh >> 24) & 31u;
-              return;
-            }
-          }
-        };
-        if (pmask) {
-          phrase_next();
-          ph_found = phave;
-          ph_field = pfield;
-        }
-        if (rank) {
-          uint64_t lcs = 0; // m_uLCS[field], one byte per field (<= 8 fields on this path)
-          uint32_t cur_lcs = 0;
-          int exp_delta = -1, last_pwf = -1;
-          // RankerState_Proximity_fn<.., false>::Update; plain keyword: weight = spanlen = 1
-          auto update = [&](uint32_t hp, uint32_t hq, uint32_t hw, uint32_t hspan) {
-            const int pwf = (int)hp;
-            const int delta = pwf - (int)hq;
-            if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + hw) & 0xffu; // BYTE arithmetic
-            const uint32_t f = hp >> 24;
-            if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu))
-              lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
-            last_pwf = pwf;
-            exp_delta = delta + (int)hspan;
-          };
-          const uint32_t dmask = smask & ~pmask; // keywords whose hits reach the ranker as they are
-          // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
-          // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
-          int phase = (multi_and && !pmask && nterms == 3 && (S.sm[0] & S.sm[1] & S.sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
-          for (;;) {
-            if (phase == 0 && !(S.sc[0] && S.sc[1] && S.sc[2])) {
-              if (!S.sc[0])
-                tl = 1, tr = 2;
-              else if (!S.sc[1])
-                tl = 0, tr = 2;
-              else
-                tl = 0, tr = 1;
-              phase = 1;
-            }
-            if (phase == 1) {
-              const uint32_t cl = tl == 0 ? S.sc[0] : S.sc[1], cr = tr == 1 ? S.sc[1] : S.sc[2];
-              if (!(cl && cr)) phase = 2;
-            }
-            int best = -1;
-            uint32_t bh = 0, bq = 0, bmask = 0;
-#pragma unroll
-            for (int t = 0; t < MAX_PROX_TERMS; ++t)
-              if (((dmask >> t) & 1u) && S.sc[t] && (best < 0 || S.sc[t] < bh || (S.sc[t] == bh && S.sq[t] < bq)))
-                best = t, bh = S.sc[t], bq = S.sq[t], bmask = S.sm[t];
-            if (phave && (best < 0 || pcur < bh || (pcur == bh && (ap0 & 0xFFFFu) < (bq & 0xFFFFu)))) {
-              update(pcur, ap0 & 0xFFFFu, nph, span);
-              phrase_next();
-              continue;
-            }
-            if (best < 0) break;
-            if (phase == 1) bmask = best == tl ? S.sm[0] : S.sm[1];
-            // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
-            if (field_queried(bmask, bh)) update(bh & ~(1u << 23), bq & 0xFFFFu, 1u, 0u);
-#pragma unroll
-            for (int t = 0; t < MAX_PROX_TERMS; ++t)
-              if (t == best) hit_advance(spp, S.sp[t], S.sc[t]);
-          }
-          int rk = 0;
-          for (uint32_t f = 0; f < nw; ++f) rk += (int)((lcs >> (8 * f)) & 0xffu) * Q->weights[f];
-          rk_out = rk;
-        }
-        if (F.over) atomicOr(a.q_flags + oq, QF_OVERFLOW);
-      };
+      // ---- hit pass context (values only; see hit_pass)
+      HitCtx C;
+      C.Q = Q;
+      C.spp = a.seg.spp;
+      C.hit = a.seg.pk_hit;
+      C.hbase = a.seg.pk_hbase;
+      C.href = &L.href[0][0];
+      C.flags = a.q_flags + oq;
+      C.blk0 = T0.blk_first + b;
+      C.attr0 = cur0.attr;
+      C.lane = lane, C.nterms = nterms, C.nw = nw;
+      C.ap0 = ap0, C.ap1 = ap1, C.ap2 = ap2, C.ap3 = ap3;
+      C.nph = ph_n, C.span = ph_span;
+      C.inline_hits = inline_hits, C.multi_and = multi_and;
 
       // ---- a PHRASE below other operators: whether it occurs has to be known before the tree is evaluated
       bool ph_ok[2] = {false, false};
@@ -779,7 +819,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         for (int r = 0; r < 2; ++r)
           if (live[r] && (pres[r] & ph_mask) == ph_mask) {
             int unused = 0;
-            hit_pass(r, ph_mask, ph_mask, false, ph_ok[r], ph_fld[r], unused);
+            hit_pass(C, r, ph_mask, ph_mask, false, ph_ok[r], ph_fld[r], unused);
           }
       }
 
@@ -870,7 +910,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
             const uint32_t pmask = phrase ? all_slots : (ph_leaf && (smask & ph_mask) == ph_mask) ? ph_mask : 0u;
             bool found = false;
             uint32_t ffield = 0;
-            hit_pass(r, smask, pmask, prox_ranker, found, ffield, prank[r]);
+            hit_pass(C, r, smask, pmask, prox_ranker, found, ffield, prank[r]);
             if (phrase) {
               live[r] = found;
               fld[r] = 1u << ffield; // the doc's field mask comes from its first occurrence (searchnode.cpp:3836)
