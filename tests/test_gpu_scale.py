@@ -101,3 +101,28 @@ def test_three_term_mixes_proximity_bm25(orc, corpus):
         assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
         n_ok += 1
     assert n_ok >= 30
+
+
+def test_phrase_mix_with_field_weights(orc, corpus):
+    """BASELINE config 5 shapes: PHRASE (alone, with another keyword, in an OR) + field weights, default ranker."""
+    from test_gpu_parity import PHRASE
+    m, hi = corpus
+    rng = np.random.default_rng(7)
+    qs = []
+    for _ in range(12):
+        a, b, c, d = (int(x) for x in rng.choice(np.arange(0, 8), 4, replace=False))
+        ph = PHRASE(m, kw(m, a, 1), kw(m, b, 2))
+        fw = [int(x) for x in rng.integers(1, 12, 3)]
+        for root in (ph, m.XQNode.AND(ph, kw(m, c, 3)), OR(m, ph, kw(m, d, 3))):
+            qs.append(m.Query(root, ranker=m.SPH_RANK_PROXIMITY_BM25, max_matches=1000, field_weights=fw))
+    got, _ = run_path(m, hi, qs, 0, 64)
+    oi = orc_index_of(orc, hi)
+    n_found = 0
+    for q, g in zip(qs, got):
+        assert g.status == 0
+        check_order(g)
+        want = to_orc(orc, q).run(oi)
+        assert g.total_found == want.total_found
+        assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+        n_found += g.total_found
+    assert n_found > 1000  # the corpus is dense enough (positions 1..64) for phrases to occur
