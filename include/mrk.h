@@ -57,7 +57,10 @@ enum {
   MRK_RANK_BM25 = 1,
   MRK_RANK_NONE = 2,
   MRK_RANK_WORDCOUNT = 3,
-  MRK_RANK_PROXIMITY = 4
+  MRK_RANK_PROXIMITY = 4,
+  MRK_RANK_MATCHANY = 5,
+  MRK_RANK_FIELDMASK = 6,
+  MRK_RANK_SPH04 = 7
 };
 
 /* XQOperator_e subset (sphinxquery.h) */

@@ -784,7 +784,8 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   }
 
   uint32_t ranker;
-  bool prox = false;
+  bool prox = false;       // a state ranker reads the hit streams
+  bool state_only = false; // ... one without a HANDLE_DUPES variant (duplicate keywords are fine)
   if (T.ph_leaf && n > MAX_PROX_TERMS)
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE in a tree of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
   if (T.phrase || T.ph_leaf) {
@@ -812,6 +813,21 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
         prox = true;
       }
       break;
+    case MRK_RANK_WORDCOUNT:
+    case MRK_RANK_MATCHANY:
+    case MRK_RANK_FIELDMASK:
+    case MRK_RANK_SPH04:
+      // always ExtRanker_State_T over the hit stream, single keyword or not (sphinxsearch.cpp:4214-4236)
+      if (!use_packed || !seg->dev.pk_hit)
+        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit rankers run on the packed path only", qi);
+      if (n > MAX_PROX_TERMS)
+        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit ranker over %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+      if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+      if (T.multiand3_inner) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: 3-keyword AND below another operator with a hit ranker", qi);
+      ranker = (uint32_t)q.ranker;
+      prox = true;
+      state_only = true;
+      break;
     default: return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker %d not on the device path", qi, q.ranker);
   }
 
@@ -823,7 +839,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
     T.kws[i].weighted_first = !seen;
     if (!seen) words.push_back(i);
   }
-  if (prox && (int)words.size() != n)
+  if (prox && !state_only && (int)words.size() != n)
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: duplicate keywords need RankerState_Proximity_fn<HANDLE_DUPES>, not on the device path", qi);
   const int64_t total_docs = q.total_docs_override > 0 ? q.total_docs_override : (int64_t)seg->total_docs;
   for (int w : words) {
@@ -834,6 +850,9 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   }
 
   dq.ranker = ranker;
+  dq.n_qwords = (uint32_t)words.size(); // ExtRanker_c::m_iQwords (sphinxsearch.cpp:730-731)
+  dq.max_qpos = 0;                      // ... m_iMaxQpos = GetQwords() (:4294-4296, 4372)
+  for (const PlanKw& k : T.kws) dq.max_qpos = std::max<uint32_t>(dq.max_qpos, (uint32_t)std::max(k.atom_pos, 0));
   dq.k = (uint32_t)q.max_matches;
   dq.n_weights = seg->n_fields;
   dq.index_weight = (uint32_t)(q.index_weight ? q.index_weight : 1);
@@ -898,12 +917,24 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
     if (prox) {
       // sum_f LCS[f] * w[f] with 0 <= LCS[f] <= number of keywords (hit weight 1, unique keywords)
       // (a phrase occurrence weighs its word count; back-to-back occurrences can add up -- beyond 2n the bins clamp)
+      // The other state rankers: SPH04 4*LCS + 2 + 1 per field; WORDCOUNT one field weight per hit (unbounded:
+      // 32 hits per keyword span the bins, more clamp); MATCHANY bits + (LCS-1) * K, K = sum(w) * words;
+      // FIELDMASK the mask itself.  Bounds only shape the pruning bins -- values outside clamp to the edge bins.
       rmin = rmax = 0;
-      const int64_t top = (T.phrase || T.ph_leaf) ? 2 * n : n;
-      for (uint32_t f = 0; f < nwf; ++f) {
-        rmin += std::min<int64_t>(0, top * dq.weights[f]);
-        rmax += std::max<int64_t>(0, top * dq.weights[f]);
+      int64_t top = (T.phrase || T.ph_leaf) ? 2 * n : n;
+      if (ranker == MRK_RANK_SPH04) top = 4 * top + 3;
+      if (ranker == MRK_RANK_WORDCOUNT) top = 32 * n;
+      if (ranker == MRK_RANK_MATCHANY) {
+        int64_t k = 0;
+        for (uint32_t f = 0; f < nwf; ++f) k += dq.weights[f];
+        top = n + top * std::llabs(k * (int64_t)words.size());
       }
+      for (uint32_t f = 0; f < nwf; ++f) {
+        const int64_t v = top * dq.weights[f];
+        rmin += ranker == MRK_RANK_MATCHANY ? -std::llabs(v) : std::min<int64_t>(0, v);
+        rmax += ranker == MRK_RANK_MATCHANY ? std::llabs(v) : std::max<int64_t>(0, v);
+      }
+      if (ranker == MRK_RANK_FIELDMASK) rmin = 0, rmax = (1ll << nwf) - 1;
     } else
       for (uint32_t m = 0; m < 256; ++m) {
         int64_t r = 0;
@@ -915,7 +946,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
         rmin = std::min(rmin, r);
         rmax = std::max(rmax, r);
       }
-    const bool with_bm = ranker != MRK_RANK_PROXIMITY;
+    const bool with_bm = ranker == MRK_RANK_BM25 || ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_SPH04;
     const int64_t iw = (int32_t)dq.index_weight;
     const int64_t sc = with_bm ? 1000 : 1, b0 = with_bm ? bm_lo : 0, b1 = with_bm ? bm_hi : 0;
     const int64_t c[4] = {(b0 + rmin * sc) * iw, (b0 + rmax * sc) * iw, (b1 + rmin * sc) * iw, (b1 + rmax * sc) * iw};

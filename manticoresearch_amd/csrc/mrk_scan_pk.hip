@@ -207,22 +207,79 @@ struct PhraseFsm {
   }
 };
 
-// RankerState_Proximity_fn<.., false> (sphinxsearch.cpp:1351-1437): m_uLCS[field] as one byte per field
-// (<= 8 fields on this path), BYTE arithmetic for the running LCS
-struct ProxState {
-  uint64_t lcs;
-  uint32_t cur_lcs;
-  int exp_delta, last_pwf;
-  __device__ __forceinline__ void reset() { lcs = 0, cur_lcs = 0, exp_delta = -1, last_pwf = -1; }
-  // Update(): plain keyword hit: weight = 1, spanlen = 1 (hspan = spanlen - 1 = 0); folded phrase hit: word count, span
-  __device__ __forceinline__ void update(uint32_t hp, uint32_t hq, uint32_t hw, uint32_t hspan) {
+// The state rankers (ExtRanker_State_T<STATE>, sphinxsearch.cpp:1198-1315), one doc at a time.  All of them see the
+// same hit stream; `ranker` picks the Update / Finalize pair:
+//   PROXIMITY_BM25 / PROXIMITY  RankerState_Proximity_fn<.., false>      :1351-1437  LCS per field (BYTE arithmetic)
+//   SPH04                       RankerState_ProximityBM25Exact_fn        :1443-1530  LCS + head hit + exact hit
+//   MATCHANY                    RankerState_MatchAny_fn                  :1577-1616  LCS + matched query positions per field
+//   WORDCOUNT                   RankerState_Wordcount_fn                 :1620-1643  field weight per hit
+//   FIELDMASK                   RankerState_Fieldmask_fn                 :1647-1668  fields that hold a hit
+// m_uLCS[field] / m_uMatchMask[field] are one byte per field in a u64 (<= 8 fields on this path).
+// A doc starts from the post-Finalize state; SPH04's m_uMinExpPos survives Finalize in the reference, which cannot
+// change a doc's first hit (it either fails the delta test or both branches agree), so every doc starts it afresh.
+struct RankState {
+  uint64_t lcs, mmask;
+  uint32_t cur_lcs, min_exp_pos, head, exact, fmask;
+  int exp_delta, last_pwf, wc;
+  bool first;
+  __device__ __forceinline__ void reset() {
+    lcs = 0, mmask = 0, cur_lcs = 0, min_exp_pos = 0, head = 0, exact = 0, fmask = 0;
+    exp_delta = -1, last_pwf = -1, wc = 0, first = true;
+  }
+  // one hit: hp = position with field (no end bit), is_end = its end-of-field marker, hq = query position,
+  // hw = weight (1; word count for a folded phrase hit), hspan = spanlen - 1; w_of = field weight table
+  __device__ __forceinline__ void update(uint32_t ranker, uint32_t hp, bool is_end, uint32_t hq, uint32_t hw, uint32_t hspan,
+                                         const uint32_t* w_of, int max_qpos) {
+    const uint32_t f = hp >> 24;
     const int pwf = (int)hp;
     const int delta = pwf - (int)hq;
-    if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + hw) & 0xffu;
-    const uint32_t f = hp >> 24;
+    if (ranker == MRK_RANK_WORDCOUNT) {
+      wc += f < 8 ? (int)w_of[1u << f] : 0;
+      return;
+    }
+    if (ranker == MRK_RANK_FIELDMASK) {
+      fmask |= 1u << (f & 31u);
+      return;
+    }
+    if (ranker == MRK_RANK_SPH04) {
+      const int pos = (int)(hp & 0x7FFFFFu);
+      if (!first && delta == exp_delta && hp >= min_exp_pos) {
+        if (pwf > last_pwf) cur_lcs = (cur_lcs + hw) & 0xffu;
+        if (is_end && (int)hq == max_qpos && pos == max_qpos) exact |= 1u << (f & 31u);
+      } else {
+        if (pwf > last_pwf) cur_lcs = hw & 0xffu;
+        if (pos == 1) {
+          head |= 1u << (f & 31u);
+          if (is_end && max_qpos == 1) exact |= 1u << (f & 31u);
+        }
+      }
+      min_exp_pos = hp + 1u;
+      first = false;
+    } else { // the proximity family
+      if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + hw) & 0xffu;
+      if (ranker == MRK_RANK_MATCHANY && f < 8) mmask |= (uint64_t)((1u << ((hq - 1u) & 31u)) & 0xffu) << (8 * f);
+    }
     if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu)) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
     last_pwf = pwf;
     exp_delta = delta + (int)hspan;
+  }
+  __device__ __forceinline__ int finalize(uint32_t ranker, uint32_t nw, const int32_t* weights, const uint32_t* w_of, int n_qwords) const {
+    if (ranker == MRK_RANK_WORDCOUNT) return wc;
+    if (ranker == MRK_RANK_FIELDMASK) return (int)fmask;
+    int rk = 0;
+    if (ranker == MRK_RANK_MATCHANY) {
+      const int phrase_k = (int)w_of[(1u << nw) - 1u] * n_qwords; // sum of the field weights x query words
+      for (uint32_t f = 0; f < nw; ++f) {
+        const uint32_t mm = (uint32_t)(mmask >> (8 * f)) & 0xffu;
+        if (mm) rk += (int)(__popc(mm) + ((int)((lcs >> (8 * f)) & 0xffu) - 1) * phrase_k) * weights[f];
+      }
+      return rk;
+    }
+    for (uint32_t f = 0; f < nw; ++f) {
+      const int l = (int)((lcs >> (8 * f)) & 0xffu);
+      rk += (ranker == MRK_RANK_SPH04 ? 4 * l + 2 * (int)((head >> f) & 1u) + (int)((exact >> f) & 1u) : l) * weights[f];
+    }
+    return rk;
   }
 };
 
@@ -247,6 +304,9 @@ struct HitCtx {
   uint32_t lane, nterms, nw;
   uint32_t ap0, ap1, ap2, ap3;
   uint32_t nph, span;     // the query's phrase: words, distance between its first and last query position
+  uint32_t ranker;        // MRK_RANK_* of the state ranker fed by the pass
+  const uint32_t* w_of;   // LDS table: field-weight sum per field mask (w_of[1 << f] = weight of field f)
+  int max_qpos, n_qwords; // ExtRanker_c::m_iMaxQpos / m_iQwords
   bool inline_hits, multi_and;
 };
 
@@ -291,7 +351,7 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, int r, uint32_t smask,
   F.reset();
   bool phave = false, pdone = pmask == 0, first = true;
   uint32_t pcur = 0, pfield = 0;
-  ProxState X;
+  RankState X;
   X.reset();
   const uint32_t dmask = smask & ~pmask; // keywords whose hits reach the ranker as they are
   // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
@@ -350,23 +410,19 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, int r, uint32_t smask,
       if (((dmask >> t) & 1u) && sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && sq[t] < bq)))
         best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
     if (phave && (best < 0 || pcur < bh || (pcur == bh && (C.ap0 & 0xFFFFu) < (bq & 0xFFFFu)))) {
-      X.update(pcur, C.ap0 & 0xFFFFu, nph, span);
+      X.update(C.ranker, pcur, false, C.ap0 & 0xFFFFu, nph, span, C.w_of, C.max_qpos);
       phave = false;
       continue;
     }
     if (best < 0) break;
     if (phase == 1) bmask = best == tl ? sm[0] : sm[1];
     // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
-    if (field_queried(bmask, bh)) X.update(bh & ~(1u << 23), bq & 0xFFFFu, 1u, 0u);
+    if (field_queried(bmask, bh)) X.update(C.ranker, bh & ~(1u << 23), ((bh >> 23) & 1u) != 0, bq & 0xFFFFu, 1u, 0u, C.w_of, C.max_qpos);
 #pragma unroll
     for (int t = 0; t < MAX_PROX_TERMS; ++t)
       if (t == best) hit_advance(C.spp, sp[t], sc[t]);
   }
-  if (rank) {
-    int rk = 0;
-    for (uint32_t f = 0; f < C.nw; ++f) rk += (int)((X.lcs >> (8 * f)) & 0xffu) * C.Q->weights[f];
-    rk_out = rk;
-  }
+  if (rank) rk_out = X.finalize(C.ranker, C.nw, C.Q->weights, C.w_of, C.n_qwords);
   if (F.over) atomicOr(C.flags, QF_OVERFLOW);
 }
 
@@ -384,7 +440,11 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const DevTerm T0 = Q->t[0];
   const DevTerm T1 = Q->t[nterms > 1 ? 1 : 0];
   const bool inline_hits = a.seg.inline_hits != 0;
-  const bool prox_ranker = PROX && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && nterms > 1;
+  // state rankers read hits; a single keyword under PROXIMITY_BM25 / PROXIMITY was mapped to the weight-sum rankers
+  const bool prox_ranker = PROX && ((ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY)
+                                        ? nterms > 1
+                                        : (ranker == MRK_RANK_WORDCOUNT || ranker == MRK_RANK_MATCHANY ||
+                                           ranker == MRK_RANK_FIELDMASK || ranker == MRK_RANK_SPH04));
   PkWaveLds<PROX, TREE>& L = s.w[wave];
   const uint32_t oq = Q->out_q; // logical query: several passes (driver keywords) may feed one result
   const uint32_t req_mask = TREE ? Q->req_mask : 0u, excl_mask = TREE ? Q->excl_mask : 0u;
@@ -808,6 +868,9 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       C.lane = lane, C.nterms = nterms, C.nw = nw;
       C.ap0 = ap0, C.ap1 = ap1, C.ap2 = ap2, C.ap3 = ap3;
       C.nph = ph_n, C.span = ph_span;
+      C.ranker = ranker;
+      C.w_of = s.rank;
+      C.max_qpos = (int)Q->max_qpos, C.n_qwords = (int)Q->n_qwords;
       C.inline_hits = inline_hits, C.multi_and = multi_and;
 
       // ---- a PHRASE below other operators: whether it occurs has to be known before the tree is evaluated
@@ -931,7 +994,8 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
           else if (PROX && prox_ranker) {
             // RankerState_Proximity_fn::Finalize, sphinxsearch.cpp:1415-1437
             const int32_t bm = (int32_t)((acc[r] + 0.5f) * 1000.0f);
-            weight = ranker == MRK_RANK_PROXIMITY_BM25 ? (uint32_t)bm + (uint32_t)prank[r] * 1000u : (uint32_t)prank[r];
+            weight = (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_SPH04) ? (uint32_t)bm + (uint32_t)prank[r] * 1000u
+                                                                                   : (uint32_t)prank[r];
           } else if (ranker == MRK_RANK_PROXIMITY) {
             weight = s.rank[fld[r]]; // single keyword: ExtRanker_WeightSum_c<> without BM25 (sphinxsearch.cpp:4216-4217, 1131)
           } else {

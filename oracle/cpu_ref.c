@@ -1542,6 +1542,94 @@ static inline int prox_finalize(prox_state* s, int n_fields, const int32_t* weig
   return use_bm25 ? (int)((uint32_t)bm25 + (uint32_t)rank * SPH_BM25_SCALE) : rank;
 }
 
+/* RankerState_ProximityBM25Exact_fn = SPH04 (sphinxsearch.cpp:1443-1530).  min_exp_pos is NOT reset by
+   Finalize in the reference; it is kept here the same way (it cannot change a doc's first hit: that one
+   either fails the delta test or takes the same values from both branches). */
+typedef struct {
+  uint8_t lcs[ORC_MAX_FIELDS];
+  uint8_t cur_lcs;
+  int exp_delta;
+  int last_hitpos;
+  uint32_t min_exp_pos;
+  uint32_t head_hit, exact_hit;
+  int max_qpos;
+} sph04_state;
+
+static void sph04_init(sph04_state* s, int max_qpos) {
+  memset(s, 0, sizeof *s);
+  s->exp_delta = -INT_MAX;
+  s->last_hitpos = -1;
+  s->max_qpos = max_qpos;
+}
+
+static inline void sph04_update(sph04_state* s, const hit_t* h) {
+  uint32_t field = ORC_HIT_FIELD(h->hitpos);
+  int pos_with_field = (int)ORC_HIT_POSWITHFIELD(h->hitpos);
+  int delta = pos_with_field - h->qpos;
+  const int is_end = (h->hitpos >> 23) & 1;
+  const int pos = (int)(h->hitpos & 0x7FFFFFu);
+  if (delta == s->exp_delta && ORC_HIT_POSWITHFIELD(h->hitpos) >= s->min_exp_pos) {
+    if (pos_with_field > s->last_hitpos) s->cur_lcs = (uint8_t)(s->cur_lcs + h->weight);
+    if (is_end && (int)h->qpos == s->max_qpos && pos == s->max_qpos) s->exact_hit |= 1u << field;
+  } else {
+    if (pos_with_field > s->last_hitpos) s->cur_lcs = (uint8_t)h->weight;
+    if (pos == 1) {
+      s->head_hit |= 1u << field;
+      if (is_end && s->max_qpos == 1) s->exact_hit |= 1u << field;
+    }
+  }
+  if (s->cur_lcs > s->lcs[field]) s->lcs[field] = s->cur_lcs;
+  s->exp_delta = delta + h->spanlen - 1;
+  s->last_hitpos = pos_with_field;
+  s->min_exp_pos = ORC_HIT_POSWITHFIELD(h->hitpos) + 1;
+}
+
+static inline int sph04_finalize(sph04_state* s, int n_fields, const int32_t* weights, int bm25) {
+  s->cur_lcs = 0;
+  s->exp_delta = -1;
+  s->last_hitpos = -1;
+  int rank = 0;
+  for (int i = 0; i < n_fields; i++) {
+    rank += (int)(4 * s->lcs[i] + 2 * ((s->head_hit >> i) & 1) + ((s->exact_hit >> i) & 1)) * weights[i];
+    s->lcs[i] = 0;
+  }
+  s->head_hit = 0;
+  s->exact_hit = 0;
+  return (int)((uint32_t)bm25 + (uint32_t)rank * SPH_BM25_SCALE);
+}
+
+/* RankerState_MatchAny_fn (sphinxsearch.cpp:1577-1616): proximity state + per-field mask of matched query positions */
+typedef struct {
+  prox_state p;
+  int phrase_k;
+  uint8_t match_mask[ORC_MAX_FIELDS];
+} matchany_state;
+
+static void matchany_init(matchany_state* s, int n_fields, const int32_t* weights, int n_qwords) {
+  prox_init(&s->p);
+  s->phrase_k = 0;
+  for (int i = 0; i < n_fields; i++) s->phrase_k += weights[i] * n_qwords;
+  memset(s->match_mask, 0, sizeof s->match_mask);
+}
+
+static inline void matchany_update(matchany_state* s, const hit_t* h) {
+  prox_update(&s->p, h);
+  s->match_mask[ORC_HIT_FIELD(h->hitpos)] |= (uint8_t)(1 << (h->qpos - 1)); /* BYTE: query positions past 8 fall off */
+}
+
+static inline int matchany_finalize(matchany_state* s, int n_fields, const int32_t* weights) {
+  s->p.cur_lcs = 0;
+  s->p.exp_delta = -1;
+  s->p.last_hitpos_with_field = -1;
+  int rank = 0;
+  for (int i = 0; i < n_fields; i++) {
+    if (s->match_mask[i]) rank += (int)(__builtin_popcount(s->match_mask[i]) + (s->p.lcs[i] - 1) * s->phrase_k) * weights[i];
+    s->match_mask[i] = 0;
+    s->p.lcs[i] = 0;
+  }
+  return rank;
+}
+
 /* ------------------------------------------------------------------------ */
 /* search = sphCreateRanker + MatchExtended + sorter                         */
 /* ------------------------------------------------------------------------ */
@@ -1562,6 +1650,11 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
     case ORC_RANK_BM25: use_bm25 = 1; state_ranker = 0; break;
     case ORC_RANK_NONE: use_bm25 = 0; state_ranker = 0; break;
     case ORC_RANK_PROXIMITY: use_bm25 = 0; state_ranker = !single_word; break;
+    /* always ExtRanker_State_T, single keyword or not (:4214-4236) */
+    case ORC_RANK_WORDCOUNT:
+    case ORC_RANK_MATCHANY:
+    case ORC_RANK_FIELDMASK: use_bm25 = 0; state_ranker = 1; break;
+    case ORC_RANK_SPH04: use_bm25 = 1; state_ranker = 1; break;
     default: return fail("ranker not restated in the oracle");
   }
 
@@ -1581,7 +1674,7 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
   h.n = 0;
   int dupes = 0;
   collect_qwords(root, &h, &dupes);
-  if (dupes && state_ranker) {
+  if (dupes && state_ranker && (ranker == ORC_RANK_PROXIMITY_BM25 || ranker == ORC_RANK_PROXIMITY)) {
     en_free(root);
     return fail("duplicate keywords with a proximity ranker (HANDLE_DUPES) not restated");
   }
@@ -1614,6 +1707,14 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
   hitvec hv = {0, 0, 0};
   prox_state ps;
   prox_init(&ps);
+  /* m_iMaxQpos = GetQwords() (max query position over all keywords), m_iQwords = distinct words (:4294-4296, 730-731) */
+  int max_qpos = 0;
+  for (int k = 0; k < q->n_nodes; k++)
+    if (q->nodes[k].op == ORC_OP_TERM && q->nodes[k].atom_pos > max_qpos) max_qpos = q->nodes[k].atom_pos;
+  sph04_state s4;
+  sph04_init(&s4, max_qpos);
+  matchany_state ms;
+  matchany_init(&ms, n_weights, weights, h.n);
   int cutoff = q->cutoff > 0 ? q->cutoff : -1;
   const int index_weight = q->index_weight ? q->index_weight : 1;
 
@@ -1627,8 +1728,29 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
       hv.n = 0;
       en_hits(root, &hv);
       if (!hv.n) continue;
-      for (int i = 0; i < hv.n; i++) prox_update(&ps, &hv.p[i]);
-      weight = prox_finalize(&ps, n_weights, weights, use_bm25, bm25);
+      switch (ranker) {
+        case ORC_RANK_WORDCOUNT: /* RankerState_Wordcount_fn :1620-1643 */
+          weight = 0;
+          for (int i = 0; i < hv.n; i++) weight += weights[ORC_HIT_FIELD(hv.p[i].hitpos)];
+          break;
+        case ORC_RANK_FIELDMASK: { /* RankerState_Fieldmask_fn :1647-1668 */
+          uint32_t mask = 0;
+          for (int i = 0; i < hv.n; i++) mask |= 1u << ORC_HIT_FIELD(hv.p[i].hitpos);
+          weight = (int)mask;
+          break;
+        }
+        case ORC_RANK_MATCHANY:
+          for (int i = 0; i < hv.n; i++) matchany_update(&ms, &hv.p[i]);
+          weight = matchany_finalize(&ms, n_weights, weights);
+          break;
+        case ORC_RANK_SPH04:
+          for (int i = 0; i < hv.n; i++) sph04_update(&s4, &hv.p[i]);
+          weight = sph04_finalize(&s4, n_weights, weights, bm25);
+          break;
+        default:
+          for (int i = 0; i < hv.n; i++) prox_update(&ps, &hv.p[i]);
+          weight = prox_finalize(&ps, n_weights, weights, use_bm25, bm25);
+      }
     } else if (ranker == ORC_RANK_NONE) {
       weight = 1; /* ExtRanker_None_c :1145-1169 */
     } else {

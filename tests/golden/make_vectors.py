@@ -41,6 +41,15 @@ G = {
                               ["sample program three", "something written in perl"], ["", "77 lies multiplied by 77"],
                               ["", "agent 0077"], ["", "1234567812345678"], ["aaa", "aaa"], ["aaa", ""], ["", "aaa"],
                               ["", "wordbefore\u0000\u0000wordafter"]]},
+        "test_037_test2": {"source": "test/test_037/test.xml (index test2) + model.bin", "min_word_len": 1,
+                           "ids": [11, 12, 13, 14, 15, 16],
+                           "docs": [["market street", ""], ["market street west", ""], ["north market street", ""],
+                                    ["farmers market street north", ""], ["flower street market", ""],
+                                    ["market street is so very market street", ""]]},
+        # test_114 builds its rows in a loop: 510 identical rows, then one long row (520 repetitions)
+        "test_114": {"source": "test/test_114/test.xml (custom_insert) + model.bin", "min_word_len": 1, "ids": list(range(1, 512)),
+                     "docs_spec": [{"count": 510, "fields": ["aaaa bbbb cccc dddd"]},
+                                   {"count": 1, "fields": ["aaaa bbbb x aaaa bbbb " + " x cccc dddd" * 520]}]},
         "test_322": {"source": "test/test_322/test.xml + model.bin", "min_word_len": 1, "ids": [1, 2, 3, 100],
                      "docs": [["|sample program", "|program flow direct", "|sample program flow"],
                               ["|one sample program", "|program rev flow", "|one rev flow"],
@@ -78,6 +87,21 @@ for spam, exp in [(1, [[1, 7415], [3, 6426], [2, 4421]]), (10, [[1, 25415], [3, 
                   (-10, [[3, -4574], [2, -6579], [1, -14585]])]:
     G["cases"].append({"name": f"322 program flow, field_weights 1,2,{spam}", "corpus": "test_322",
                        "query": OP("and", T("program", 1), T("flow", 2)), "ranker": "proximity_bm25",
+                       "field_weights": [1, 2, spam], "expect": exp})
+
+G["cases"] += [
+    {"name": "037 phrase wordcount", "corpus": "test_037", "query": OP("phrase", T("зимние", 1), T("шины", 2)),
+     "ranker": "wordcount", "expect": [[1, 2]], "total_found": 1},
+    {"name": "037/test2 market street sph04", "corpus": "test_037_test2", "query": OP("and", T("market", 1), T("street", 2)),
+     "ranker": "sph04", "expect": [[11, 11290], [12, 10290], [16, 10212], [13, 8290], [14, 8290], [15, 4290]]},
+    {"name": "114 \"aaaa bbbb\" wordcount", "corpus": "test_114", "query": OP("phrase", T("aaaa", 1), T("bbbb", 2)),
+     "ranker": "wordcount", "expect": [[511, 2]] + [[i, 1] for i in range(1, 20)], "limit": 20, "total_found": 511},
+    {"name": "114 \"cccc dddd\" wordcount", "corpus": "test_114", "query": OP("phrase", T("cccc", 1), T("dddd", 2)),
+     "ranker": "wordcount", "expect": [[511, 520]] + [[i, 1] for i in range(1, 20)], "limit": 20, "total_found": 511},
+]
+for spam, exp in [(10, [[1, 25], [2, 15], [3, 15]]), (0, [[1, 5], [2, 5], [3, 5]]), (-10, [[2, -5], [3, -5], [1, -15]])]:
+    G["cases"].append({"name": f"322 program flow wordcount, field_weights 1,2,{spam}", "corpus": "test_322",
+                       "query": OP("and", T("program", 1), T("flow", 2)), "ranker": "wordcount",
                        "field_weights": [1, 2, spam], "expect": exp})
 
 if __name__ == "__main__":

@@ -329,13 +329,17 @@ def test_random_corpus_proximity(orc, dev, block, fmt):
             ap += 1 if rng.random() < 0.85 else 2
             pos.append(ap)
         root = m.XQNode.AND(*[kw(m, int(t), p, mk) for t, p, mk in zip(ts, pos, masks)])
-        qs.append(m.Query(root, ranker=int(rng.choice([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY])),
+        qs.append(m.Query(root, ranker=int(rng.choice([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY, m.SPH_RANK_WORDCOUNT,
+                                                       m.SPH_RANK_MATCHANY, m.SPH_RANK_FIELDMASK, m.SPH_RANK_SPH04])),
                           max_matches=int(rng.choice([5, 100, 1000])),
                           field_weights=[int(x) for x in rng.integers(-3, 12, 3)] if rng.random() < 0.5 else None,
                           index_weight=int(rng.choice([1, 1, 2]))))
-    for t in range(len(probs)):  # single keyword: WeightSum with / without BM25
+    for t in range(len(probs)):  # single keyword: WeightSum with / without BM25; the other state rankers still read hits
         qs.append(m.Query(kw(m, t, 1), ranker=m.SPH_RANK_PROXIMITY))
         qs.append(m.Query(kw(m, t, 1), ranker=m.SPH_RANK_PROXIMITY_BM25))
+        for rk in (m.SPH_RANK_WORDCOUNT, m.SPH_RANK_MATCHANY, m.SPH_RANK_FIELDMASK, m.SPH_RANK_SPH04):
+            qs.append(m.Query(kw(m, t, 1, int(rng.choice([0xFFFFFFFF, 0b011]))), ranker=rk,
+                              field_weights=[int(x) for x in rng.integers(-3, 12, 3)]))
     check_batch(orc, dev, hi, qs)
 
 
@@ -503,6 +507,7 @@ def test_random_corpus_phrases(orc, dev, block, fmt):
     hi = m.index_from_hits(W, R, H, n_terms=len(probs), total_docs=n_docs, skiplist_block_size=block, hit_format=fmt, n_fields=3)
     qs = []
     rankers = [m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_PROXIMITY]
+    more = [m.SPH_RANK_WORDCOUNT, m.SPH_RANK_SPH04, m.SPH_RANK_MATCHANY, m.SPH_RANK_FIELDMASK]
     for i in range(140):
         k = int(rng.integers(2, 5))
         dupes = rng.random() < 0.15
@@ -514,7 +519,7 @@ def test_random_corpus_phrases(orc, dev, block, fmt):
         mask = 0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8))
         root = PHRASE(m, *[kw(m, int(t), p) for t, p in zip(ts, pos)], mask=mask)
         has_dupes = len(set(int(t) for t in ts)) != k
-        rk = rankers[i % 4]
+        rk = rankers[i % 4] if i % 3 else more[(i // 3) % 4]
         if has_dupes and rk in (m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY):
             rk = m.SPH_RANK_BM25  # HANDLE_DUPES is restated neither in the oracle nor on the device
         qs.append(m.Query(root, ranker=rk, max_matches=int(rng.choice([5, 100, 1000])),
@@ -709,7 +714,8 @@ def test_golden_vectors_on_device(dev):
     A case whose shape a path declines must say so, not answer wrongly."""
     from test_oracle_golden import GOLDEN
     m, ctx, batch = dev
-    rankers = {"proximity_bm25": m.SPH_RANK_PROXIMITY_BM25, "bm25": m.SPH_RANK_BM25, "none": m.SPH_RANK_NONE}
+    rankers = {"proximity_bm25": m.SPH_RANK_PROXIMITY_BM25, "bm25": m.SPH_RANK_BM25, "none": m.SPH_RANK_NONE,
+               "wordcount": m.SPH_RANK_WORDCOUNT, "sph04": m.SPH_RANK_SPH04}
     ops = {"and": m.SPH_QUERY_AND, "or": m.SPH_QUERY_OR, "andnot": m.SPH_QUERY_ANDNOT, "phrase": m.SPH_QUERY_PHRASE}
 
     def tree(v, q):
@@ -728,7 +734,8 @@ def test_golden_vectors_on_device(dev):
             if r.status == -2:
                 continue
             assert r.status == 0
-            assert [(corpus["ids"][i], int(w)) for i, w in zip(r.rowid, r.weight)] == [tuple(x) for x in c["expect"]], c["name"]
+            got = [(corpus["ids"][i], int(w)) for i, w in zip(r.rowid, r.weight)]
+            assert got[:c.get("limit", len(got))] == [tuple(x) for x in c["expect"]], c["name"]
             if "total_found" in c:
                 assert r.total_found == c["total_found"]
             n_ok += 1
@@ -776,7 +783,8 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
                 root = PHRASE(m, *kws)
             else:
                 root = m.XQNode.AND(OR(m, *kws[:2]), *kws[2:]) if k > 2 else OR(m, *kws)
-            rk = [m.SPH_RANK_BM25, m.SPH_RANK_NONE] + ([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY] if packed else [])
+            rk = [m.SPH_RANK_BM25, m.SPH_RANK_NONE] + ([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY, m.SPH_RANK_WORDCOUNT,
+                                                       m.SPH_RANK_MATCHANY, m.SPH_RANK_FIELDMASK, m.SPH_RANK_SPH04] if packed else [])
             qs.append(m.Query(root, ranker=int(rng.choice(rk)), max_matches=int(rng.choice([1, 3, 1000, 1024])),
                               field_weights=[int(x) for x in rng.integers(-2, 9, 3)] if rng.random() < 0.4 else None))
         base = int(rng.choice([0, 7, 1 << 20]))

@@ -20,6 +20,9 @@ from helpers import mini_index
 
 GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json"),
                         encoding="utf-8"))
+for _c in GOLDEN["corpora"].values():  # corpora the reference builds in a loop are stored as (count, row) runs
+    if "docs_spec" in _c:
+        _c["docs"] = [list(run["fields"]) for run in _c["docs_spec"] for _ in range(run["count"])]
 
 
 # ------------------------------------------------------------------ VLB bytes
@@ -197,7 +200,7 @@ def test_reference_vectors(orc, case):
     idx, v = mini_index(orc, corpus["docs"], min_word_len=corpus["min_word_len"])
     got, r = run(orc, idx, _golden_tree(orc, v, case["query"]), getattr(orc, "RANK_" + case["ranker"].upper()), corpus["ids"],
                  **({"field_weights": case["field_weights"]} if "field_weights" in case else {}))
-    assert got == [tuple(x) for x in case["expect"]]
+    assert got[:case.get("limit", len(got))] == [tuple(x) for x in case["expect"]]
     if "total_found" in case:
         assert r.total_found == case["total_found"]
 
