@@ -28,10 +28,13 @@ namespace mrk {
 constexpr int BM_CBUF = 128; // candidates a wave collects before it publishes them
 constexpr int BM_QCAP = 128; // match queue entries per wave (scored in batches of 64)
 constexpr int BM_WORDS = 64; // words per window
+#ifndef MRK_BM_BURST
+#define MRK_BM_BURST 4 // windows requested back to back
+#endif
+constexpr int BM_BURST = MRK_BM_BURST;
 
 struct __align__(16) BmWaveLds {
   uint64_t cbuf[BM_CBUF];
-  uint32_t hist[NBINS]; // publishing scratch
   uint32_t qrow[BM_QCAP];
   uint32_t qra[BM_QCAP];
   uint32_t qrb[BM_QCAP];
@@ -39,6 +42,8 @@ struct __align__(16) BmWaveLds {
 
 struct __align__(16) BmSmem {
   BmWaveLds w[WAVES];
+  uint32_t hist[NBINS]; // publishing scratch, one per workgroup behind hist_lock (publishes are rare once pruning bites;
+  uint32_t hist_lock;   // a private 4 KB per wave would cap the occupancy at 5 waves per SIMD)
   uint32_t rank[256];
   float tfidf[2][256];
 };
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       for (uint32_t f = 0; f < nw; ++f)
         if (tid & (1u << f)) rk += (uint32_t)Q->weights[f];
     s.rank[tid] = rk;
+    if (!tid) s.hist_lock = 0;
   }
   const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
   const int32_t bin_lo = Q->bin_lo;
@@ -98,16 +104,27 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       basep = rdlane(basep, 0);
       const bool fits = basep + cn <= cand_cap;
       const uint32_t npub = cn;
-      for (uint32_t i = lane; i < (uint32_t)NBINS; i += 64) L.hist[i] = 0;
+      if (lane == 0) {
+        uint32_t expected = 0;
+        while (!__hip_atomic_compare_exchange_strong(&s.hist_lock, &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          expected = 0;
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      wave_lds_fence();
+      for (uint32_t i = lane; i < (uint32_t)NBINS; i += 64) s.hist[i] = 0;
       wave_lds_fence();
       for (uint32_t i = lane; i < cn; i += 64) {
         const uint64_t key = L.cbuf[i];
         if (fits) cand[basep + i] = key;
-        atomicAdd(&L.hist[bin_of(bin_mode, bin_lo, bin_shift, key_weight(key), key_rowid(key))], 1u);
+        atomicAdd(&s.hist[bin_of(bin_mode, bin_lo, bin_shift, key_weight(key), key_rowid(key))], 1u);
       }
       if (!fits && lane == 0) atomicOr(a.q_flags + oq, QF_OVERFLOW);
       wave_lds_fence();
-      flush_hist(L.hist, ghist);
+      flush_hist(s.hist, ghist);
+      wave_lds_fence();
+      if (lane == 0) __hip_atomic_store(&s.hist_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       cn = 0;
       // only the publisher whose slice crosses a 2048-candidate boundary recomputes the threshold
       if ((basep >> 11) != ((basep + npub) >> 11) || basep == 0) {
@@ -169,12 +186,12 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     }
   };
 
-  for (uint32_t wb = w0; wb < w1; wb += 4) {
-    // four windows requested back to back (one memory round trip per burst)
-    const uint32_t nb = w1 - wb < 4u ? w1 - wb : 4u;
-    uint32_t av[4], bv[4], dv[4];
+  for (uint32_t wb = w0; wb < w1; wb += BM_BURST) {
+    // BM_BURST windows requested back to back (one memory round trip per burst)
+    const uint32_t nb = w1 - wb < (uint32_t)BM_BURST ? w1 - wb : (uint32_t)BM_BURST;
+    uint32_t av[BM_BURST], bv[BM_BURST], dv[BM_BURST];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BM_BURST; ++i) {
       av[i] = bv[i] = dv[i] = 0;
       if ((uint32_t)i < nb) {
         const uint64_t o = (uint64_t)(wb + i) * BM_WORDS + lane;
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     }
 #endif
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BM_BURST; ++i) {
       if ((uint32_t)i < nb) {
         const uint32_t aw = av[i], bw = bv[i];
         uint32_t m = aw & bw & ~dv[i];
