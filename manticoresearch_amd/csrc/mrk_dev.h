@@ -102,6 +102,7 @@ struct DevQuery {
   uint32_t prog[16];  // op | left node << 8 | right node << 16 | keyword << 24
   uint32_t ph_atoms[MAX_PROX_TERMS_]; // PHRASE: query positions of its words, in phrase order
   uint32_t ph_mask;                   // TF_PHRASE_LEAF: keyword slots of the phrase's words
+  uint32_t px_dist;                   // 0 = exact PHRASE; else PROXIMITY ('"a b"~N'): XQNode_t::m_iOpArg
   uint32_t max_qpos, n_qwords;        // ExtRanker_c::m_iMaxQpos (largest query position) / m_iQwords (distinct words)
   int32_t weights[32];
   DevTerm t[MRK_MAX_AND_TERMS];

@@ -589,6 +589,7 @@ struct PlanTree {
   bool phrase = false;          // root is a PHRASE (ExtNWay_T<FSMphrase_c>)
   bool ph_leaf = false;         // one PHRASE below other operators; its words are kws[ph_kw0 .. ph_kw0 + ph_n)
   int ph_kw0 = 0, ph_n = 0;
+  int px_dist = 0;              // > 0: the phrase node is a PROXIMITY operator ('"a b"~N')
   std::vector<int> atoms;       // its words' query positions, phrase order
 };
 
@@ -625,9 +626,10 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     return (int)T.nodes.size() - 1;
   };
   if (n.op == MRK_OP_TERM) return leaf(ni);
-  if (n.op == MRK_OP_PHRASE && (T.phrase || T.ph_leaf))
+  const bool nway = n.op == MRK_OP_PHRASE || n.op == MRK_OP_PROXIMITY; // ExtNWay_T<FSMphrase_c / FSMproximity_c>
+  if (nway && (T.phrase || T.ph_leaf))
     return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: more than one PHRASE (device path: one per query)", qi), -1;
-  if (n.op != MRK_OP_PHRASE && n.op != MRK_OP_AND && n.op != MRK_OP_OR && n.op != MRK_OP_MAYBE && n.op != MRK_OP_ANDNOT)
+  if (!nway && n.op != MRK_OP_AND && n.op != MRK_OP_OR && n.op != MRK_OP_MAYBE && n.op != MRK_OP_ANDNOT)
     return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, n.op), -1;
   if (n.n_children < 1 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
   std::vector<int32_t> kids(n.n_children);
@@ -637,8 +639,12 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     if (kids[i] < 0 || kids[i] >= q.n_nodes) return err = mrk_fail(MRK_E_INVAL, "query %u: child index out of range", qi), -1;
     all_terms &= q.nodes[kids[i]].op == MRK_OP_TERM;
   }
-  if (n.op == MRK_OP_PHRASE) {
-    // CreateMultiNode<ExtPhrase_c> (searchnode.cpp:984-1041): plain keywords only; ExtNWay_T::ConstructNode
+  if (nway) {
+    if (n.op == MRK_OP_PROXIMITY) {
+      if (n.opt <= 0 || n.opt > (1 << 20)) return err = mrk_fail(MRK_E_INVAL, "query %u: proximity distance %d", qi, n.opt), -1;
+      T.px_dist = n.opt;
+    }
+    // CreateMultiNode<ExtPhrase_c / ExtProximity_c> (searchnode.cpp:984-1041): plain keywords only; ExtNWay_T::ConstructNode
     // (:3767-3787) chains them left-deep in ascending doc-count order, so docs / tfidf come out as for a MultiAnd
     if (!all_terms || n.n_children < 2 || n.n_children > MAX_PROX_TERMS)
       return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE of %d nodes (device path: 2..%d plain keywords)", qi, n.n_children,
@@ -652,7 +658,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
       return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: phrase spans %d positions (device path: < %d)", qi,
                             T.atoms.back() - T.atoms.front(), PHRASE_STATES), -1;
   }
-  if ((n.op == MRK_OP_AND || n.op == MRK_OP_PHRASE) && all_terms && n.n_children > 1) {
+  if ((n.op == MRK_OP_AND || nway) && all_terms && n.n_children > 1) {
     std::vector<int> ord(n.n_children), docs(n.n_children);
     for (int i = 0; i < n.n_children; ++i) {
       const mrk_node& t = q.nodes[kids[i]];
@@ -671,7 +677,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
       const int r = leaf(kids[ord[i]]);
       cur = join(PN_AND, cur, r);
     }
-    if (n.op == MRK_OP_PHRASE) { // the words are created with the phrase node's field limit (searchnode.cpp:1020-1024)
+    if (nway) { // the words are created with the phrase node's field limit (searchnode.cpp:1020-1024)
       for (size_t k = (size_t)kw0; k < T.kws.size(); ++k) T.kws[k].queried32 &= n.field_mask;
       if (!is_root) { // ExtNWay_T on top of the words' AND chain: keeps the docs where the words line up
         T.ph_kw0 = kw0;
@@ -771,7 +777,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   const bool single_word = T.nodes.size() == 1;
   bool pure_and = true; // single keyword or one ExtMultiAnd_T: the kernel's N-way AND loop, no program
   for (const PlanNode& pn : T.nodes) pure_and &= pn.op == PN_TERM || pn.op == PN_AND;
-  if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE))
+  if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE || q.nodes[q.root].op == MRK_OP_PROXIMITY))
     for (int i = 0; i < q.nodes[q.root].n_children; ++i) pure_and &= q.nodes[q.children[q.nodes[q.root].first_child + i]].op == MRK_OP_TERM;
   if (!pure_and && !use_packed) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: boolean trees run on the packed path only", qi);
   if (!pure_and) { // the device evaluates the program on a TREE_STACK-deep register stack
@@ -1030,6 +1036,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
     P->req_mask = P->excl_mask = 0;
     P->tree_flags = T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0;
+    P->px_dist = (uint32_t)T.px_dist;
     P->ph_mask = 0;
     for (int k = 0; k < T.ph_n; ++k) P->ph_mask |= 1u << slot[T.ph_kw0 + k];
     for (size_t i = 0; i < T.atoms.size(); ++i) P->ph_atoms[i] = (uint32_t)T.atoms[i];

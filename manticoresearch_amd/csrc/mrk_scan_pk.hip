@@ -205,6 +205,98 @@ struct PhraseFsm {
     if (emit) fvalid = 0; // ResetFSM
     return emit;
   }
+
+  // FSMproximity_c (searchnode.cpp:3958-4075), '"a b c"~N', on the same storage: fexp[i] = m_dProx[i] (last position
+  // of the word at query offset i, ~0 = none), ftag = m_uWords, fvalid = m_iMinQindex + 1, exp = m_uExpPos.
+  // A hit that completes "all words within qlen + dist" folds them into one hit: position / spanlen of the words
+  // gathered, weight from how many of them keep the query's relative offsets; the earliest word is then dropped.
+  uint32_t exp;
+  __device__ __forceinline__ void reset_prox() {
+#pragma unroll
+    for (int i = 0; i < PHRASE_STATES; ++i) fexp[i] = 0xFFFFFFFFu;
+    ftag = 0, fvalid = 0, over = false, exp = 0;
+  }
+  __device__ __forceinline__ bool step_prox(uint32_t hp, uint32_t hq, uint32_t nph, uint32_t min_qpos, uint32_t qlen, uint32_t dist,
+                                            uint32_t& out_pos, uint32_t& out_w, uint32_t& out_span) {
+    const uint32_t qi = hq - min_qpos;
+    int min_q = (int)fvalid - 1;
+#pragma unroll
+    for (int i = 0; i < PHRASE_STATES; ++i)
+      if ((uint32_t)i == qi) {
+        if (fexp[i] == 0xFFFFFFFFu) ++ftag;
+        fexp[i] = hp;
+      }
+    if (hp >= exp || (int)qi == min_q) {
+      min_q = (int)qi;
+      uint32_t h = hp;
+      const int min_pos = (int)(hp - qlen - dist);
+#pragma unroll
+      for (int i = 0; i < PHRASE_STATES; ++i)
+        if ((uint32_t)i <= qlen && fexp[i] != 0xFFFFFFFFu) {
+          if ((int)fexp[i] <= min_pos) {
+            fexp[i] = 0xFFFFFFFFu;
+            --ftag;
+          } else if (fexp[i] < h) {
+            min_q = i;
+            h = fexp[i];
+          }
+        }
+      uint32_t pm = 0;
+#pragma unroll
+      for (int i = 0; i < PHRASE_STATES; ++i)
+        if (i == min_q) pm = fexp[i];
+      exp = pm + qlen + dist;
+    }
+    fvalid = (uint32_t)(min_q + 1);
+    if (ftag != nph) return false;
+    // weight: sort the words' (position - query offset); runs of equal values are words in the query's order
+    int d[PHRASE_STATES];
+    uint32_t umax = 0;
+#pragma unroll
+    for (int i = 0; i < PHRASE_STATES; ++i) {
+      const bool have = (uint32_t)i <= qlen && fexp[i] != 0xFFFFFFFFu;
+      d[i] = have ? (int)(fexp[i] - (uint32_t)i) : 0x7FFFFFFF;
+      if (have && fexp[i] > umax) umax = fexp[i];
+    }
+#pragma unroll
+    for (int pass = 0; pass < PHRASE_STATES; ++pass) // odd-even transposition sort, 8 elements
+#pragma unroll
+      for (int i = pass & 1; i + 1 < PHRASE_STATES; i += 2) {
+        const int lo = d[i] < d[i + 1] ? d[i] : d[i + 1], hi = d[i] < d[i + 1] ? d[i + 1] : d[i];
+        d[i] = lo;
+        d[i + 1] = hi;
+      }
+    uint32_t cur_w = 0, w = 0;
+    int last = -0x7FFFFFFF;
+#pragma unroll
+    for (int i = 0; i < PHRASE_STATES; ++i)
+      if (d[i] != 0x7FFFFFFF) {
+        if (d[i] == last)
+          ++cur_w;
+        else {
+          w += cur_w ? 1u + cur_w : 0u;
+          cur_w = 0;
+        }
+        last = d[i];
+      }
+    w += cur_w ? 1u + cur_w : 0u;
+    if (!w) w = 1;
+    uint32_t pm = 0;
+#pragma unroll
+    for (int i = 0; i < PHRASE_STATES; ++i)
+      if (i == min_q) pm = fexp[i];
+    out_pos = pm;
+    out_w = w;
+    out_span = umax - pm; // spanlen - 1
+    // drop the earliest word and force a recompute on the next hit
+#pragma unroll
+    for (int i = 0; i < PHRASE_STATES; ++i)
+      if (i == min_q) fexp[i] = 0xFFFFFFFFu;
+    fvalid = 0;
+    --ftag;
+    exp = 0;
+    return true;
+  }
 };
 
 // The state rankers (ExtRanker_State_T<STATE>, sphinxsearch.cpp:1198-1315), one doc at a time.  All of them see the
@@ -304,6 +396,7 @@ struct HitCtx {
   uint32_t lane, nterms, nw;
   uint32_t ap0, ap1, ap2, ap3;
   uint32_t nph, span;     // the query's phrase: words, distance between its first and last query position
+  uint32_t px_dist;       // 0 = exact PHRASE, else the PROXIMITY operator's distance ('"a b"~N')
   uint32_t ranker;        // MRK_RANK_* of the state ranker fed by the pass
   const uint32_t* w_of;   // LDS table: field-weight sum per field mask (w_of[1 << f] = weight of field f)
   int max_qpos, n_qwords; // ExtRanker_c::m_iMaxQpos / m_iQwords
@@ -348,9 +441,12 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, int r, uint32_t smask,
   // the phrase as a stream of folded hits: position = first word's, weight = word count, spanlen = span + 1
   const uint32_t nph = C.nph, span = C.span; // the query's one phrase: word count, last - first query position
   PhraseFsm F;
-  F.reset();
+  if (C.px_dist)
+    F.reset_prox();
+  else
+    F.reset();
   bool phave = false, pdone = pmask == 0, first = true;
-  uint32_t pcur = 0, pfield = 0;
+  uint32_t pcur = 0, pfield = 0, pw = 0, pspan = 0;
   RankState X;
   X.reset();
   const uint32_t dmask = smask & ~pmask; // keywords whose hits reach the ranker as they are
@@ -372,13 +468,16 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, int r, uint32_t smask,
         }
         const uint32_t hp = bh & ~(1u << 23);
         bool emit = false;
-        if (field_queried(bmask, bh)) emit = F.step(hp, bq & 0xFFFFu, nph, C.ap0, C.ap1, C.ap2, C.ap3);
+        uint32_t e_pos = hp - span, e_w = nph, e_span = span; // exact phrase: first word's position, word count, span
+        if (field_queried(bmask, bh))
+          emit = C.px_dist ? F.step_prox(hp, bq & 0xFFFFu, nph, C.ap0 & 0xFFFFu, span, C.px_dist, e_pos, e_w, e_span)
+                           : F.step(hp, bq & 0xFFFFu, nph, C.ap0, C.ap1, C.ap2, C.ap3);
 #pragma unroll
         for (int t = 0; t < MAX_PROX_TERMS; ++t)
           if (t == best) hit_advance(C.spp, sp[t], sc[t]);
         if (emit) {
           phave = true;
-          pcur = hp - span;
+          pcur = e_pos, pw = e_w, pspan = e_span;
           pfield = (bh >> 24) & 31u;
           break;
         }
@@ -410,7 +509,7 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, int r, uint32_t smask,
       if (((dmask >> t) & 1u) && sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && sq[t] < bq)))
         best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
     if (phave && (best < 0 || pcur < bh || (pcur == bh && (C.ap0 & 0xFFFFu) < (bq & 0xFFFFu)))) {
-      X.update(C.ranker, pcur, false, C.ap0 & 0xFFFFu, nph, span, C.w_of, C.max_qpos);
+      X.update(C.ranker, pcur, false, C.ap0 & 0xFFFFu, pw, pspan, C.w_of, C.max_qpos);
       phave = false;
       continue;
     }
@@ -868,6 +967,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       C.lane = lane, C.nterms = nterms, C.nw = nw;
       C.ap0 = ap0, C.ap1 = ap1, C.ap2 = ap2, C.ap3 = ap3;
       C.nph = ph_n, C.span = ph_span;
+      C.px_dist = Q->px_dist;
       C.ranker = ranker;
       C.w_of = s.rank;
       C.max_qpos = (int)Q->max_qpos, C.n_qwords = (int)Q->n_qwords;

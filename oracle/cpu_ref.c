@@ -676,6 +676,13 @@ struct enode {
   fsm_state* states;
   int n_states, cap_states;
   hitvec myhits;
+  /* PROXIMITY (ExtNWay_T<FSMproximity_c>): same node, other state machine */
+  int is_proximity;
+  int max_distance;          /* m_iMaxDistance = XQNode_t::m_iOpArg */
+  uint32_t px_min_qpos, px_qlen, px_exp_pos, px_words;
+  int px_min_qindex;
+  uint32_t* px_prox;         /* [px_qlen + 1] last position of the word with that query offset, UINT_MAX = none */
+  int* px_deltas;
   hitvec tmp, tmp2;
   /* common */
   int atom; /* ExtNode_i::GetAtomPos */
@@ -1080,17 +1087,96 @@ static int fsm_hit(enode* e, const hit_t* h) { /* FSMphrase_c::HitFSM :3901-3947
   return 0;
 }
 
+/* FSMproximity_c (searchnode.cpp:3958-4075) */
+static void px_reset(enode* e) { /* ResetFSM :4068-4075 */
+  e->px_exp_pos = 0;
+  e->px_words = 0;
+  e->px_min_qindex = -1;
+  for (uint32_t i = 0; i <= e->px_qlen; i++) e->px_prox[i] = UINT32_MAX;
+}
+
+static int cmp_int(const void* a, const void* b) {
+  int x = *(const int*)a, y = *(const int*)b;
+  return x < y ? -1 : x > y;
+}
+
+static int px_hit(enode* e, const hit_t* h) { /* HitFSM :3973-4065 */
+  int qindex = (int)h->qpos - (int)e->px_min_qpos;
+  uint32_t hpf = ORC_HIT_POSWITHFIELD(h->hitpos);
+  const int n = (int)e->px_qlen + 1;
+  if (e->px_prox[qindex] == UINT32_MAX) e->px_words++;
+  e->px_prox[qindex] = hpf;
+  if (hpf >= e->px_exp_pos || qindex == e->px_min_qindex) {
+    e->px_min_qindex = qindex;
+    int min_pos = (int)(hpf - e->px_qlen - (uint32_t)e->max_distance);
+    for (int i = 0; i < n; i++)
+      if (e->px_prox[i] != UINT32_MAX) {
+        if ((int)e->px_prox[i] <= min_pos) {
+          e->px_prox[i] = UINT32_MAX;
+          e->px_words--;
+          continue;
+        }
+        if (e->px_prox[i] < hpf) {
+          e->px_min_qindex = i;
+          hpf = e->px_prox[i];
+        }
+      }
+    e->px_exp_pos = e->px_prox[e->px_min_qindex] + e->px_qlen + (uint32_t)e->max_distance;
+  }
+  if (e->px_words != (uint32_t)e->n_atoms) return 0;
+  /* phrase weight from the words' deltas */
+  uint32_t umax = 0;
+  for (int i = 0; i < n; i++)
+    if (e->px_prox[i] != UINT32_MAX) {
+      e->px_deltas[i] = (int)(e->px_prox[i] - (uint32_t)i);
+      if (e->px_prox[i] > umax) umax = e->px_prox[i];
+    } else
+      e->px_deltas[i] = INT_MAX;
+  qsort(e->px_deltas, (size_t)n, sizeof(int), cmp_int);
+  uint32_t cur_weight = 0, weight = 0;
+  int last = -INT_MAX;
+  for (int i = 0; i < n && e->px_deltas[i] != INT_MAX; i++) {
+    if (e->px_deltas[i] == last)
+      cur_weight++;
+    else {
+      weight += cur_weight ? (1 + cur_weight) : 0;
+      cur_weight = 0;
+    }
+    last = e->px_deltas[i];
+  }
+  weight += cur_weight ? (1 + cur_weight) : 0;
+  if (!weight) weight = 1;
+  hit_t t;
+  t.rowid = h->rowid;
+  t.hitpos = e->px_prox[e->px_min_qindex];
+  t.qpos = (uint16_t)e->px_min_qpos;
+  t.nodepos = 0;
+  t.matchlen = t.spanlen = (uint16_t)(umax - e->px_prox[e->px_min_qindex] + 1);
+  t.weight = weight;
+  t.qposmask = 0;
+  hv_push(&e->myhits, &t);
+  /* remove the current min, force a recompute */
+  e->px_prox[e->px_min_qindex] = UINT32_MAX;
+  e->px_min_qindex = -1;
+  e->px_words--;
+  e->px_exp_pos = 0;
+  return 1;
+}
+
 static int phrase_next(enode* e) { /* ExtNWay_T::GetDocsChunk :3806-3848 */
   for (;;) {
     if (!en_next(e->inner)) return 0;
     e->tmp.n = 0;
     en_hits(e->inner, &e->tmp);
     e->myhits.n = 0;
-    fsm_reset(e);
+    if (e->is_proximity)
+      px_reset(e);
+    else
+      fsm_reset(e);
     int matched = 0;
     for (int i = 0; i < e->tmp.n; i++) {
       const hit_t* h = &e->tmp.p[i];
-      if (fsm_hit(e, h) && !matched) {
+      if ((e->is_proximity ? px_hit(e, h) : fsm_hit(e, h)) && !matched) {
         matched = 1;
         e->rowid = h->rowid;
         e->fields = 1u << (ORC_HIT_FIELD(h->hitpos) & 31);
@@ -1164,6 +1250,8 @@ static void en_free(enode* e) {
   free(e->atom_pos);
   free(e->qpos_delta);
   free(e->states);
+  free(e->px_prox);
+  free(e->px_deltas);
   free(e->myhits.p);
   free(e->tmp.p);
   free(e->tmp2.p);
@@ -1281,6 +1369,20 @@ static enode* build_phrase(build_ctx* bc, const orc_node* qn) {
   }
   if (cur_ex) cur_ex->qpos_reverse = 1;
   e->inner = cur;
+  if (qn->op == ORC_OP_PROXIMITY) { /* FSMproximity_c ctor :3958-3970 */
+    if (qn->opt <= 0) {
+      bc->error = 1;
+      fail("proximity needs a positive distance");
+      en_free(e);
+      return NULL;
+    }
+    e->is_proximity = 1;
+    e->max_distance = qn->opt;
+    e->px_min_qpos = (uint32_t)e->atom_pos[0];
+    e->px_qlen = (uint32_t)(e->atom_pos[k - 1] - e->atom_pos[0]);
+    e->px_prox = (uint32_t*)malloc((size_t)(e->px_qlen + 1) * sizeof(uint32_t));
+    e->px_deltas = (int*)malloc((size_t)(e->px_qlen + 1) * sizeof(int));
+  }
   return e;
 }
 
@@ -1289,7 +1391,8 @@ static enode* build_node(build_ctx* bc, int ni) {
   const orc_node* qn = &q->nodes[ni];
   switch (qn->op) {
     case ORC_OP_TERM: return build_term(bc, qn);
-    case ORC_OP_PHRASE: return build_phrase(bc, qn);
+    case ORC_OP_PHRASE:
+    case ORC_OP_PROXIMITY: return build_phrase(bc, qn);
     case ORC_OP_AND: {
       int k = qn->n_children;
       if (k < 1 || k > 32) {

@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libcpu_ref.so")
 
 RANK_PROXIMITY_BM25, RANK_BM25, RANK_NONE, RANK_WORDCOUNT, RANK_PROXIMITY = 0, 1, 2, 3, 4
 RANK_MATCHANY, RANK_FIELDMASK, RANK_SPH04 = 5, 6, 7
-OP_TERM, OP_AND, OP_OR, OP_MAYBE, OP_ANDNOT, OP_PHRASE = 0, 1, 2, 3, 4, 5
+OP_TERM, OP_AND, OP_OR, OP_MAYBE, OP_ANDNOT, OP_PHRASE, OP_PROXIMITY, OP_QUORUM = 0, 1, 2, 3, 4, 5, 6, 7
 ALL_FIELDS = 0xFFFFFFFF
 
 
@@ -216,14 +216,15 @@ class QNode:
     atom_pos: int = 0
     field_mask: int = ALL_FIELDS
     boost: float = 1.0
+    opt: int = 0  # XQNode_t::m_iOpArg (proximity distance, quorum threshold)
 
 
 def term(term_id: int, atom_pos: int, field_mask: int = ALL_FIELDS, boost: float = 1.0) -> QNode:
     return QNode(OP_TERM, [], term_id, atom_pos, field_mask, boost)
 
 
-def op(kind: int, *children: QNode, field_mask: int = ALL_FIELDS) -> QNode:
-    return QNode(kind, list(children), field_mask=field_mask)
+def op(kind: int, *children: QNode, field_mask: int = ALL_FIELDS, opt: int = 0) -> QNode:
+    return QNode(kind, list(children), field_mask=field_mask, opt=opt)
 
 
 @dataclass
@@ -259,6 +260,7 @@ class FlatQuery:
             cn.op, cn.n_children, cn.first_child = n.op, len(n._kids), len(kids)  # type: ignore[attr-defined]
             kids.extend(n._kids)  # type: ignore[attr-defined]
             cn.term_id, cn.atom_pos, cn.field_mask, cn.boost = n.term_id, n.atom_pos, n.field_mask, n.boost
+            cn.opt = n.opt
         self.children = (C.c_int * max(1, len(kids)))(*kids)
         q = _Query()
         q.nodes, q.n_nodes = self.nodes, len(nodes)

@@ -16,8 +16,8 @@ def T(word, pos, mask=ALL):
     return {"word": word, "pos": pos, "mask": mask}
 
 
-def OP(op, *kids, mask=ALL):
-    return {"op": op, "kids": list(kids), "mask": mask}
+def OP(op, *kids, mask=ALL, opt=0):
+    return {"op": op, "kids": list(kids), "mask": mask, "opt": opt}
 
 
 G = {
@@ -90,6 +90,8 @@ for spam, exp in [(1, [[1, 7415], [3, 6426], [2, 4421]]), (10, [[1, 25415], [3, 
                        "field_weights": [1, 2, spam], "expect": exp})
 
 G["cases"] += [
+    {"name": "019 \"hello program\"~4", "corpus": "test_019", "query": OP("proximity", T("hello", 1), T("program", 2), opt=4),
+     "ranker": "proximity_bm25", "expect": [[333, 1687]]},
     {"name": "037 phrase wordcount", "corpus": "test_037", "query": OP("phrase", T("зимние", 1), T("шины", 2)),
      "ranker": "wordcount", "expect": [[1, 2]], "total_found": 1},
     {"name": "037/test2 market street sph04", "corpus": "test_037_test2", "query": OP("and", T("market", 1), T("street", 2)),

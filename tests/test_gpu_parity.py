@@ -35,7 +35,7 @@ def to_orc(orc, q):
     def conv(n):
         if n.word is not None:
             return orc.term(n.word.term_id, n.word.atom_pos, n.field_mask, n.word.boost)
-        return orc.op(n.op, *[conv(c) for c in n.children], field_mask=n.field_mask)
+        return orc.op(n.op, *[conv(c) for c in n.children], field_mask=n.field_mask, opt=n.opt)
 
     return orc.FlatQuery(conv(q.root), ranker=q.ranker, max_matches=q.max_matches, field_weights=q.field_weights,
                          index_weight=q.index_weight, plain_idf=q.plain_idf, normalized_tfidf=q.normalized_tfidf,
@@ -215,8 +215,8 @@ def test_unsupported_shapes_fail_loudly(dev):
     m, ctx, batch = dev
     hi = m.synth_index(1000, [0.5, 0.5], seed=1)
     seg = m.Segment(ctx, hi)
-    # an operator the device path does not know (proximity / near / quorum ... would be op codes > PHRASE)
-    q_or = m.Query(m.XQNode(6, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
+    # an operator the device path does not know (quorum / near / ... : op codes beyond PROXIMITY)
+    q_or = m.Query(m.XQNode(7, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
     q_big = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25, max_matches=5000)
     q_ok = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25)
     r = batch.search(seg, [q_or, q_ok, q_big])
@@ -483,6 +483,10 @@ def PHRASE(m, *k, mask=0xFFFFFFFF):
     return m.XQNode(m.SPH_QUERY_PHRASE, list(k), None, mask)
 
 
+def PROXIMITY(m, dist, *k, mask=0xFFFFFFFF):
+    return m.XQNode(m.SPH_QUERY_PROXIMITY, list(k), None, mask, dist)
+
+
 def test_golden_phrase_weight_on_device(dev):
     """test_019: '"phrase query"' under the default ranker -> 222:2687."""
     _tree_only(dev)
@@ -517,7 +521,8 @@ def test_random_corpus_phrases(orc, dev, block, fmt):
             ap += 1 if rng.random() < 0.85 else 2  # a stop word leaves a gap in the atom positions
             pos.append(ap)
         mask = 0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8))
-        root = PHRASE(m, *[kw(m, int(t), p) for t, p in zip(ts, pos)], mask=mask)
+        words = [kw(m, int(t), p) for t, p in zip(ts, pos)]
+        root = PHRASE(m, *words, mask=mask) if i % 2 else PROXIMITY(m, int(rng.integers(1, 6)), *words, mask=mask)
         has_dupes = len(set(int(t) for t in ts)) != k
         rk = rankers[i % 4] if i % 3 else more[(i // 3) % 4]
         if has_dupes and rk in (m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY):
@@ -533,7 +538,9 @@ def test_random_corpus_phrases(orc, dev, block, fmt):
         for _ in range(4):
             ap += 1 if rng.random() < 0.85 else 2
             pos.append(ap)
-        ph = PHRASE(m, *[kw(m, ts[j], pos[j]) for j in range(npw)], mask=0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)))
+        ph_mask = 0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8))
+        ph_words = [kw(m, ts[j], pos[j]) for j in range(npw)]
+        ph = PHRASE(m, *ph_words, mask=ph_mask) if i % 3 else PROXIMITY(m, int(rng.integers(1, 5)), *ph_words, mask=ph_mask)
         c = kw(m, ts[npw], pos[npw], 0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)))
         shape = i % 6
         if shape == 0:
@@ -716,12 +723,13 @@ def test_golden_vectors_on_device(dev):
     m, ctx, batch = dev
     rankers = {"proximity_bm25": m.SPH_RANK_PROXIMITY_BM25, "bm25": m.SPH_RANK_BM25, "none": m.SPH_RANK_NONE,
                "wordcount": m.SPH_RANK_WORDCOUNT, "sph04": m.SPH_RANK_SPH04}
-    ops = {"and": m.SPH_QUERY_AND, "or": m.SPH_QUERY_OR, "andnot": m.SPH_QUERY_ANDNOT, "phrase": m.SPH_QUERY_PHRASE}
+    ops = {"and": m.SPH_QUERY_AND, "or": m.SPH_QUERY_OR, "andnot": m.SPH_QUERY_ANDNOT, "phrase": m.SPH_QUERY_PHRASE,
+           "proximity": m.SPH_QUERY_PROXIMITY}
 
     def tree(v, q):
         if "word" in q:
             return kw(m, v[q["word"]], q["pos"], q["mask"])
-        return m.XQNode(ops[q["op"]], [tree(v, k) for k in q["kids"]], None, q["mask"])
+        return m.XQNode(ops[q["op"]], [tree(v, k) for k in q["kids"]], None, q["mask"], q.get("opt", 0))
 
     n_ok = 0
     for name, corpus in GOLDEN["corpora"].items():

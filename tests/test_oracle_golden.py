@@ -191,7 +191,8 @@ def test_dead_rows_skip_the_sorter(orc):
 def _golden_tree(orc, v, q):
     if "word" in q:
         return orc.term(v[q["word"]], q["pos"], field_mask=q["mask"])
-    return orc.op(getattr(orc, "OP_" + q["op"].upper()), *[_golden_tree(orc, v, k) for k in q["kids"]], field_mask=q["mask"])
+    return orc.op(getattr(orc, "OP_" + q["op"].upper()), *[_golden_tree(orc, v, k) for k in q["kids"]], field_mask=q["mask"],
+                  opt=q.get("opt", 0))
 
 
 @pytest.mark.parametrize("case", GOLDEN["cases"], ids=[c["name"] for c in GOLDEN["cases"]])
