@@ -590,6 +590,7 @@ struct PlanTree {
   bool ph_leaf = false;         // one PHRASE below other operators; its words are kws[ph_kw0 .. ph_kw0 + ph_n)
   int ph_kw0 = 0, ph_n = 0;
   int px_dist = 0;              // > 0: the phrase node is a PROXIMITY operator ('"a b"~N')
+  bool force_tree = false;      // the query must run as a tree program even if it only holds TERM / AND nodes
   std::vector<int> atoms;       // its words' query positions, phrase order
 };
 
@@ -629,6 +630,37 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
   const bool nway = n.op == MRK_OP_PHRASE || n.op == MRK_OP_PROXIMITY; // ExtNWay_T<FSMphrase_c / FSMproximity_c>
   if (nway && (T.phrase || T.ph_leaf))
     return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: more than one PHRASE (device path: one per query)", qi), -1;
+  if (n.op == MRK_OP_QUORUM) {
+    // ExtNode_i::Create, SPH_QUERY_QUORUM (searchnode.cpp:1638-1686): threshold 1 = an ExtOr_c chain, threshold >= word
+    // count = an ExtAnd_c chain, both over the words sorted by ascending doc count; a real ExtQuorum_c in between
+    if (n.n_children < 2 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
+    if (n.opt != 1 && n.opt < n.n_children)
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum %d of %d (ExtQuorum_c) is not on the device path", qi, n.opt, n.n_children), -1;
+    std::vector<int32_t> kids(n.n_children);
+    std::vector<int> ord(n.n_children), docs(n.n_children);
+    for (int i = 0; i < n.n_children; ++i) {
+      kids[i] = q.children[n.first_child + i];
+      if (kids[i] < 0 || kids[i] >= q.n_nodes || q.nodes[kids[i]].op != MRK_OP_TERM)
+        return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum over plain keywords only", qi), -1;
+      const mrk_node& t = q.nodes[kids[i]];
+      docs[i] = (t.term_id >= 0 && (uint32_t)t.term_id < seg->terms.size()) ? (int)seg->terms[t.term_id].docs : 0;
+      ord[i] = i;
+    }
+    for (int i = 1; i < n.n_children; ++i)
+      for (int j = i; j > 0; --j) {
+        if (docs[ord[j - 1]] < docs[ord[j]]) break;
+        std::swap(ord[j], ord[j - 1]);
+      }
+    const size_t kw0 = T.kws.size();
+    int cur = leaf(kids[ord[0]]);
+    for (int i = 1; i < n.n_children; ++i) {
+      const int r = leaf(kids[ord[i]]);
+      cur = join(n.opt == 1 ? PN_OR : PN_AND, cur, r);
+    }
+    for (size_t k = kw0; k < T.kws.size(); ++k) T.kws[k].queried32 &= n.field_mask; // Create ( word, pNode, .. )
+    T.force_tree = true; // an ExtAnd_c chain is not an ExtMultiAnd_T (no MergeHits3 quirk): always the tree program
+    return cur;
+  }
   if (!nway && n.op != MRK_OP_AND && n.op != MRK_OP_OR && n.op != MRK_OP_MAYBE && n.op != MRK_OP_ANDNOT)
     return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, n.op), -1;
   if (n.n_children < 1 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
@@ -775,7 +807,7 @@ static int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_b
   if (n > MRK_MAX_AND_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d keywords (device path: <= %d)", qi, n, MRK_MAX_AND_TERMS);
   if (T.nodes.size() > 16) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
   const bool single_word = T.nodes.size() == 1;
-  bool pure_and = true; // single keyword or one ExtMultiAnd_T: the kernel's N-way AND loop, no program
+  bool pure_and = !T.force_tree; // single keyword or one ExtMultiAnd_T: the kernel's N-way AND loop, no program
   for (const PlanNode& pn : T.nodes) pure_and &= pn.op == PN_TERM || pn.op == PN_AND;
   if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE || q.nodes[q.root].op == MRK_OP_PROXIMITY))
     for (int i = 0; i < q.nodes[q.root].n_children; ++i) pure_and &= q.nodes[q.children[q.nodes[q.root].first_child + i]].op == MRK_OP_TERM;

@@ -1393,6 +1393,43 @@ static enode* build_node(build_ctx* bc, int ni) {
     case ORC_OP_TERM: return build_term(bc, qn);
     case ORC_OP_PHRASE:
     case ORC_OP_PROXIMITY: return build_phrase(bc, qn);
+    case ORC_OP_QUORUM: {
+      /* ExtNode_i::Create, SPH_QUERY_QUORUM (searchnode.cpp:1638-1686): a threshold of 1 becomes an ExtOr_c chain,
+         a threshold >= the word count an ExtAnd_c chain, both over the words sorted by ascending doc count
+         (ExtNodeTF_fn); only what lies between is a real ExtQuorum_c, which is not restated here */
+      int k = qn->n_children;
+      if (k < 2 || k > 32) {
+        bc->error = 1;
+        fail("quorum needs 2..32 keywords");
+        return NULL;
+      }
+      const int thr = qn->opt;
+      if (thr != 1 && thr < k) {
+        bc->error = 1;
+        fail("ExtQuorum_c (1 < threshold < words) not restated in the oracle");
+        return NULL;
+      }
+      enode* terms[32];
+      int key[32], pos[32];
+      for (int i = 0; i < k; i++) {
+        const orc_node* c = &q->nodes[q->children[qn->first_child + i]];
+        if (c->op != ORC_OP_TERM) {
+          bc->error = 1;
+          fail("quorum over plain keywords only");
+          for (int j = 0; j < i; j++) en_free(terms[j]);
+          return NULL;
+        }
+        orc_node w = *c;
+        w.field_mask = qn->field_mask & c->field_mask; /* Create ( word, pNode, .. ): the quorum node's field spec */
+        terms[i] = build_term(bc, &w);
+        key[i] = en_docs_count(terms[i]);
+        pos[i] = i;
+      }
+      sph_isort_idx(pos, k, key); /* dTerms.Sort ( ExtNodeTF_fn() ) */
+      enode* cur = terms[pos[0]];
+      for (int i = 1; i < k; i++) cur = build_twofer(bc, thr == 1 ? EN_OR : EN_AND, cur, terms[pos[i]]);
+      return cur;
+    }
     case ORC_OP_AND: {
       int k = qn->n_children;
       if (k < 1 || k > 32) {

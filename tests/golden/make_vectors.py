@@ -90,6 +90,9 @@ for spam, exp in [(1, [[1, 7415], [3, 6426], [2, 4421]]), (10, [[1, 25415], [3, 
                        "field_weights": [1, 2, spam], "expect": exp})
 
 G["cases"] += [
+    {"name": "019 \"quorum query test\"/1", "corpus": "test_019",
+     "query": OP("quorum", T("quorum", 1), T("query", 2), T("test", 3), opt=1), "ranker": "proximity_bm25",
+     "expect": [[333, 1573], [111, 1551], [222, 1551]]},
     {"name": "019 \"hello program\"~4", "corpus": "test_019", "query": OP("proximity", T("hello", 1), T("program", 2), opt=4),
      "ranker": "proximity_bm25", "expect": [[333, 1687]]},
     {"name": "037 phrase wordcount", "corpus": "test_037", "query": OP("phrase", T("зимние", 1), T("шины", 2)),

@@ -215,8 +215,8 @@ def test_unsupported_shapes_fail_loudly(dev):
     m, ctx, batch = dev
     hi = m.synth_index(1000, [0.5, 0.5], seed=1)
     seg = m.Segment(ctx, hi)
-    # an operator the device path does not know (quorum / near / ... : op codes beyond PROXIMITY)
-    q_or = m.Query(m.XQNode(7, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
+    # an operator the device path does not know (near / before / sentence ...: op codes beyond QUORUM)
+    q_or = m.Query(m.XQNode(9, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
     q_big = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25, max_matches=5000)
     q_ok = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25)
     r = batch.search(seg, [q_or, q_ok, q_big])
@@ -445,7 +445,10 @@ def test_random_boolean_trees(orc, dev, block, fmt):
              m.XQNode.AND(a, ANDNOT(m, b, c)), MAYBE(m, b, a), MAYBE(m, c, OR(m, a, b)), OR(m, a, b, c, d),
              OR(m, m.XQNode.AND(a, b), m.XQNode.AND(c, d)), m.XQNode.AND(OR(m, a, b), OR(m, c, d)),
              OR(m, a, kw(m, nt - 1, 2)), m.XQNode.AND(OR(m, a, kw(m, nt - 1, 2)), c), ANDNOT(m, a, kw(m, nt - 1, 2)),
-             ANDNOT(m, OR(m, a, b), c), OR(m, ANDNOT(m, a, b), c), m.XQNode.AND(m.XQNode.AND(a, b), c)]
+             ANDNOT(m, OR(m, a, b), c), OR(m, ANDNOT(m, a, b), c), m.XQNode.AND(m.XQNode.AND(a, b), c),
+             # quorum operator: threshold 1 = OR chain, threshold >= words = AND chain (searchnode.cpp:1638-1686)
+             m.XQNode(m.SPH_QUERY_QUORUM, [a, b, c], None, 0xFFFFFFFF, 1), m.XQNode(m.SPH_QUERY_QUORUM, [c, a, b], None, 0b011, 3),
+             m.XQNode(m.SPH_QUERY_QUORUM, [b, d], None, 0xFFFFFFFF, 5), m.XQNode(m.SPH_QUERY_QUORUM, [a, kw(m, nt - 1, 2)], None, 0xFFFFFFFF, 1)]
     qs = []
     for root in fixed:
         for rk in (m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_PROXIMITY_BM25):
@@ -724,11 +727,11 @@ def test_golden_vectors_on_device(dev):
     rankers = {"proximity_bm25": m.SPH_RANK_PROXIMITY_BM25, "bm25": m.SPH_RANK_BM25, "none": m.SPH_RANK_NONE,
                "wordcount": m.SPH_RANK_WORDCOUNT, "sph04": m.SPH_RANK_SPH04}
     ops = {"and": m.SPH_QUERY_AND, "or": m.SPH_QUERY_OR, "andnot": m.SPH_QUERY_ANDNOT, "phrase": m.SPH_QUERY_PHRASE,
-           "proximity": m.SPH_QUERY_PROXIMITY}
+           "proximity": m.SPH_QUERY_PROXIMITY, "quorum": m.SPH_QUERY_QUORUM}
 
     def tree(v, q):
         if "word" in q:
-            return kw(m, v[q["word"]], q["pos"], q["mask"])
+            return kw(m, v.get(q["word"], -1), q["pos"], q["mask"])  # -1: keyword not in the dictionary
         return m.XQNode(ops[q["op"]], [tree(v, k) for k in q["kids"]], None, q["mask"], q.get("opt", 0))
 
     n_ok = 0

@@ -190,7 +190,7 @@ def test_dead_rows_skip_the_sorter(orc):
 # ------------------------------------------------------------------ tests/golden/reference_vectors.json, every case
 def _golden_tree(orc, v, q):
     if "word" in q:
-        return orc.term(v[q["word"]], q["pos"], field_mask=q["mask"])
+        return orc.term(v.get(q["word"], -1), q["pos"], field_mask=q["mask"])  # -1: keyword not in the dictionary
     return orc.op(getattr(orc, "OP_" + q["op"].upper()), *[_golden_tree(orc, v, k) for k in q["kids"]], field_mask=q["mask"],
                   opt=q.get("opt", 0))
 
