@@ -88,6 +88,7 @@ def main() -> None:
     ap.add_argument("--latency-samples", type=int, default=96)
     ap.add_argument("--strata", default="cc,sc,ss", help="subset of strata to run (profiling aid; the metric uses all three)")
     ap.add_argument("--path", type=int, default=0, help="0 = packed doclists (default), 1 = VLB-direct")
+    ap.add_argument("--no-config3", action="store_true", help="skip the extra 3-term AND/OR mix leg (BASELINE config 3)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -369,6 +370,40 @@ def main() -> None:
     }
 
     out["host_ms_per_step"] = {k_: round(v / max(1, host_ms["n"]), 4) for k_, v in host_ms.items() if k_ != "n"}
+    # BASELINE config 3 on the same corpus, outside the timed region: 3-term mixes a b c / (a|b) c / a (b|c) / a b -c under
+    # SPH_RANK_PROXIMITY_BM25 (hitlist decode); a = selective keyword, b and c = common ones.  Extra information only.
+    if rank == 0 and world == 1 and not sharded and not args.no_config3 and args.path == 0 and set(names) == {"cc", "sc", "ss"}:
+        OR_, ANDNOT_ = m.SPH_QUERY_OR, m.SPH_QUERY_ANDNOT
+        c3 = []
+        for i in range(nq):
+            a_, b_ = strata["sc"][i]
+            c_ = strata["cc"][i][0] if strata["cc"][i][0] != b_ else strata["cc"][i][1]
+            ka, kb, kc = kw(a_, 1), kw(b_, 2), kw(c_, 3)
+            root = [m.XQNode.AND(ka, kb, kc), m.XQNode.AND(m.XQNode(OR_, [ka, kb]), kc), m.XQNode.AND(ka, m.XQNode(OR_, [kb, kc])),
+                    m.XQNode(ANDNOT_, [m.XQNode.AND(ka, kb), kc])][i % 4]
+            c3.append(m.Query(root, ranker=m.SPH_RANK_PROXIMITY_BM25, max_matches=K, total_docs=int(total_docs),
+                              local_docs={t: int(global_docs[t]) for t in (a_, b_, c_)}))
+        cq3 = m.prepare(c3)
+        b3 = [m.Batch(ctx, nq), m.Batch(ctx, nq)]
+        for bb in b3:
+            bb.submit_prepared(seg, cq3, nq)
+            bb.wait()
+        t3 = time.perf_counter()
+        reps = 6
+        for i in range(reps):
+            b3[i % 2].wait()
+            b3[i % 2].submit_prepared(seg, cq3, nq)
+        for bb in b3:
+            bb.wait()
+        dt3 = time.perf_counter() - t3
+        st3 = b3[0].stats()
+        res3 = b3[0].results()
+        out["config3"] = {"workload": f"{nq} queries/launch: a b c | (a|b) c | a (b|c) | a b -c, SPH_RANK_PROXIMITY_BM25, top-{K}",
+                          "queries_per_s": round(reps * nq / dt3, 1), "scan_ms": round(st3["scan_ms"], 4),
+                          "merge_ms": round(st3["merge_ms"], 4), "algo_MB": round(st3["algo_bytes"] / 1e6, 2),
+                          "ok": int(sum(r.status == 0 for r in res3)), "matches": int(sum(r.total_found for r in res3))}
+        for bb in b3:
+            bb.close()
     if merger is not None and merger.timing:
         out["dist_timing_ms_per_call"] = {k_: round(v / max(1, merger.timing["calls"]), 4) for k_, v in merger.timing.items() if k_ != "calls"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/traffic
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline --latency-samples 0 --strata cc"
+ARGS="$ROOT/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline --no-config3 --latency-samples 0 --strata cc"
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o w -- python3 $ARGS > $OUT/write.log 2>&1
 python3 - <<PY
