@@ -24,6 +24,7 @@ namespace mrk {
 #define MRK_CBUF 128
 #endif
 constexpr int CBUF = MRK_CBUF; // candidates a wave collects before it publishes them
+constexpr int MQCAP = 128;     // matched docs a wave queues for the hit pass (processed 64 at a time)
 
 template <bool PROX, bool TREE>
 struct __align__(16) PkWaveLds {
@@ -33,6 +34,12 @@ struct __align__(16) PkWaveLds {
   uint32_t tj_rowid[DEVBLK];
   uint32_t tj_attr[64];
   // boolean trees: what each keyword contributes to each doc of the driver block (tfidf term, field bits)
+  // hit rankers / PHRASE: matched docs wait here until 64 of them can go through the hit pass with every lane busy
+  // (row, tfidf sum, fields | contributing keywords << 8, one hit reference per keyword)
+  uint32_t mq_row[PROX ? MQCAP : 1];
+  float mq_acc[PROX ? MQCAP : 1];
+  uint32_t mq_fa[PROX ? MQCAP : 1];
+  uint32_t mq_ref[PROX ? MAX_PROX_TERMS : 1][PROX ? MQCAP : 1];
   float kv[TREE ? MRK_MAX_AND_TERMS : 1][TREE ? DEVBLK : 4];
   uint8_t kf[TREE ? MRK_MAX_AND_TERMS : 1][TREE ? DEVBLK : 16];
   union {
@@ -389,11 +396,8 @@ struct HitCtx {
   const uint8_t* spp;
   const uint32_t* hit;    // DevSegment::pk_hit
   const uint64_t* hbase;  // DevSegment::pk_hbase
-  const uint32_t* href;   // this wave's [MAX_PROX_TERMS - 1][DEVBLK] hit references of the non-driver keywords
   uint32_t* flags;        // the query's flag word
-  uint32_t blk0;          // global index of the driver block
-  uint32_t attr0;         // the lane's driver attr word
-  uint32_t lane, nterms, nw;
+  uint32_t nterms, nw;
   uint32_t ap0, ap1, ap2, ap3;
   uint32_t nph, span;     // the query's phrase: words, distance between its first and last query position
   uint32_t px_dist;       // 0 = exact PHRASE, else the PROXIMITY operator's distance ('"a b"~N')
@@ -403,10 +407,11 @@ struct HitCtx {
   bool inline_hits, multi_and;
 };
 
-// One doc's hit pass.  smask = keyword slots whose hits take part, pmask = slots forming the phrase (0 = none),
-// rank = feed RankerState_Proximity_fn (else: stop at the first phrase occurrence).
-__device__ __forceinline__ void hit_pass(const HitCtx& C, int r, uint32_t smask, uint32_t pmask, bool rank, bool& ph_found,
-                                         uint32_t& ph_field, int& rk_out) {
+// One doc's hit pass.  ref0..ref3 = where the doc sits in each keyword's packed arrays (block within the keyword << 7 |
+// slot, bit 31 = its one hit was inlined), smask = keyword slots whose hits take part, pmask = slots forming the
+// phrase (0 = none), rank = feed the state ranker (else: stop at the first phrase occurrence).
+__device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_t ref1, uint32_t ref2, uint32_t ref3, uint32_t smask,
+                                         uint32_t pmask, bool rank, bool& ph_found, uint32_t& ph_field, int& rk_out) {
   // .spp cursor (0 = inlined hit / exhausted), current Hitpos_t (0 = exhausted), query position, field limit
   uint64_t sp[MAX_PROX_TERMS];
   uint32_t sc[MAX_PROX_TERMS], sq[MAX_PROX_TERMS], sm[MAX_PROX_TERMS];
@@ -415,18 +420,9 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, int r, uint32_t smask,
     sp[t] = 0, sc[t] = 0, sq[t] = 0, sm[t] = 0;
     if ((uint32_t)t < C.nterms && ((smask >> t) & 1u)) {
       const DevTerm& Tt = C.Q->t[t];
-      uint32_t gblk, idx;
-      bool lone;
-      if (t == 0) {
-        gblk = C.blk0;
-        idx = C.lane + 64 * r;
-        lone = C.inline_hits && ((C.attr0 >> (8 * r)) & 0xffu) == 1u;
-      } else {
-        const uint32_t h = C.href[(t - 1) * DEVBLK + C.lane + 64 * r];
-        gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu);
-        idx = h & 127u;
-        lone = (h >> 31) != 0;
-      }
+      const uint32_t h = t == 0 ? ref0 : t == 1 ? ref1 : t == 2 ? ref2 : ref3;
+      const uint32_t gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu), idx = h & 127u;
+      const bool lone = (h >> 31) != 0;
       sq[t] = Tt.qpos;
       sm[t] = Tt.queried32;
       const uint32_t hv = C.hit[(uint64_t)gblk * DEVBLK + idx];
@@ -553,6 +549,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const uint32_t ph_mask = ph_leaf ? Q->ph_mask : 0u;                         // its words' keyword slots
   const uint32_t ph_n = !PROX ? 0u : phrase ? nterms : (uint32_t)__popc(ph_mask);
   const uint32_t ph_span = !PROX || ph_n < 2 ? 0u : Q->ph_atoms[ph_n - 1] - Q->ph_atoms[0];
+  const bool need_hits = PROX && (prox_ranker || phrase); // matches go through the hit pass before they are weighed
   const bool multi_and = (!TREE || (Q->tree_flags & TF_MULTIAND) != 0) && !phrase;
   // PHRASE: query positions of its words in phrase order (FSMphrase_c::m_dAtomPos, searchnode.cpp:3884-3899)
   const uint32_t ap0 = PROX ? Q->ph_atoms[0] : 0u, ap1 = PROX ? Q->ph_atoms[1] : 0u, ap2 = PROX ? Q->ph_atoms[2] : 0u,
@@ -641,6 +638,93 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
     }
     const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gt > tau_bin) tau_bin = gt;
+  };
+
+  const uint32_t rowid_base = a.seg.rowid_base;
+  // one match: weight, pruning bin, candidate buffer (all lanes call it; live = this lane holds a match)
+  auto emit_match = [&](bool is_live, uint32_t rowid, float tfidf, uint32_t fields, int rk) {
+    bool push = false;
+    uint64_t key = 0;
+    if (is_live) {
+      ++total;
+      uint32_t weight;
+      if (ranker == MRK_RANK_NONE)
+        weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
+      else if (PROX && prox_ranker) {
+        // Finalize() of the state rankers, e.g. RankerState_Proximity_fn sphinxsearch.cpp:1415-1437
+        const int32_t bm = (int32_t)((tfidf + 0.5f) * 1000.0f);
+        weight = (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_SPH04) ? (uint32_t)bm + (uint32_t)rk * 1000u : (uint32_t)rk;
+      } else if (ranker == MRK_RANK_PROXIMITY) {
+        weight = s.rank[fields]; // single keyword: ExtRanker_WeightSum_c<> without BM25 (sphinxsearch.cpp:4216-4217, 1131)
+      } else {
+        // ExtRanker_WeightSum_c<BM25>, sphinxsearch.cpp:1070, 1112-1129
+        const int32_t bm = (int32_t)((tfidf + 0.5f) * 1000.0f);
+        weight = (uint32_t)bm + s.rank[fields] * 1000u;
+      }
+      weight *= index_weight; // MatchExtended, sphinx.cpp:12220
+      const uint32_t grow = rowid_base + rowid;
+      const uint32_t bin = bin_of(bin_mode, bin_lo, bin_shift, (int32_t)weight, grow);
+#if MRK_EXP != 1 && MRK_EXP != 6 && MRK_EXP != 7
+      if (bin >= tau_bin) {
+        push = true;
+        key = make_key((int32_t)weight, grow);
+      }
+#endif
+    }
+    const uint64_t bal = __ballot(push);
+    if (bal) {
+      const uint32_t n = (uint32_t)__popcll(bal);
+      if (cn + n > (uint32_t)CBUF) publish(); // keys pushed under the older threshold stay valid candidates
+      if (push) L.cbuf[cn + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+      cn += n;
+      if (cn >= flush_at) {
+        publish();
+        flush_at = CBUF - 64;
+      }
+    }
+  };
+
+  // hit pass over queued matches [from, from + n), n <= 64, one per lane
+  uint32_t mqn = 0;
+  HitCtx HC;
+  HC.Q = Q;
+  HC.spp = a.seg.spp;
+  HC.hit = a.seg.pk_hit;
+  HC.hbase = a.seg.pk_hbase;
+  HC.flags = a.q_flags + oq;
+  HC.nterms = nterms, HC.nw = nw;
+  HC.ap0 = ap0, HC.ap1 = ap1, HC.ap2 = ap2, HC.ap3 = ap3;
+  HC.nph = ph_n, HC.span = ph_span;
+  HC.px_dist = PROX ? Q->px_dist : 0u;
+  HC.ranker = ranker;
+  HC.w_of = s.rank;
+  HC.max_qpos = (int)Q->max_qpos, HC.n_qwords = (int)Q->n_qwords;
+  HC.inline_hits = inline_hits, HC.multi_and = multi_and;
+  auto drain_hits = [&](uint32_t from, uint32_t n) {
+    if (!PROX) return;
+    wave_lds_fence();
+    const bool valid = lane < n;
+    const uint32_t e = from + (valid ? lane : 0u);
+    const uint32_t rowid = L.mq_row[e], fa = L.mq_fa[e];
+    const float tfidf = L.mq_acc[e];
+    const uint32_t r0 = L.mq_ref[0][e], r1 = L.mq_ref[1][e], r2 = L.mq_ref[2][e], r3 = L.mq_ref[3][e];
+    wave_lds_fence(); // the slots may be refilled from here on
+    bool is_live = valid;
+    uint32_t fields = fa & 0xffu;
+    int rk = 0;
+    if (valid) {
+      const uint32_t all_slots = (1u << (nterms < (uint32_t)MAX_PROX_TERMS ? nterms : (uint32_t)MAX_PROX_TERMS)) - 1u;
+      const uint32_t smask = (fa >> 8) & all_slots;
+      const uint32_t pmask = phrase ? all_slots : (ph_leaf && (smask & ph_mask) == ph_mask) ? ph_mask : 0u;
+      bool found = false;
+      uint32_t ffield = 0;
+      hit_pass(HC, r0, r1, r2, r3, smask, pmask, prox_ranker, found, ffield, rk);
+      if (phrase) {
+        is_live = found;
+        fields = 1u << ffield; // the doc's field mask comes from its first occurrence (searchnode.cpp:3836)
+      }
+    }
+    emit_match(is_live, rowid, tfidf, fields, rk);
   };
 
   for (uint32_t b = wb0; b < wb1; ++b) {
@@ -952,27 +1036,6 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         }
       }
 
-      // ---- one doc's hit pass.  smask = keyword slots whose hits take part, pmask = slots forming the phrase
-      // (0 = none), rank = feed RankerState_Proximity_fn (else: stop at the first phrase occurrence).
-      // ---- hit pass context (values only; see hit_pass)
-      HitCtx C;
-      C.Q = Q;
-      C.spp = a.seg.spp;
-      C.hit = a.seg.pk_hit;
-      C.hbase = a.seg.pk_hbase;
-      C.href = &L.href[0][0];
-      C.flags = a.q_flags + oq;
-      C.blk0 = T0.blk_first + b;
-      C.attr0 = cur0.attr;
-      C.lane = lane, C.nterms = nterms, C.nw = nw;
-      C.ap0 = ap0, C.ap1 = ap1, C.ap2 = ap2, C.ap3 = ap3;
-      C.nph = ph_n, C.span = ph_span;
-      C.px_dist = Q->px_dist;
-      C.ranker = ranker;
-      C.w_of = s.rank;
-      C.max_qpos = (int)Q->max_qpos, C.n_qwords = (int)Q->n_qwords;
-      C.inline_hits = inline_hits, C.multi_and = multi_and;
-
       // ---- a PHRASE below other operators: whether it occurs has to be known before the tree is evaluated
       bool ph_ok[2] = {false, false};
       uint32_t ph_fld[2] = {0u, 0u};
@@ -982,7 +1045,9 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         for (int r = 0; r < 2; ++r)
           if (live[r] && (pres[r] & ph_mask) == ph_mask) {
             int unused = 0;
-            hit_pass(C, r, ph_mask, ph_mask, false, ph_ok[r], ph_fld[r], unused);
+            const uint32_t dref = ((inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u) ? 0x80000000u : 0u) | (b << 7) | (lane + 64 * r);
+            hit_pass(HC, dref, L.href[0][lane + 64 * r], L.href[1][lane + 64 * r], L.href[2][lane + 64 * r], ph_mask, ph_mask, false,
+                     ph_ok[r], ph_fld[r], unused);
           }
       }
 
@@ -1058,75 +1123,39 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         for (int r = 0; r < 2; ++r)
           if (live[r] && row_is_dead(a.seg, row[r])) live[r] = false;
       }
-      // ---- hit rankers / PHRASE: per matched doc merge the keywords' hit streams by (hitpos, qpos)
-      // (MergeHits2/3/N, searchnode.cpp:3047-3181; ExtAnd_c / ExtOr_c::CollectHits) and run
-      // RankerState_Proximity_fn (sphinxsearch.cpp:1351-1437).  The words of a PHRASE go through FSMphrase_c first:
-      // to the ranker the phrase is one more stream, of folded hits.
-      int prank[2] = {0, 0};
-      if (PROX && (prox_ranker || phrase)) {
-        wave_lds_fence();
+      // ---- matches.  Hit rankers / PHRASE: per matched doc the keywords' hit streams are merged by (hitpos, qpos)
+      // (MergeHits2/3/N, searchnode.cpp:3047-3181; ExtAnd_c / ExtOr_c::CollectHits) and fed to the state ranker
+      // (sphinxsearch.cpp:1351-1668); the words of a PHRASE go through their state machine first -- to the ranker the
+      // phrase is one more stream, of folded hits.  That pass is a chain of dependent loads per doc, so matched docs
+      // are queued and go through it 64 at a time, one per lane, instead of the few a single driver block holds.
+      if (PROX && need_hits) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          if (live[r]) {
-            const uint32_t all_slots = (1u << (nterms < (uint32_t)MAX_PROX_TERMS ? nterms : (uint32_t)MAX_PROX_TERMS)) - 1u;
-            const uint32_t smask = TREE ? act[r] & all_slots : all_slots;
-            const uint32_t pmask = phrase ? all_slots : (ph_leaf && (smask & ph_mask) == ph_mask) ? ph_mask : 0u;
-            bool found = false;
-            uint32_t ffield = 0;
-            hit_pass(C, r, smask, pmask, prox_ranker, found, ffield, prank[r]);
-            if (phrase) {
-              live[r] = found;
-              fld[r] = 1u << ffield; // the doc's field mask comes from its first occurrence (searchnode.cpp:3836)
+          const uint64_t bal = __ballot(live[r]);
+          if (bal) {
+            if (live[r]) {
+              const uint32_t pos = mqn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+              L.mq_row[pos] = row[r];
+              L.mq_acc[pos] = acc[r];
+              L.mq_fa[pos] = (fld[r] & 0xffu) | ((TREE ? act[r] : 0xffu) << 8);
+              L.mq_ref[0][pos] = ((inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u) ? 0x80000000u : 0u) | (b << 7) | (lane + 64 * r);
+#pragma unroll
+              for (int t = 1; t < MAX_PROX_TERMS; ++t) L.mq_ref[t][pos] = L.href[t - 1][lane + 64 * r];
+            }
+            mqn += (uint32_t)__popcll(bal);
+            if (mqn >= 64u) {
+              drain_hits(mqn - 64u, 64u);
+              mqn -= 64u;
             }
           }
         }
-      }
-      // ---- matches: weight, pruning bin, candidates
+      } else {
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        bool push = false;
-        uint64_t key = 0;
-        if (live[r]) {
-          ++total;
-          uint32_t weight;
-          if (ranker == MRK_RANK_NONE)
-            weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
-          else if (PROX && prox_ranker) {
-            // RankerState_Proximity_fn::Finalize, sphinxsearch.cpp:1415-1437
-            const int32_t bm = (int32_t)((acc[r] + 0.5f) * 1000.0f);
-            weight = (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_SPH04) ? (uint32_t)bm + (uint32_t)prank[r] * 1000u
-                                                                                   : (uint32_t)prank[r];
-          } else if (ranker == MRK_RANK_PROXIMITY) {
-            weight = s.rank[fld[r]]; // single keyword: ExtRanker_WeightSum_c<> without BM25 (sphinxsearch.cpp:4216-4217, 1131)
-          } else {
-            // ExtRanker_WeightSum_c<BM25>, sphinxsearch.cpp:1070, 1112-1129
-            const int32_t bm = (int32_t)((acc[r] + 0.5f) * 1000.0f);
-            weight = (uint32_t)bm + s.rank[fld[r]] * 1000u;
-          }
-          weight *= index_weight; // MatchExtended, sphinx.cpp:12220
-          const uint32_t grow = a.seg.rowid_base + row[r];
-          const uint32_t bin = bin_of(bin_mode, bin_lo, bin_shift, (int32_t)weight, grow);
-#if MRK_EXP != 1 && MRK_EXP != 6 && MRK_EXP != 7
-          if (bin >= tau_bin) {
-            push = true;
-            key = make_key((int32_t)weight, grow);
-          }
-#endif
-        }
-        const uint64_t bal = __ballot(push);
-        if (bal) {
-          const uint32_t n = (uint32_t)__popcll(bal);
-          if (cn + n > (uint32_t)CBUF) publish(); // keys pushed under the older threshold stay valid candidates
-          if (push) L.cbuf[cn + __popcll(bal & ((1ull << lane) - 1ull))] = key;
-          cn += n;
-          if (cn >= flush_at) {
-            publish();
-            flush_at = CBUF - 64;
-          }
-        }
+        for (int r = 0; r < 2; ++r) emit_match(live[r], row[r], acc[r], fld[r], 0);
       }
     }
   }
+  if (PROX && mqn) drain_hits(0u, mqn);
 
   // ---- wave epilogue
   if (cn) publish();
