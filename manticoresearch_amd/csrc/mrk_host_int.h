@@ -1,0 +1,74 @@
+// mrk_host_int.h -- host-side objects shared by mrk_host.cpp (segments, batches, C-ABI) and mrk_plan.cpp (query planner).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "mrk_dev.h"
+
+int mrk_fail(int code, const char* fmt, ...);
+
+using mrk::DevItem;
+using mrk::DevQuery;
+using mrk::DevSegment;
+using mrk::DevTerm;
+
+struct mrk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t merge_stream = nullptr; // mrk_topk_merge: never queued behind the scans of a following batch
+  hipEvent_t merge_done[MRK_MERGE_SLOTS] = {};
+  bool merge_used[MRK_MERGE_SLOTS] = {};
+  int64_t item_bytes = 128 << 10; // target doclist bytes per work item
+  int path = 0;                   // 0 = packed doclists when the segment has them, 1 = VLB (.spd) direct, 2 = packed only
+  int pack = 1;                   // build packed doclists at segment load
+  int bitmap_inv = 64;            // terms in >= 1/bitmap_inv of the docs also get a bitmap (0 = never)
+  int bm_target_items = 6144;     // bitmap kernel: work items per launch the window ranges are cut into
+};
+
+struct HostTerm {
+  uint64_t doclist_off = 0, doclist_len = 0;
+  uint64_t packed_bytes = 0;
+  uint32_t blk_first = 0, nblocks = 0, docs = 0, hits = 0;
+  uint32_t exc_first = 0, exc_n = 0;
+  uint64_t bm_off = ~0ull, dir_off = ~0ull; // word offsets of the term's bitmap / rank directory, ~0 = none
+};
+
+struct mrk_segment {
+  mrk_ctx* ctx = nullptr;
+  DevSegment dev{};
+  std::vector<HostTerm> terms;
+  uint64_t total_docs = 0;
+  uint32_t n_fields = 0;
+  uint64_t device_bytes = 0;
+  void* d_spd = nullptr;
+  void* d_spp = nullptr;
+  void* d_blk_base = nullptr;
+  void* d_blk_off = nullptr;
+  void* d_blk_hit = nullptr;
+  bool has_packed = false;
+  void* d_pk_base = nullptr;
+  void* d_pk_doff = nullptr;
+  void* d_pk_w = nullptr;
+  void* d_pk_delta = nullptr;
+  void* d_pk_attr = nullptr;
+  void* d_pk_exc = nullptr;
+  void* d_pk_hit = nullptr;
+  void* d_pk_hbase = nullptr;
+  void* d_dead = nullptr;
+  void* d_bm = nullptr;
+  void* d_bm_dir = nullptr;
+};
+
+namespace mrk {
+
+// Plans one query of a batch: validates it, builds the reference-shaped evaluation tree, computes IDFs, pruning
+// histogram geometry and candidate capacity, and emits the query's passes and work items.  Returns MRK_OK, or
+// MRK_E_UNSUPPORTED / MRK_E_INVAL with the message set.  dq = the query's head pass (index qi); further passes go to
+// `extra` and get pass indices n_queries + position; bitmap-kernel work goes to items_bm as one whole-range entry.
+int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
+               std::vector<DevQuery>& extra, uint32_t n_queries, std::vector<DevItem>& items, std::vector<DevItem>& items_bm,
+               uint32_t qi, uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out);
+
+} // namespace mrk

@@ -1,0 +1,550 @@
+// mrk_plan.cpp -- the query planner: mrk_query (flattened XQNode_t tree + ranker knobs) -> device passes and work
+// items.  Mirrors what sphCreateRanker / ExtNode_i::Create decide on the host in the reference
+// (sphinxsearch.cpp:4167-4378, searchnode.cpp:1599-1811).
+#include "mrk_host_int.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+using namespace mrk;
+
+// planner: mrk_query -> DevQuery + work items
+// ----------------------------------------------------------------------------------------
+struct PlanKw { // one keyword occurrence of the query tree
+  int32_t term_id;
+  int32_t node;
+  int docs;
+  float boost, idf;
+  uint32_t queried32;
+  int atom_pos;
+  bool weighted_first; // first node of its word in GetQwords order gets the IDF, later dupes get 0
+};
+
+struct PlanNode { // binary eval-tree node, post-order
+  uint32_t op;
+  int l = -1, r = -1, kw = -1;
+};
+
+struct PlanTree {
+  std::vector<PlanKw> kws;     // in GetQwords traversal order
+  std::vector<PlanNode> nodes; // post-order; root = last
+  bool multiand3_inner = false; // a 3-keyword ExtMultiAnd_T below the root (MergeHits3 quirk not restated there)
+  bool phrase = false;          // root is a PHRASE (ExtNWay_T<FSMphrase_c>)
+  bool ph_leaf = false;         // one PHRASE below other operators; its words are kws[ph_kw0 .. ph_kw0 + ph_n)
+  int ph_kw0 = 0, ph_n = 0;
+  int px_dist = 0;              // > 0: the phrase node is a PROXIMITY operator ('"a b"~N')
+  bool force_tree = false;      // the query must run as a tree program even if it only holds TERM / AND nodes
+  std::vector<int> atoms;       // its words' query positions, phrase order
+};
+
+// Mirrors ExtNode_i::Create (searchnode.cpp:1599-1811) for the operators the device path knows:
+// AND over plain keywords -> ExtMultiAnd_T (nodes sorted by ascending docs with sphSort's small-array
+// insertion sort, sphinxstd.h:853-869: equal keys end in reverse arrival order); other AND / OR / MAYBE /
+// ANDNOT -> left-deep chains in child order (searchnode.cpp:1785-1806).  An N-way MultiAnd is emitted as
+// a left-deep AND chain: ((0+t0)+t1)+t2 and (t0+t1)+t2 are the same fp32 value.
+static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, PlanTree& T, uint32_t qi, int depth, bool is_root, int& err) {
+  if (ni < 0 || ni >= q.n_nodes || depth > 16) return err = mrk_fail(MRK_E_INVAL, "query %u: bad tree", qi), -1;
+  const mrk_node& n = q.nodes[ni];
+  auto leaf = [&](int32_t li) -> int {
+    const mrk_node& t = q.nodes[li];
+    PlanKw k{};
+    k.term_id = t.term_id;
+    k.node = li;
+    k.docs = (t.term_id >= 0 && (uint32_t)t.term_id < seg->terms.size()) ? (int)seg->terms[t.term_id].docs : 0;
+    k.boost = t.boost;
+    k.queried32 = t.field_mask;
+    k.atom_pos = t.atom_pos;
+    T.kws.push_back(k);
+    PlanNode pn;
+    pn.op = PN_TERM;
+    pn.kw = (int)T.kws.size() - 1;
+    T.nodes.push_back(pn);
+    return (int)T.nodes.size() - 1;
+  };
+  auto join = [&](uint32_t op, int l, int r) -> int {
+    PlanNode pn;
+    pn.op = op;
+    pn.l = l;
+    pn.r = r;
+    T.nodes.push_back(pn);
+    return (int)T.nodes.size() - 1;
+  };
+  if (n.op == MRK_OP_TERM) return leaf(ni);
+  const bool nway = n.op == MRK_OP_PHRASE || n.op == MRK_OP_PROXIMITY; // ExtNWay_T<FSMphrase_c / FSMproximity_c>
+  if (nway && (T.phrase || T.ph_leaf))
+    return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: more than one PHRASE (device path: one per query)", qi), -1;
+  if (n.op == MRK_OP_QUORUM) {
+    // ExtNode_i::Create, SPH_QUERY_QUORUM (searchnode.cpp:1638-1686): threshold 1 = an ExtOr_c chain, threshold >= word
+    // count = an ExtAnd_c chain, both over the words sorted by ascending doc count; a real ExtQuorum_c in between
+    if (n.n_children < 2 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
+    if (n.opt != 1 && n.opt < n.n_children)
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum %d of %d (ExtQuorum_c) is not on the device path", qi, n.opt, n.n_children), -1;
+    std::vector<int32_t> kids(n.n_children);
+    std::vector<int> ord(n.n_children), docs(n.n_children);
+    for (int i = 0; i < n.n_children; ++i) {
+      kids[i] = q.children[n.first_child + i];
+      if (kids[i] < 0 || kids[i] >= q.n_nodes || q.nodes[kids[i]].op != MRK_OP_TERM)
+        return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum over plain keywords only", qi), -1;
+      const mrk_node& t = q.nodes[kids[i]];
+      docs[i] = (t.term_id >= 0 && (uint32_t)t.term_id < seg->terms.size()) ? (int)seg->terms[t.term_id].docs : 0;
+      ord[i] = i;
+    }
+    for (int i = 1; i < n.n_children; ++i)
+      for (int j = i; j > 0; --j) {
+        if (docs[ord[j - 1]] < docs[ord[j]]) break;
+        std::swap(ord[j], ord[j - 1]);
+      }
+    const size_t kw0 = T.kws.size();
+    int cur = leaf(kids[ord[0]]);
+    for (int i = 1; i < n.n_children; ++i) {
+      const int r = leaf(kids[ord[i]]);
+      cur = join(n.opt == 1 ? PN_OR : PN_AND, cur, r);
+    }
+    for (size_t k = kw0; k < T.kws.size(); ++k) T.kws[k].queried32 &= n.field_mask; // Create ( word, pNode, .. )
+    T.force_tree = true; // an ExtAnd_c chain is not an ExtMultiAnd_T (no MergeHits3 quirk): always the tree program
+    return cur;
+  }
+  if (!nway && n.op != MRK_OP_AND && n.op != MRK_OP_OR && n.op != MRK_OP_MAYBE && n.op != MRK_OP_ANDNOT)
+    return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, n.op), -1;
+  if (n.n_children < 1 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
+  std::vector<int32_t> kids(n.n_children);
+  bool all_terms = true;
+  for (int i = 0; i < n.n_children; ++i) {
+    kids[i] = q.children[n.first_child + i];
+    if (kids[i] < 0 || kids[i] >= q.n_nodes) return err = mrk_fail(MRK_E_INVAL, "query %u: child index out of range", qi), -1;
+    all_terms &= q.nodes[kids[i]].op == MRK_OP_TERM;
+  }
+  if (nway) {
+    if (n.op == MRK_OP_PROXIMITY) {
+      if (n.opt <= 0 || n.opt > (1 << 20)) return err = mrk_fail(MRK_E_INVAL, "query %u: proximity distance %d", qi, n.opt), -1;
+      T.px_dist = n.opt;
+    }
+    // CreateMultiNode<ExtPhrase_c / ExtProximity_c> (searchnode.cpp:984-1041): plain keywords only; ExtNWay_T::ConstructNode
+    // (:3767-3787) chains them left-deep in ascending doc-count order, so docs / tfidf come out as for a MultiAnd
+    if (!all_terms || n.n_children < 2 || n.n_children > MAX_PROX_TERMS)
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE of %d nodes (device path: 2..%d plain keywords)", qi, n.n_children,
+                            MAX_PROX_TERMS), -1;
+    (is_root ? T.phrase : T.ph_leaf) = true;
+    for (int i = 0; i < n.n_children; ++i) {
+      T.atoms.push_back(q.nodes[kids[i]].atom_pos);
+      if (i && T.atoms[i] <= T.atoms[i - 1]) return err = mrk_fail(MRK_E_INVAL, "query %u: phrase atom positions must ascend", qi), -1;
+    }
+    if (T.atoms.back() - T.atoms.front() >= PHRASE_STATES)
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: phrase spans %d positions (device path: < %d)", qi,
+                            T.atoms.back() - T.atoms.front(), PHRASE_STATES), -1;
+  }
+  if ((n.op == MRK_OP_AND || nway) && all_terms && n.n_children > 1) {
+    std::vector<int> ord(n.n_children), docs(n.n_children);
+    for (int i = 0; i < n.n_children; ++i) {
+      const mrk_node& t = q.nodes[kids[i]];
+      docs[i] = (t.term_id >= 0 && (uint32_t)t.term_id < seg->terms.size()) ? (int)seg->terms[t.term_id].docs : 0;
+      ord[i] = i;
+    }
+    for (int i = 1; i < n.n_children; ++i)
+      for (int j = i; j > 0; --j) {
+        if (docs[ord[j - 1]] < docs[ord[j]]) break;
+        std::swap(ord[j], ord[j - 1]);
+      }
+    if (n.op == MRK_OP_AND && n.n_children == 3 && !is_root) T.multiand3_inner = true;
+    const int kw0 = (int)T.kws.size();
+    int cur = leaf(kids[ord[0]]);
+    for (int i = 1; i < n.n_children; ++i) {
+      const int r = leaf(kids[ord[i]]);
+      cur = join(PN_AND, cur, r);
+    }
+    if (nway) { // the words are created with the phrase node's field limit (searchnode.cpp:1020-1024)
+      for (size_t k = (size_t)kw0; k < T.kws.size(); ++k) T.kws[k].queried32 &= n.field_mask;
+      if (!is_root) { // ExtNWay_T on top of the words' AND chain: keeps the docs where the words line up
+        T.ph_kw0 = kw0;
+        T.ph_n = n.n_children;
+        PlanNode pn;
+        pn.op = PN_PHRASEFIX;
+        pn.l = cur;
+        T.nodes.push_back(pn);
+        cur = (int)T.nodes.size() - 1;
+      }
+    }
+    return cur;
+  }
+  const uint32_t op = n.op == MRK_OP_AND ? PN_AND : n.op == MRK_OP_OR ? PN_OR : n.op == MRK_OP_MAYBE ? PN_MAYBE : PN_ANDNOT;
+  int cur = -1;
+  for (int i = 0; i < n.n_children; ++i) {
+    const int c = build_tree(seg, q, kids[i], T, qi, depth + 1, false, err);
+    if (c < 0) return -1;
+    cur = cur < 0 ? c : join(op, cur, c);
+  }
+  return cur;
+}
+
+// keywords whose doc streams together contain every possible match of the subtree
+static void cover_of(const PlanTree& T, int ni, std::vector<int>& out) {
+  const PlanNode& n = T.nodes[ni];
+  if (n.op == PN_TERM) {
+    out.push_back(n.kw);
+    return;
+  }
+  if (n.op == PN_OR) {
+    cover_of(T, n.l, out);
+    cover_of(T, n.r, out);
+    return;
+  }
+  if (n.op == PN_AND) {
+    std::vector<int> a, b;
+    cover_of(T, n.l, a);
+    cover_of(T, n.r, b);
+    uint64_t ca = 0, cb = 0;
+    for (int k : a) ca += (uint64_t)T.kws[k].docs;
+    for (int k : b) cb += (uint64_t)T.kws[k].docs;
+    const std::vector<int>& w = (cb < ca || (cb == ca && b.size() < a.size())) ? b : a;
+    out.insert(out.end(), w.begin(), w.end());
+    return;
+  }
+  cover_of(T, n.l, out); // MAYBE, ANDNOT, PHRASEFIX: the left side carries the docs
+}
+
+// keywords that must be present for the subtree to match
+static uint32_t required_of(const PlanTree& T, int ni) {
+  const PlanNode& n = T.nodes[ni];
+  if (n.op == PN_TERM) return 1u << n.kw;
+  if (n.op == PN_AND) return required_of(T, n.l) | required_of(T, n.r);
+  if (n.op == PN_OR) return required_of(T, n.l) & required_of(T, n.r);
+  return required_of(T, n.l);
+}
+
+static void fill_term(const mrk_segment* seg, const PlanKw& k, DevTerm& dt) {
+  memset(&dt, 0, sizeof dt);
+  dt.queried32 = k.queried32;
+  dt.idf = k.weighted_first ? k.idf : 0.0f;
+  dt.qpos = (uint32_t)k.atom_pos;
+  if (!k.docs) return; // keyword without postings: nblocks = 0, never present
+  const HostTerm& h = seg->terms[k.term_id];
+  dt.blk_first = h.blk_first;
+  dt.nblocks = h.nblocks;
+  dt.docs = h.docs;
+  dt.spd_end = h.doclist_off + h.doclist_len;
+  dt.exc_first = h.exc_first;
+  dt.exc_n = h.exc_n;
+  dt.bm_off = h.bm_off;
+  dt.dir_off = h.dir_off;
+}
+
+// returns MRK_OK, or MRK_E_UNSUPPORTED / MRK_E_INVAL with the message set.  dq = the query's head pass
+// (index qi); further passes go to `extra` and get pass indices n_queries + position.
+int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
+                      std::vector<DevQuery>& extra, uint32_t n_queries, std::vector<DevItem>& items,
+                      std::vector<DevItem>& items_bm, uint32_t qi,
+                      uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out) {
+  memset(&dq, 0, sizeof dq);
+  dq.item_first = (uint32_t)items.size();
+  dq.out_q = qi;
+  if (!q.nodes || q.n_nodes <= 0 || q.root < 0 || q.root >= q.n_nodes) return mrk_fail(MRK_E_INVAL, "query %u: bad tree", qi);
+  if (q.max_matches <= 0 || q.max_matches > MRK_MAX_K)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: max_matches %d outside 1..%d", qi, q.max_matches, MRK_MAX_K);
+  if (q.cutoff > 0) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: cutoff is order-dependent; not on the device path", qi);
+
+  PlanTree T;
+  int tree_err = MRK_OK;
+  const int root = build_tree(seg, q, q.root, T, qi, 0, true, tree_err);
+  if (root < 0) return tree_err;
+  const int n = (int)T.kws.size();
+  if (n > MRK_MAX_AND_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d keywords (device path: <= %d)", qi, n, MRK_MAX_AND_TERMS);
+  if (T.nodes.size() > 16) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
+  const bool single_word = T.nodes.size() == 1;
+  bool pure_and = !T.force_tree; // single keyword or one ExtMultiAnd_T: the kernel's N-way AND loop, no program
+  for (const PlanNode& pn : T.nodes) pure_and &= pn.op == PN_TERM || pn.op == PN_AND;
+  if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE || q.nodes[q.root].op == MRK_OP_PROXIMITY))
+    for (int i = 0; i < q.nodes[q.root].n_children; ++i) pure_and &= q.nodes[q.children[q.nodes[q.root].first_child + i]].op == MRK_OP_TERM;
+  if (!pure_and && !use_packed) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: boolean trees run on the packed path only", qi);
+  if (!pure_and) { // the device evaluates the program on a TREE_STACK-deep register stack
+    int sp = 0, deep = 0;
+    for (const PlanNode& pn : T.nodes) {
+      sp += pn.op == PN_TERM ? 1 : pn.op == PN_PHRASEFIX ? 0 : -1;
+      deep = std::max(deep, sp);
+    }
+    if (deep > TREE_STACK) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree nests deeper than the device path evaluates", qi);
+  }
+
+  uint32_t ranker;
+  bool prox = false;       // a state ranker reads the hit streams
+  bool state_only = false; // ... one without a HANDLE_DUPES variant (duplicate keywords are fine)
+  if (T.ph_leaf && n > MAX_PROX_TERMS)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE in a tree of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+  if (T.phrase || T.ph_leaf) {
+    if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE runs on the packed path only", qi);
+    if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+  }
+  switch (q.ranker) {
+    case MRK_RANK_NONE: ranker = MRK_RANK_NONE; break;
+    case MRK_RANK_BM25: ranker = MRK_RANK_BM25; break;
+    case MRK_RANK_PROXIMITY_BM25:
+    case MRK_RANK_PROXIMITY:
+      // a single keyword is ranked by ExtRanker_WeightSum_c (sphinxsearch.cpp:4195-4196, 4216-4217)
+      if (single_word) {
+        ranker = q.ranker == MRK_RANK_PROXIMITY_BM25 ? MRK_RANK_BM25 : MRK_RANK_PROXIMITY;
+        if (ranker == MRK_RANK_PROXIMITY && !use_packed)
+          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker=proximity runs on the packed path only", qi);
+      } else {
+        if (!use_packed || !seg->dev.pk_hit)
+          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity rankers run on the packed path only", qi);
+        if (n > MAX_PROX_TERMS)
+          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity over %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+        if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity path needs < 2^31 docs per segment", qi);
+        if (T.multiand3_inner) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: 3-keyword AND below another operator with a hit ranker", qi);
+        ranker = (uint32_t)q.ranker;
+        prox = true;
+      }
+      break;
+    case MRK_RANK_WORDCOUNT:
+    case MRK_RANK_MATCHANY:
+    case MRK_RANK_FIELDMASK:
+    case MRK_RANK_SPH04:
+      // always ExtRanker_State_T over the hit stream, single keyword or not (sphinxsearch.cpp:4214-4236)
+      if (!use_packed || !seg->dev.pk_hit)
+        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit rankers run on the packed path only", qi);
+      if (n > MAX_PROX_TERMS)
+        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit ranker over %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+      if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+      if (T.multiand3_inner) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: 3-keyword AND below another operator with a hit ranker", qi);
+      ranker = (uint32_t)q.ranker;
+      prox = true;
+      state_only = true;
+      break;
+    default: return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker %d not on the device path", qi, q.ranker);
+  }
+
+  // IDFs: distinct words in GetQwords traversal order (searchnode.cpp:2029-2055, 3276-3286)
+  std::vector<int> words;
+  for (int i = 0; i < n; ++i) {
+    bool seen = false;
+    for (int w : words) seen |= T.kws[w].term_id == T.kws[i].term_id;
+    T.kws[i].weighted_first = !seen;
+    if (!seen) words.push_back(i);
+  }
+  if (prox && !state_only && (int)words.size() != n)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: duplicate keywords need RankerState_Proximity_fn<HANDLE_DUPES>, not on the device path", qi);
+  const int64_t total_docs = q.total_docs_override > 0 ? q.total_docs_override : (int64_t)seg->total_docs;
+  for (int w : words) {
+    PlanKw& t = T.kws[w];
+    int64_t term_docs = t.docs;
+    if (q.local_docs && q.local_docs[t.node] >= 0) term_docs = q.local_docs[t.node];
+    t.idf = mrk_idf(term_docs, total_docs, q.plain_idf, q.normalized_tfidf, (int)words.size(), t.boost);
+  }
+
+  dq.ranker = ranker;
+  dq.n_qwords = (uint32_t)words.size(); // ExtRanker_c::m_iQwords (sphinxsearch.cpp:730-731)
+  dq.max_qpos = 0;                      // ... m_iMaxQpos = GetQwords() (:4294-4296, 4372)
+  for (const PlanKw& k : T.kws) dq.max_qpos = std::max<uint32_t>(dq.max_qpos, (uint32_t)std::max(k.atom_pos, 0));
+  dq.k = (uint32_t)q.max_matches;
+  dq.n_weights = seg->n_fields;
+  dq.index_weight = (uint32_t)(q.index_weight ? q.index_weight : 1);
+  for (uint32_t f = 0; f < 32; ++f)
+    dq.weights[f] = (q.field_weights && (int)f < q.n_weights) ? q.field_weights[f] : 1; // BindWeights default
+
+  // ---- passes: one per driver keyword of the tree's candidate cover
+  std::vector<int> cover;
+  if (pure_and)
+    cover.push_back(0); // kws are already in ExtMultiAnd_T node order: the rarest keyword drives
+  else
+    cover_of(T, root, cover);
+  {
+    std::vector<int> uniq;
+    for (int k : cover)
+      if (std::find(uniq.begin(), uniq.end(), k) == uniq.end()) uniq.push_back(k);
+    cover.swap(uniq);
+  }
+  if ((int)cover.size() > MAX_PASSES)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %zu driver keywords (device path: <= %d)", qi, cover.size(), MAX_PASSES);
+  const uint32_t req = pure_and ? (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u) : required_of(T, root);
+  bool empty = false;
+  for (int k = 0; k < n; ++k)
+    if ((req >> k & 1u) && !T.kws[k].docs) empty = true; // a required keyword without postings (searchnode.cpp:2922)
+
+  uint64_t bytes = 0, pbytes = 0;
+  for (int k = 0; k < n; ++k)
+    if (T.kws[k].docs) {
+      bytes += seg->terms[T.kws[k].term_id].doclist_len;
+      pbytes += seg->terms[T.kws[k].term_id].packed_bytes;
+    }
+
+  // pruning histogram geometry (packed path): bins must be monotone in the sorter's order
+  dq.bin_mode = BIN_WEIGHT;
+  dq.bin_lo = INT32_MIN;
+  dq.bin_shift = 31; // fallback: (almost) no pruning, always correct
+  if (ranker == MRK_RANK_NONE) {
+    // all weights equal: order is rowid ascending => bin on the (global) rowid
+    dq.bin_mode = BIN_ROWID;
+    const uint64_t max_row = (uint64_t)seg->dev.rowid_base + (seg->total_docs ? seg->total_docs : 1);
+    uint32_t sh = 0;
+    while (sh < 31 && (max_row >> sh) >= (uint64_t)NBINS) ++sh;
+    if (max_row > 0xFFFFFFFFull) sh = 22;
+    dq.bin_shift = sh;
+    dq.bin_lo = 0;
+  } else {
+    // weight = ((int)((sum tfidf + 0.5f) * 1000) + rank * 1000) * index_weight; any keyword may be absent
+    double lo = 0.0, hi = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double idf = T.kws[i].weighted_first ? T.kws[i].idf : 0.0;
+      const double a0 = idf * (1.0 / 2.2), a1 = idf;
+      lo += std::min(0.0, std::min(a0, a1));
+      hi += std::max(0.0, std::max(a0, a1));
+      if (pure_and) { // every keyword contributes
+        lo += std::min(a0, a1) - std::min(0.0, std::min(a0, a1));
+        hi += std::max(a0, a1) - std::max(0.0, std::max(a0, a1));
+      }
+    }
+    const int64_t bm_lo = (int64_t)floor((lo + 0.5) * 1000.0) - 2, bm_hi = (int64_t)ceil((hi + 0.5) * 1000.0) + 2;
+    int64_t rmin = INT64_MAX, rmax = INT64_MIN;
+    const uint32_t nwf = std::min<uint32_t>(dq.n_weights, 8u);
+    if (prox) {
+      // sum_f LCS[f] * w[f] with 0 <= LCS[f] <= number of keywords (hit weight 1, unique keywords)
+      // (a phrase occurrence weighs its word count; back-to-back occurrences can add up -- beyond 2n the bins clamp)
+      // The other state rankers: SPH04 4*LCS + 2 + 1 per field; WORDCOUNT one field weight per hit (unbounded:
+      // 32 hits per keyword span the bins, more clamp); MATCHANY bits + (LCS-1) * K, K = sum(w) * words;
+      // FIELDMASK the mask itself.  Bounds only shape the pruning bins -- values outside clamp to the edge bins.
+      rmin = rmax = 0;
+      int64_t top = (T.phrase || T.ph_leaf) ? 2 * n : n;
+      if (ranker == MRK_RANK_SPH04) top = 4 * top + 3;
+      if (ranker == MRK_RANK_WORDCOUNT) top = 32 * n;
+      if (ranker == MRK_RANK_MATCHANY) {
+        int64_t k = 0;
+        for (uint32_t f = 0; f < nwf; ++f) k += dq.weights[f];
+        top = n + top * std::llabs(k * (int64_t)words.size());
+      }
+      for (uint32_t f = 0; f < nwf; ++f) {
+        const int64_t v = top * dq.weights[f];
+        rmin += ranker == MRK_RANK_MATCHANY ? -std::llabs(v) : std::min<int64_t>(0, v);
+        rmax += ranker == MRK_RANK_MATCHANY ? std::llabs(v) : std::max<int64_t>(0, v);
+      }
+      if (ranker == MRK_RANK_FIELDMASK) rmin = 0, rmax = (1ll << nwf) - 1;
+    } else
+      for (uint32_t m = 0; m < 256; ++m) {
+        int64_t r = 0;
+        if (!m)
+          r = 1;
+        else
+          for (uint32_t f = 0; f < nwf; ++f)
+            if (m & (1u << f)) r += dq.weights[f];
+        rmin = std::min(rmin, r);
+        rmax = std::max(rmax, r);
+      }
+    const bool with_bm = ranker == MRK_RANK_BM25 || ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_SPH04;
+    const int64_t iw = (int32_t)dq.index_weight;
+    const int64_t sc = with_bm ? 1000 : 1, b0 = with_bm ? bm_lo : 0, b1 = with_bm ? bm_hi : 0;
+    const int64_t c[4] = {(b0 + rmin * sc) * iw, (b0 + rmax * sc) * iw, (b1 + rmin * sc) * iw, (b1 + rmax * sc) * iw};
+    const int64_t wlo = *std::min_element(c, c + 4), whi = *std::max_element(c, c + 4);
+    if (wlo > INT32_MIN && whi < INT32_MAX && std::llabs(rmin * 1000) < INT32_MAX && std::llabs(rmax * 1000) < INT32_MAX) {
+      const uint64_t span = (uint64_t)(whi - wlo) + 1;
+      uint32_t sh = 0;
+      while (sh < 31 && ((span - 1) >> sh) >= (uint64_t)NBINS) ++sh;
+      dq.bin_lo = (int32_t)wlo;
+      dq.bin_shift = sh;
+    }
+  }
+  {
+    uint64_t cap = 0;
+    for (int k : cover) cap += (uint64_t)T.kws[k].docs;
+    cap = std::min<uint64_t>(std::max<uint64_t>(cap, 1), (uint64_t)1 << 20);
+    dq.cand_cap = (uint32_t)cap;
+    dq.cand_off = cand_total;
+    cand_total += cap;
+  }
+  if (empty) {
+    dq.n_terms = (uint32_t)n;
+    dq.n_items = 0;
+    return MRK_OK;
+  }
+  algo_bytes += bytes;
+  dev_bytes += use_packed ? pbytes : bytes;
+  prox_out = prox_out || prox || T.phrase || T.ph_leaf;
+  tree_out = tree_out || !pure_and;
+
+  // two dense keywords: the bitmap kernel (mrk_scan_bm.hip) walks 2048-rowid windows instead of blocks
+  if (use_packed && pure_and && !T.phrase && n == 2 && (ranker == MRK_RANK_NONE || ranker == MRK_RANK_BM25) && seg->dev.bm &&
+      seg->ctx->bitmap_inv > 0 && seg->terms[T.kws[0].term_id].bm_off != ~0ull && seg->terms[T.kws[1].term_id].bm_off != ~0ull) {
+    dq.n_terms = 2;
+    for (int i = 0; i < 2; ++i) fill_term(seg, T.kws[i], dq.t[i]);
+    dq.tree_flags = TF_MULTIAND | TF_BITMAP;
+    dq.item_first = (uint32_t)items_bm.size();
+    const uint64_t nwin = seg->dev.n_windows;
+    const uint64_t bm_bytes = 2 * nwin * 256 + ((uint64_t)dq.t[0].nblocks + dq.t[1].nblocks) * 256; // bitmaps + attr words
+    dev_bytes += bm_bytes - pbytes; // (pbytes was added above)
+    // one entry for the whole window range; mrk_batch_submit cuts it once the batch's total is known (a wave's
+    // fixed costs -- tables, final publish, atomics on the query's counters -- want long runs of windows)
+    DevItem it{};
+    it.query = qi;
+    it.blk_begin = 0;
+    it.blk_end = (uint32_t)nwin;
+    items_bm.push_back(it);
+    dq.n_items = 1;
+    return MRK_OK;
+  }
+
+  const DevQuery base = dq;
+  for (size_t p = 0; p < cover.size(); ++p) {
+    DevQuery* P = &dq;
+    uint32_t pass_index = qi;
+    if (p > 0) {
+      extra.push_back(base);
+      P = &extra.back();
+      pass_index = n_queries + (uint32_t)extra.size() - 1;
+      P->item_first = (uint32_t)items.size();
+    }
+    // keyword order of this pass: driver, then required keywords by ascending docs, then the rest
+    std::vector<int> order;
+    const int drv = cover[p];
+    order.push_back(drv);
+    if (pure_and)
+      for (int k = 1; k < n; ++k) order.push_back(k);
+    else {
+      std::vector<int> rq, rest;
+      for (int k = 0; k < n; ++k)
+        if (k != drv) ((req >> k & 1u) ? rq : rest).push_back(k);
+      auto by_docs = [&](int a, int b) { return T.kws[a].docs < T.kws[b].docs; };
+      std::stable_sort(rq.begin(), rq.end(), by_docs);
+      std::stable_sort(rest.begin(), rest.end(), by_docs);
+      order.insert(order.end(), rq.begin(), rq.end());
+      order.insert(order.end(), rest.begin(), rest.end());
+    }
+    std::vector<int> slot(n);
+    for (int i = 0; i < n; ++i) slot[order[i]] = i;
+    P->n_terms = (uint32_t)n;
+    for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
+    P->req_mask = P->excl_mask = 0;
+    P->tree_flags = T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0;
+    P->px_dist = (uint32_t)T.px_dist;
+    P->ph_mask = 0;
+    for (int k = 0; k < T.ph_n; ++k) P->ph_mask |= 1u << slot[T.ph_kw0 + k];
+    for (size_t i = 0; i < T.atoms.size(); ++i) P->ph_atoms[i] = (uint32_t)T.atoms[i];
+    {
+      for (int k = 0; k < n; ++k)
+        if (req >> k & 1u) P->req_mask |= 1u << slot[k];
+      for (size_t e = 0; e < p; ++e) P->excl_mask |= 1u << slot[cover[e]];
+      P->n_nodes = (uint32_t)T.nodes.size();
+      for (size_t i = 0; i < T.nodes.size(); ++i) {
+        const PlanNode& pn = T.nodes[i];
+        P->prog[i] = pn.op | ((uint32_t)(pn.l < 0 ? 0 : pn.l) << 8) | ((uint32_t)(pn.r < 0 ? 0 : pn.r) << 16) |
+                     ((uint32_t)(pn.kw < 0 ? 0 : slot[pn.kw]) << 24);
+      }
+    }
+    // work items: contiguous ranges of driver-term blocks, ~item_bytes of doclist each
+    const uint32_t nb0 = P->t[0].nblocks;
+    if (nb0) {
+      const double per_block = (double)(use_packed ? pbytes : bytes) / (double)nb0 / (double)cover.size();
+      uint64_t bpi = (uint64_t)((double)item_bytes / std::max(per_block, 1.0));
+      bpi = std::max<uint64_t>(T0_BLOCKS, (bpi / T0_BLOCKS) * T0_BLOCKS);
+      for (uint64_t b = 0; b < nb0; b += bpi) {
+        DevItem it{};
+        it.query = pass_index;
+        it.blk_begin = (uint32_t)b;
+        it.blk_end = (uint32_t)std::min<uint64_t>(nb0, b + bpi);
+        items.push_back(it);
+      }
+    }
+    P->n_items = (uint32_t)items.size() - P->item_first;
+  }
+  return MRK_OK;
+}
+
+// ----------------------------------------------------------------------------------------
