@@ -125,20 +125,18 @@ __device__ __forceinline__ uint32_t read_vlb32(const uint8_t* __restrict__ spp, 
   const uint64_t al = p & ~3ull;
   const uint32_t w0 = *reinterpret_cast<const uint32_t*>(spp + al);
   const uint32_t w1 = *reinterpret_cast<const uint32_t*>(spp + al + 4);
-  uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)p & 3u);
-  uint32_t val = 0, n = 0, bb;
-  do {
-    bb = x & 0xffu;
-    x >>= 8;
-    val = (val << 7) | (bb & 0x7fu);
-    ++n;
-  } while ((bb & 0x80u) && n < 4);
-  if (bb & 0x80u) { // 5-byte varint
-    bb = spp[p + 4];
-    val = (val << 7) | (bb & 0x7fu);
-    ++n;
+  const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)p & 3u);
+  // branch-free for 1..4 bytes: the first byte with a clear top bit ends the value; the 7-bit groups are MSB first
+  const uint32_t stop = ~x & 0x80808080u;
+  const uint32_t n = stop ? ((uint32_t)__builtin_ctz(stop) >> 3) + 1u : 4u;
+  const uint32_t all = ((x & 0x7Fu) << 21) | ((x & 0x7F00u) << 6) | ((x >> 9) & 0x3F80u) | ((x >> 24) & 0x7Fu); // 4 groups
+  uint32_t val = all >> (7u * (4u - n));
+  uint32_t len = n;
+  if (!stop) { // 5-byte varint
+    val = (val << 7) | (spp[p + 4] & 0x7fu);
+    len = 5;
   }
-  p += n;
+  p += len;
   return val;
 }
 
@@ -468,9 +466,14 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
         if (field_queried(bmask, bh))
           emit = C.px_dist ? F.step_prox(hp, bq & 0xFFFFu, nph, C.ap0 & 0xFFFFu, span, C.px_dist, e_pos, e_w, e_span)
                            : F.step(hp, bq & 0xFFFFu, nph, C.ap0, C.ap1, C.ap2, C.ap3);
+        { // advance the chosen stream: one decode for the wave, whatever stream each lane picked
+          uint64_t ap = best == 0 ? sp[0] : best == 1 ? sp[1] : best == 2 ? sp[2] : sp[3];
+          uint32_t ac = best == 0 ? sc[0] : best == 1 ? sc[1] : best == 2 ? sc[2] : sc[3];
+          hit_advance(C.spp, ap, ac);
 #pragma unroll
-        for (int t = 0; t < MAX_PROX_TERMS; ++t)
-          if (t == best) hit_advance(C.spp, sp[t], sc[t]);
+          for (int t = 0; t < MAX_PROX_TERMS; ++t)
+            if (t == best) sp[t] = ap, sc[t] = ac;
+        }
         if (emit) {
           phave = true;
           pcur = e_pos, pw = e_w, pspan = e_span;
@@ -513,9 +516,14 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
     if (phase == 1) bmask = best == tl ? sm[0] : sm[1];
     // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
     if (field_queried(bmask, bh)) X.update(C.ranker, bh & ~(1u << 23), ((bh >> 23) & 1u) != 0, bq & 0xFFFFu, 1u, 0u, C.w_of, C.max_qpos);
+    { // advance the chosen stream: one decode for the wave, whatever stream each lane picked
+      uint64_t ap = best == 0 ? sp[0] : best == 1 ? sp[1] : best == 2 ? sp[2] : sp[3];
+      uint32_t ac = best == 0 ? sc[0] : best == 1 ? sc[1] : best == 2 ? sc[2] : sc[3];
+      hit_advance(C.spp, ap, ac);
 #pragma unroll
-    for (int t = 0; t < MAX_PROX_TERMS; ++t)
-      if (t == best) hit_advance(C.spp, sp[t], sc[t]);
+      for (int t = 0; t < MAX_PROX_TERMS; ++t)
+        if (t == best) sp[t] = ap, sc[t] = ac;
+    }
   }
   if (rank) rk_out = X.finalize(C.ranker, C.nw, C.Q->weights, C.w_of, C.n_qwords);
   if (F.over) atomicOr(C.flags, QF_OVERFLOW);
