@@ -104,6 +104,28 @@ G["cases"] += [
     {"name": "114 \"cccc dddd\" wordcount", "corpus": "test_114", "query": OP("phrase", T("cccc", 1), T("dddd", 2)),
      "ranker": "wordcount", "expect": [[511, 520]] + [[i, 1] for i in range(1, 20)], "limit": 20, "total_found": 511},
 ]
+G["cases"] += [  # the rest of test_019's query list, as far as its trees can be written down without the query parser
+    {"name": "019 \"test that\"~3 | basic", "corpus": "test_019",
+     "query": OP("or", OP("proximity", T("test", 1), T("that", 2), opt=3), T("basic", 3)), "ranker": "proximity_bm25",
+     "expect": [[333, 1647], [111, 1551], [555, 1551]]},
+    {"name": "019 \"hello program\"~3", "corpus": "test_019", "query": OP("proximity", T("hello", 1), T("program", 2), opt=3),
+     "ranker": "proximity_bm25", "expect": []},
+    {"name": "019 \"quorum query test\"/4", "corpus": "test_019",
+     "query": OP("quorum", T("quorum", 1), T("query", 2), T("test", 3), opt=4), "ranker": "proximity_bm25", "expect": []},
+    {"name": "019 0077", "corpus": "test_019", "query": T("0077", 1), "ranker": "proximity_bm25", "expect": [[888, 1720]]},
+    {"name": "019 @title test", "corpus": "test_019", "query": T("test", 1, 0b01), "ranker": "proximity_bm25", "expect": []},
+    {"name": "019 @!title aaa", "corpus": "test_019", "query": T("aaa", 1, 0xFFFFFFFE), "ranker": "proximity_bm25",
+     "expect": [[901, 1653], [903, 1611]]},
+    {"name": "019 @@relaxed @!nonexistent test", "corpus": "test_019", "query": T("test", 1), "ranker": "proximity_bm25",
+     "expect": [[333, 1720]]},
+    {"name": "019 \"phrase (!query)/ ~on @steroids\"", "corpus": "test_019",
+     "query": OP("phrase", T("phrase", 1), T("query", 2), T("on", 3), T("steroids", 4)), "ranker": "proximity_bm25",
+     "expect": [[222, 4704]]},
+    {"name": "019 1234567812345678", "corpus": "test_019", "query": T("1234567812345678", 1), "ranker": "proximity_bm25",
+     "expect": [[999, 1720]]},
+    {"name": "019 canon 16 35", "corpus": "test_019", "query": OP("and", T("canon", 1), T("16", 2), T("35", 3)),
+     "ranker": "proximity_bm25", "expect": [[555, 2720]]},
+]
 for spam, exp in [(10, [[1, 25], [2, 15], [3, 15]]), (0, [[1, 5], [2, 5], [3, 5]]), (-10, [[2, -5], [3, -5], [1, -15]])]:
     G["cases"].append({"name": f"322 program flow wordcount, field_weights 1,2,{spam}", "corpus": "test_322",
                        "query": OP("and", T("program", 1), T("flow", 2)), "ranker": "wordcount",
