@@ -50,6 +50,12 @@ G = {
         "test_114": {"source": "test/test_114/test.xml (custom_insert) + model.bin", "min_word_len": 1, "ids": list(range(1, 512)),
                      "docs_spec": [{"count": 510, "fields": ["aaaa bbbb cccc dddd"]},
                                    {"count": 1, "fields": ["aaaa bbbb x aaaa bbbb " + " x cccc dddd" * 520]}]},
+        # test_116 (bound cases of the proximity node) also builds its rows in loops
+        "test_116": {"source": "test/test_116/test.xml (custom_insert) + model.bin", "min_word_len": 1, "ids": list(range(1, 523)),
+                     "docs_spec": [{"count": 1, "fields": ["a " + "x " * i + " b"]} for i in range(10)] +
+                                  [{"count": 510, "fields": ["e x f"]},
+                                   {"count": 1, "fields": ["e x f x x x e x f x x e x f x x"]},
+                                   {"count": 1, "fields": [" y y i x j" * 532]}]},
         "test_322": {"source": "test/test_322/test.xml + model.bin", "min_word_len": 1, "ids": [1, 2, 3, 100],
                      "docs": [["|sample program", "|program flow direct", "|sample program flow"],
                               ["|one sample program", "|program rev flow", "|one rev flow"],
@@ -103,6 +109,14 @@ G["cases"] += [
      "ranker": "wordcount", "expect": [[511, 2]] + [[i, 1] for i in range(1, 20)], "limit": 20, "total_found": 511},
     {"name": "114 \"cccc dddd\" wordcount", "corpus": "test_114", "query": OP("phrase", T("cccc", 1), T("dddd", 2)),
      "ranker": "wordcount", "expect": [[511, 520]] + [[i, 1] for i in range(1, 20)], "limit": 20, "total_found": 511},
+]
+G["cases"] += [
+    {"name": "116 \"a b\"~3 wordcount", "corpus": "test_116", "query": OP("proximity", T("a", 1), T("b", 2), opt=3),
+     "ranker": "wordcount", "expect": [[1, 1], [2, 1], [3, 1]], "total_found": 3},
+    {"name": "116 \"e f\"~2 wordcount", "corpus": "test_116", "query": OP("proximity", T("e", 1), T("f", 2), opt=2),
+     "ranker": "wordcount", "expect": [[521, 3]] + [[i, 1] for i in range(11, 30)], "limit": 20, "total_found": 511},
+    {"name": "116 \"i j\"~2 wordcount", "corpus": "test_116", "query": OP("proximity", T("i", 1), T("j", 2), opt=2),
+     "ranker": "wordcount", "expect": [[522, 532]], "total_found": 1},
 ]
 G["cases"] += [  # the rest of test_019's query list, as far as its trees can be written down without the query parser
     {"name": "019 \"test that\"~3 | basic", "corpus": "test_019",
