@@ -56,6 +56,7 @@ constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
 constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4, PN_PHRASEFIX = 5; // prog[] opcodes
 constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
 constexpr uint32_t TF_BITMAP = 4;   // 2-keyword AND answered by the bitmap kernel (items are window ranges)
+constexpr uint32_t TF_DUPES = 16;      // a keyword occurs more than once in the query (HasQwordDupes, sphinxsearch.cpp:4178)
 constexpr uint32_t TF_PHRASE_LEAF = 8; // one PHRASE below other operators: ph_mask = its words' slots in t[]
 constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[] = atom positions in phrase order
 constexpr int PHRASE_STATES = 8;    // live FSMphrase_c states per doc (>= phrase span + 1)

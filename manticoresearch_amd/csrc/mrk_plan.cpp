@@ -268,7 +268,6 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
 
   uint32_t ranker;
   bool prox = false;       // a state ranker reads the hit streams
-  bool state_only = false; // ... one without a HANDLE_DUPES variant (duplicate keywords are fine)
   if (T.ph_leaf && n > MAX_PROX_TERMS)
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE in a tree of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
   if (T.phrase || T.ph_leaf) {
@@ -309,7 +308,6 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       if (T.multiand3_inner) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: 3-keyword AND below another operator with a hit ranker", qi);
       ranker = (uint32_t)q.ranker;
       prox = true;
-      state_only = true;
       break;
     default: return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker %d not on the device path", qi, q.ranker);
   }
@@ -322,8 +320,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     T.kws[i].weighted_first = !seen;
     if (!seen) words.push_back(i);
   }
-  if (prox && !state_only && (int)words.size() != n)
-    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: duplicate keywords need RankerState_Proximity_fn<HANDLE_DUPES>, not on the device path", qi);
+  const bool got_dupes = (int)words.size() != n; // HasQwordDupes: proximity rankers switch to their HANDLE_DUPES update
   const int64_t total_docs = q.total_docs_override > 0 ? q.total_docs_override : (int64_t)seg->total_docs;
   for (int w : words) {
     PlanKw& t = T.kws[w];
@@ -512,7 +509,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     P->n_terms = (uint32_t)n;
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
     P->req_mask = P->excl_mask = 0;
-    P->tree_flags = T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0;
+    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0);
     P->px_dist = (uint32_t)T.px_dist;
     P->ph_mask = 0;
     for (int k = 0; k < T.ph_n; ++k) P->ph_mask |= 1u << slot[T.ph_kw0 + k];

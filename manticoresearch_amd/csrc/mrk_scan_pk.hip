@@ -325,8 +325,8 @@ struct RankState {
   }
   // one hit: hp = position with field (no end bit), is_end = its end-of-field marker, hq = query position,
   // hw = weight (1; word count for a folded phrase hit), hspan = spanlen - 1; w_of = field weight table
-  __device__ __forceinline__ void update(uint32_t ranker, uint32_t hp, bool is_end, uint32_t hq, uint32_t hw, uint32_t hspan,
-                                         const uint32_t* w_of, int max_qpos) {
+  __device__ __forceinline__ void update(uint32_t ranker, bool dupes, uint32_t hp, bool is_end, uint32_t hq, uint32_t hw,
+                                         uint32_t hspan, const uint32_t* w_of, int max_qpos) {
     const uint32_t f = hp >> 24;
     const int pwf = (int)hp;
     const int delta = pwf - (int)hq;
@@ -352,6 +352,31 @@ struct RankState {
       }
       min_exp_pos = hp + 1u;
       first = false;
+    } else if (dupes) {
+      // RankerState_Proximity_fn<.., true>::Update (:1370-1412): repeated query keywords -- several query positions
+      // may share a hit position.  min_exp_pos / head / exact / fmask double as m_uLcsTailPos / m_uLcsTailQposMask /
+      // m_uCurQposMask / m_uCurPos (SPH04 and FIELDMASK have no dupes variant).
+      if ((fmask >> 24) != f) exact = 0;
+      if (hp != fmask) {
+        if (cur_lcs < 2) {
+          min_exp_pos = fmask;
+          head = exact;
+          cur_lcs = 1;
+        }
+        exact = 0;
+        fmask = hp;
+        if (f < 8 && (uint32_t)((lcs >> (8 * f)) & 0xffu) < hw) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)(hw & 0xffu) << (8 * f));
+      }
+      exact |= 1u << (hq & 31u);
+      const int dd = (int)(fmask - min_exp_pos);
+      if (dd && dd < 32 && ((exact >> (dd & 31)) & head)) {
+        head = 1u << (hq & 31u);
+        min_exp_pos = fmask;
+        cur_lcs = (cur_lcs + hw) & 0xffu;
+        exact = 0;
+        if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu)) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
+      }
+      return;
     } else { // the proximity family
       if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + hw) & 0xffu;
       if (ranker == MRK_RANK_MATCHANY && f < 8) mmask |= (uint64_t)((1u << ((hq - 1u) & 31u)) & 0xffu) << (8 * f);
@@ -403,6 +428,7 @@ struct HitCtx {
   const uint32_t* w_of;   // LDS table: field-weight sum per field mask (w_of[1 << f] = weight of field f)
   int max_qpos, n_qwords; // ExtRanker_c::m_iMaxQpos / m_iQwords
   bool inline_hits, multi_and;
+  bool dupes;             // repeated query keywords under a proximity ranker: RankerState_Proximity_fn<.., true>
 };
 
 // One doc's hit pass.  ref0..ref3 = where the doc sits in each keyword's packed arrays (block within the keyword << 7 |
@@ -508,14 +534,15 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
       if (((dmask >> t) & 1u) && sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && sq[t] < bq)))
         best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
     if (phave && (best < 0 || pcur < bh || (pcur == bh && (C.ap0 & 0xFFFFu) < (bq & 0xFFFFu)))) {
-      X.update(C.ranker, pcur, false, C.ap0 & 0xFFFFu, pw, pspan, C.w_of, C.max_qpos);
+      X.update(C.ranker, C.dupes, pcur, false, C.ap0 & 0xFFFFu, pw, pspan, C.w_of, C.max_qpos);
       phave = false;
       continue;
     }
     if (best < 0) break;
     if (phase == 1) bmask = best == tl ? sm[0] : sm[1];
     // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
-    if (field_queried(bmask, bh)) X.update(C.ranker, bh & ~(1u << 23), ((bh >> 23) & 1u) != 0, bq & 0xFFFFu, 1u, 0u, C.w_of, C.max_qpos);
+    if (field_queried(bmask, bh))
+      X.update(C.ranker, C.dupes, bh & ~(1u << 23), ((bh >> 23) & 1u) != 0, bq & 0xFFFFu, 1u, 0u, C.w_of, C.max_qpos);
     { // advance the chosen stream: one decode for the wave, whatever stream each lane picked
       uint64_t ap = best == 0 ? sp[0] : best == 1 ? sp[1] : best == 2 ? sp[2] : sp[3];
       uint32_t ac = best == 0 ? sc[0] : best == 1 ? sc[1] : best == 2 ? sc[2] : sc[3];
@@ -708,6 +735,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   HC.w_of = s.rank;
   HC.max_qpos = (int)Q->max_qpos, HC.n_qwords = (int)Q->n_qwords;
   HC.inline_hits = inline_hits, HC.multi_and = multi_and;
+  HC.dupes = (Q->tree_flags & TF_DUPES) != 0 && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY);
   auto drain_hits = [&](uint32_t from, uint32_t n) {
     if (!PROX) return;
     wave_lds_fence();

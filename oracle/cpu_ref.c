@@ -1650,6 +1650,8 @@ typedef struct {
   uint8_t cur_lcs;
   int exp_delta;
   int last_hitpos_with_field;
+  /* HANDLE_DUPES */
+  uint32_t lcs_tail_pos, lcs_tail_qpos_mask, cur_qpos_mask, cur_pos;
 } prox_state;
 
 static void prox_init(prox_state* s) {
@@ -1657,6 +1659,36 @@ static void prox_init(prox_state* s) {
   s->cur_lcs = 0;
   s->exp_delta = -INT_MAX;
   s->last_hitpos_with_field = -INT_MAX;
+  s->lcs_tail_pos = s->lcs_tail_qpos_mask = s->cur_qpos_mask = s->cur_pos = 0;
+}
+
+/* RankerState_Proximity_fn<USE_BM25,true>::Update (sphinxsearch.cpp:1370-1412): query keywords repeat, several query
+   positions may share a hit position */
+static inline void prox_update_dupes(prox_state* s, const hit_t* h) {
+  uint32_t pos = ORC_HIT_POSWITHFIELD(h->hitpos);
+  uint32_t field = ORC_HIT_FIELD(h->hitpos);
+  if (ORC_HIT_FIELD(s->cur_pos) != field) s->cur_qpos_mask = 0; /* reset accumulated data from the previous field */
+  if (pos != s->cur_pos) {
+    if (s->cur_lcs < 2) {
+      s->lcs_tail_pos = s->cur_pos;
+      s->lcs_tail_qpos_mask = s->cur_qpos_mask;
+      s->cur_lcs = 1;
+    }
+    s->cur_qpos_mask = 0;
+    s->cur_pos = pos;
+    if (s->lcs[field] < h->weight) s->lcs[field] = (uint8_t)h->weight;
+  }
+  s->cur_qpos_mask |= 1u << (h->qpos & 31);
+  int delta = (int)(s->cur_pos - s->lcs_tail_pos);
+  /* (a negative delta -- positions running backwards -- is a negative shift count in the reference, undefined in C++;
+     x86 masks the count to 5 bits, and so do we) */
+  if (delta && delta < 32 && ((s->cur_qpos_mask >> (delta & 31)) & s->lcs_tail_qpos_mask)) {
+    s->lcs_tail_qpos_mask = 1u << (h->qpos & 31);
+    s->lcs_tail_pos = s->cur_pos;
+    s->cur_lcs = (uint8_t)(s->cur_lcs + h->weight);
+    s->cur_qpos_mask = 0;
+    if (s->cur_lcs > s->lcs[field]) s->lcs[field] = s->cur_lcs;
+  }
 }
 
 static inline void prox_update(prox_state* s, const hit_t* h) {
@@ -1674,6 +1706,7 @@ static inline int prox_finalize(prox_state* s, int n_fields, const int32_t* weig
   s->cur_lcs = 0;
   s->exp_delta = -1;
   s->last_hitpos_with_field = -1;
+  s->lcs_tail_pos = s->lcs_tail_qpos_mask = s->cur_qpos_mask = s->cur_pos = 0; /* if_const ( HANDLE_DUPES ) */
   int rank = 0;
   for (int i = 0; i < n_fields; i++) {
     rank += (int)(s->lcs[i]) * weights[i];
@@ -1814,10 +1847,7 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
   h.n = 0;
   int dupes = 0;
   collect_qwords(root, &h, &dupes);
-  if (dupes && state_ranker && (ranker == ORC_RANK_PROXIMITY_BM25 || ranker == ORC_RANK_PROXIMITY)) {
-    en_free(root);
-    return fail("duplicate keywords with a proximity ranker (HANDLE_DUPES) not restated");
-  }
+  const int handle_dupes = dupes != 0; /* HasQwordDupes -> RankerState_Proximity_fn<.., true> (:4178, 4197, 4218) */
   int64_t total_docs = q->total_docs_override > 0 ? q->total_docs_override : idx->total_docs;
   for (int i = 0; i < h.n; i++) {
     int64_t term_docs = h.w[i].docs;
@@ -1888,7 +1918,10 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
           weight = sph04_finalize(&s4, n_weights, weights, bm25);
           break;
         default:
-          for (int i = 0; i < hv.n; i++) prox_update(&ps, &hv.p[i]);
+          if (handle_dupes)
+            for (int i = 0; i < hv.n; i++) prox_update_dupes(&ps, &hv.p[i]);
+          else
+            for (int i = 0; i < hv.n; i++) prox_update(&ps, &hv.p[i]);
           weight = prox_finalize(&ps, n_weights, weights, use_bm25, bm25);
       }
     } else if (ranker == ORC_RANK_NONE) {

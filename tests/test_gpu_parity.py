@@ -321,7 +321,7 @@ def test_random_corpus_proximity(orc, dev, block, fmt):
     qs = []
     for _ in range(120):
         k = int(rng.integers(2, 5))
-        ts = rng.choice(len(probs), size=k, replace=False)
+        ts = rng.choice(len(probs), size=k, replace=bool(rng.random() < 0.25))  # repeated keywords: the HANDLE_DUPES update
         masks = [0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)) for _ in ts]
         # atom positions as the parser numbers them, sometimes with a gap (stop word)
         pos, ap = [], 0
@@ -526,10 +526,8 @@ def test_random_corpus_phrases(orc, dev, block, fmt):
         mask = 0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8))
         words = [kw(m, int(t), p) for t, p in zip(ts, pos)]
         root = PHRASE(m, *words, mask=mask) if i % 2 else PROXIMITY(m, int(rng.integers(1, 6)), *words, mask=mask)
-        has_dupes = len(set(int(t) for t in ts)) != k
         rk = rankers[i % 4] if i % 3 else more[(i // 3) % 4]
-        if has_dupes and rk in (m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY):
-            rk = m.SPH_RANK_BM25  # HANDLE_DUPES is restated neither in the oracle nor on the device
+        # (repeated words under the proximity rankers take RankerState_Proximity_fn<.., true>)
         qs.append(m.Query(root, ranker=rk, max_matches=int(rng.choice([5, 100, 1000])),
                           field_weights=[int(x) for x in rng.integers(-3, 12, 3)] if rng.random() < 0.5 else None,
                           index_weight=int(rng.choice([1, 1, 2]))))
