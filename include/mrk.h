@@ -204,6 +204,8 @@ int mrk_batch_export_rows(mrk_batch* b, uint64_t* rows_dst);
    batch's own stream right behind the selection kernel -- valid after mrk_batch_wait, no device work at collection
    time.  NULL cancels it. */
 int mrk_batch_set_rows_dst(mrk_batch* b, uint64_t* rows_dst);
+/* (A query whose candidate list overflowed is rerun by mrk_batch_wait; a row that left through the standing export
+   before that carries no keys and bit 63 of total_found, which survives the merge's sum: ask that shard again.) */
 /* record a caller-owned hipEvent_t on the batch's stream, i.e. behind everything the last submit queued there
    (selection, standing rows export, result copies): lets another stream (RCCL's) wait for the rows without the host */
 int mrk_batch_record_event(mrk_batch* b, void* hip_event);

@@ -62,7 +62,8 @@ constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[]
 constexpr int PHRASE_STATES = 8;    // live FSMphrase_c states per doc (>= phrase span + 1)
 constexpr int TREE_STACK = 4;       // evaluation stack depth of the tree program
 constexpr int MAX_PASSES = 4; // driver keywords per query (size of the tree's candidate cover)
-constexpr uint32_t QF_OVERFLOW = 1; // candidate list overflowed: the query's result is not trustworthy
+constexpr uint32_t QF_OVERFLOW = 1; // candidate list overflowed: the host reruns the query with a list that holds every doc
+constexpr uint32_t QF_FSM = 2;      // more live phrase states than the kernel keeps: the query fails
 constexpr int MAX_PROX_TERMS_ = 4;
 constexpr int MAPCAP = 4096; // direct-map probe window (rowids) per decoded block
 
@@ -174,6 +175,7 @@ struct PackRowsArgs {
   const uint32_t* cnt;    // [n]
   const uint64_t* total;  // [n]
   uint64_t* rows;         // [n][ROW_WORDS]
+  const uint32_t* flags;  // [n] QF_* of the scan (NULL = none): a flagged query's row is poisoned, not trusted
   uint32_t n;
 };
 void launch_pack_rows(const PackRowsArgs& a, void* stream);

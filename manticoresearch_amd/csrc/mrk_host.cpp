@@ -144,6 +144,11 @@ struct mrk_batch {
   std::vector<int32_t> status;
   bool decoded = false;
   bool packed_run = false;
+  // what a rerun of an overflowed query needs (mrk_batch_wait)
+  mrk_segment* last_seg = nullptr;
+  uint32_t n_pass = 0, last_max_terms = 1;
+  bool last_prox = false, last_tree = false;
+  mrk_batch* retry = nullptr;
   hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_merge1 = nullptr;
   mrk_batch_stats stats{};
 };
@@ -548,6 +553,7 @@ extern "C" void mrk_batch_destroy(mrk_batch* b) {
   b->h_cand_n.release();
   b->d_cand.release();
   b->h_flags.release();
+  if (b->retry) mrk_batch_destroy(b->retry);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
   if (b->ev_scan1) (void)hipEventDestroy(b->ev_scan1);
@@ -752,11 +758,17 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
     pa.cnt = b->d_out_cnt.p;
     pa.total = b->d_q_total.p;
     pa.rows = b->rows_dst;
+    pa.flags = use_packed ? b->d_q_flags.p : nullptr;
     pa.n = n;
     launch_pack_rows(pa, st2);
   }
   HIP_TRY(hipGetLastError());
   b->packed_run = use_packed;
+  b->last_seg = seg;
+  b->n_pass = (uint32_t)n_pass;
+  b->last_max_terms = max_terms;
+  b->last_prox = any_prox;
+  b->last_tree = any_tree;
   if (use_packed) {
     HIP_TRY(hipMemcpyAsync(b->h_flags.p, b->d_q_flags.p, n * 4, hipMemcpyDeviceToHost, st2));
     HIP_TRY(hipMemcpyAsync(b->h_cand_n.p, b->d_q_cand_n.p, n * 4, hipMemcpyDeviceToHost, st2));
@@ -778,6 +790,99 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   return MRK_OK;
 }
 
+// One query of the last submit again, with a candidate list sized for every doc of its driver keywords.  The passes
+// planned at submit are reused (they hold everything but the work items); results replace the query's host rows.
+static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
+  mrk_segment* seg = b->last_seg;
+  if (!seg) return mrk_fail(MRK_E_INVAL, "query %u: candidate list overflowed and the segment is gone", qi);
+  if (!b->retry) {
+    int rc = mrk_batch_create(b->ctx, 1 + MAX_PASSES, &b->retry);
+    if (rc != MRK_OK) return rc;
+  }
+  mrk_batch* r = b->retry;
+  hipStream_t st = r->stream;
+  std::vector<DevQuery> passes;
+  passes.push_back(b->h_queries.p[qi]);
+  for (uint32_t e = b->n_queries; e < b->n_pass; ++e)
+    if (b->h_queries.p[e].out_q == qi) passes.push_back(b->h_queries.p[e]);
+  uint64_t cap = 0;
+  for (const DevQuery& p : passes) cap += (p.tree_flags & TF_BITMAP) ? std::min<uint64_t>(p.t[0].docs, p.t[1].docs) : p.t[0].docs;
+  cap = std::max<uint64_t>(cap, 1);
+  if (cap > 0xFFFFFFF0ull) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: candidate list overflowed", qi);
+  std::vector<DevItem> items_pk, items_bm;
+  for (size_t p = 0; p < passes.size(); ++p) {
+    DevQuery& P = passes[p];
+    P.out_q = 0;
+    P.cand_off = 0;
+    P.cand_cap = (uint32_t)cap;
+    const bool bm = (P.tree_flags & TF_BITMAP) != 0;
+    const uint32_t n = bm ? seg->dev.n_windows : P.t[0].nblocks, step = bm ? 1024u : 256u;
+    for (uint32_t x = 0; x < n; x += step) {
+      DevItem it{};
+      it.query = (uint32_t)p;
+      it.blk_begin = x;
+      it.blk_end = std::min(n, x + step);
+      (bm ? items_bm : items_pk).push_back(it);
+    }
+  }
+  const size_t n_pk = items_pk.size();
+  items_pk.insert(items_pk.end(), items_bm.begin(), items_bm.end());
+  const size_t n_items = items_pk.size();
+  int rc;
+  if ((rc = r->h_queries.reserve(passes.size())) || (rc = r->d_queries.reserve(passes.size())) || (rc = r->h_items.reserve(n_items + 1)) ||
+      (rc = r->d_items.reserve(n_items + 1)) || (rc = r->d_cand.reserve(cap + 64)))
+    return rc;
+  memcpy(r->h_queries.p, passes.data(), passes.size() * sizeof(DevQuery));
+  if (n_items) memcpy(r->h_items.p, items_pk.data(), n_items * sizeof(DevItem));
+  HIP_TRY(hipMemcpyAsync(r->d_queries.p, r->h_queries.p, passes.size() * sizeof(DevQuery), hipMemcpyHostToDevice, st));
+  if (n_items) HIP_TRY(hipMemcpyAsync(r->d_items.p, r->h_items.p, n_items * sizeof(DevItem), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(r->d_state.p, 0, (size_t)r->max_queries * 28 + (size_t)NBINS * 4, st));
+  ScanArgs sa{};
+  sa.seg = seg->dev;
+  sa.queries = r->d_queries.p;
+  sa.items = r->d_items.p;
+  sa.q_total = r->d_q_total.p;
+  sa.q_tau = r->d_q_tau.p;
+  sa.n_items = (uint32_t)n_pk;
+  sa.q_hist = r->d_q_hist.p;
+  sa.q_cand_n = r->d_q_cand_n.p;
+  sa.q_flags = r->d_q_flags.p;
+  sa.q_tau_bin = r->d_q_tau_bin.p;
+  sa.cand = r->d_cand.p;
+  launch_scan_pk(sa, b->last_max_terms, b->last_prox, b->last_tree, st);
+  if (n_items > n_pk) {
+    ScanArgs sb = sa;
+    sb.items = r->d_items.p + n_pk;
+    sb.n_items = (uint32_t)(n_items - n_pk);
+    launch_scan_bm(sb, st);
+  }
+  SelectArgs se{};
+  se.queries = r->d_queries.p;
+  se.q_hist = r->d_q_hist.p;
+  se.q_cand_n = r->d_q_cand_n.p;
+  se.cand = r->d_cand.p;
+  se.n_queries = 1;
+  se.rowid_base = seg->dev.rowid_base;
+  se.out_keys = r->d_out_keys.p;
+  se.out_cnt = r->d_out_cnt.p;
+  launch_select(se, st);
+  HIP_TRY(hipGetLastError());
+  uint32_t flags = 0;
+  HIP_TRY(hipMemcpyAsync(&flags, r->d_q_flags.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_cnt.p + qi, r->d_out_cnt.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_total.p + qi, r->d_q_total.p, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_keys.p + (size_t)qi * KCAP, r->d_out_keys.p, (size_t)KCAP * 8, hipMemcpyDeviceToHost, st));
+  // the batch's device-side results (mrk_batch_device_results / export) get the repaired row too
+  HIP_TRY(hipMemcpyAsync(b->d_out_cnt.p + qi, r->d_out_cnt.p, 4, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(b->d_q_total.p + qi, r->d_q_total.p, 8, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(b->d_out_keys.p + (size_t)qi * KCAP, r->d_out_keys.p, (size_t)KCAP * 8, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemsetAsync(b->d_q_flags.p + qi, 0, 4, st)); // the device-side row is good again
+  HIP_TRY(hipStreamSynchronize(st));
+  if (flags & (QF_OVERFLOW | QF_FSM)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: candidate list overflowed again on the rerun", qi);
+  b->decoded = false;
+  return MRK_OK;
+}
+
 extern "C" int mrk_batch_wait(mrk_batch* b) {
   if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_wait: NULL batch");
   if (!b->in_flight) return MRK_OK;
@@ -791,11 +896,18 @@ extern "C" int mrk_batch_wait(mrk_batch* b) {
   if (b->packed_run)
     for (uint32_t i = 0; i < b->n_queries; ++i) b->stats.n_cands += b->h_cand_n.p[i];
   if (b->packed_run)
-    for (uint32_t i = 0; i < b->n_queries; ++i)
-      if (b->status[i] == MRK_OK && (b->h_flags.p[i] & QF_OVERFLOW)) {
-        // never hand back a silently truncated result
-        b->status[i] = mrk_fail(MRK_E_UNSUPPORTED, "query %u: candidate list overflowed (%u slots); rerun with path=1", i, 1u << 20);
+    for (uint32_t i = 0; i < b->n_queries; ++i) {
+      if (b->status[i] != MRK_OK) continue;
+      // never hand back a silently truncated result
+      if (b->h_flags.p[i] & QF_FSM)
+        b->status[i] = mrk_fail(MRK_E_UNSUPPORTED, "query %u: a doc held more live phrase states than the device path keeps", i);
+      else if (b->h_flags.p[i] & QF_OVERFLOW) {
+        // more matches tied at the pruning threshold than the candidate list holds (e.g. millions of docs with the
+        // very same weight): run the query again, alone, with room for every doc its drivers can deliver
+        const int rc = rerun_overflowed(b, i);
+        if (rc != MRK_OK) b->status[i] = rc;
       }
+    }
   return MRK_OK;
 }
 
@@ -881,6 +993,7 @@ extern "C" int mrk_batch_export_rows(mrk_batch* b, uint64_t* rows_dst) {
   pa.cnt = b->d_out_cnt.p;
   pa.total = b->d_q_total.p;
   pa.rows = rows_dst;
+  pa.flags = b->packed_run ? b->d_q_flags.p : nullptr;
   pa.n = b->n_queries;
   launch_pack_rows(pa, b->stream); // behind the batch's selection kernel
   HIP_TRY(hipGetLastError());

@@ -582,11 +582,14 @@ __global__ __launch_bounds__(WG) void pack_rows_kernel(PackRowsArgs a) {
   const uint32_t q = blockIdx.x;
   if (q >= a.n) return;
   uint64_t* __restrict__ row = a.rows + (uint64_t)q * ROW_WORDS;
-  const uint32_t n = a.cnt[q] < (uint32_t)KCAP ? a.cnt[q] : (uint32_t)KCAP;
+  // a query whose candidate list overflowed has no trustworthy list on the device until the host reran it: its row goes
+  // out empty with bit 63 of total_found set, which survives the merge's sum and tells the receiver to ask again
+  const bool bad = a.flags && (a.flags[q] & (QF_OVERFLOW | QF_FSM)) != 0;
+  const uint32_t n = bad ? 0u : a.cnt[q] < (uint32_t)KCAP ? a.cnt[q] : (uint32_t)KCAP;
   for (uint32_t i = threadIdx.x; i < (uint32_t)KCAP; i += WG) row[i] = i < n ? a.keys[(uint64_t)q * KCAP + i] : 0ull;
   if (threadIdx.x == 0) {
     row[KCAP] = n;
-    row[KCAP + 1] = a.total[q];
+    row[KCAP + 1] = bad ? (1ull << 63) : a.total[q];
   }
 }
 

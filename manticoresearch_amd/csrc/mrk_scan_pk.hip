@@ -553,7 +553,7 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
     }
   }
   if (rank) rk_out = X.finalize(C.ranker, C.nw, C.Q->weights, C.w_of, C.n_qwords);
-  if (F.over) atomicOr(C.flags, QF_OVERFLOW);
+  if (F.over) atomicOr(C.flags, QF_FSM);
 }
 
 template <bool PROX, bool TREE>

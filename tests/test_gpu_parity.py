@@ -817,3 +817,35 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
         finally:
             seg.close()
     assert n_checked > 200
+
+
+# ------------------------------------------------------------------ more ties than the candidate list holds
+def test_candidate_overflow_is_rerun(orc, dev):
+    """1.3 M docs that all match with the very same weight: nothing can be pruned, the 2^20-slot candidate list
+    overflows, and the query is rerun with a full-size list instead of failing or truncating."""
+    _tree_only(dev)
+    m, ctx, batch = dev
+    n_docs = 1_300_000
+    rows = np.arange(n_docs, dtype=np.uint32)
+    W = np.concatenate([np.full(n_docs, 1, np.uint64), np.full(n_docs, 2, np.uint64)])
+    R = np.concatenate([rows, rows])
+    H = np.concatenate([np.full(n_docs, (1 << 24) | 1, np.uint32), np.full(n_docs, (1 << 24) | 2, np.uint32)])
+    hi = m.index_from_hits(W, R, H, n_terms=2, total_docs=n_docs, n_fields=2)
+    qs = [m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_BM25, max_matches=1000),
+          m.Query(OR(m, kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_BM25, max_matches=10),
+          m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_FIELDMASK, max_matches=100)]
+    for inv in (64, 0):  # bitmap kernel and block kernel
+        ctx.set("bitmap_inv", inv)
+        seg = m.Segment(ctx, hi)
+        try:
+            got = batch.search(seg, qs)
+            for q, g in zip(qs, got):
+                assert g.status == 0
+                assert g.total_found == n_docs
+                assert list(g.rowid) == list(range(len(g.rowid))) and len(g.rowid) == q.max_matches  # ties: lowest rowids win
+                assert len(set(int(w) for w in g.weight)) == 1
+            want = to_orc(orc, qs[0]).run(orc_index_of(orc, hi))
+            assert (got[0].weight == want.weight).all() and (got[0].rowid == want.rowid).all()
+        finally:
+            seg.close()
+    ctx.set("bitmap_inv", 64)
