@@ -126,3 +126,61 @@ def test_phrase_mix_with_field_weights(orc, corpus):
         assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
         n_found += g.total_found
     assert n_found > 1000  # the corpus is dense enough (positions 1..64) for phrases to occur
+
+
+# ------------------------------------------------------------------ BASELINE.json's full size: 100 M docs
+FULL_DOCS = int(os.environ.get("MRK_FULL_DOCS", 100_000_000))  # 0 skips the test
+
+
+@pytest.mark.skipif(FULL_DOCS == 0, reason="MRK_FULL_DOCS=0")
+def test_full_size_properties(orc):
+    """The headline configuration (100 M docs, 2-term AND, BM25, top-1000) through size-independent properties: the
+    three device paths agree bit for bit on one segment, results obey the sorter's order, a second run returns the
+    same bytes, totals are consistent (|A and B| <= min(|A|, |B|), AND is symmetric in its result set), and a few
+    selective queries -- cheap enough for the CPU -- equal the oracle."""
+    import manticoresearch_amd as m
+
+    probs = [0.25, 0.08, 0.03, 0.002, 0.0005, 0.0001]
+    hi = m.synth_index(FULL_DOCS, probs, seed=20261005)
+    docs = [int(hi.dict[t]["docs"]) for t in range(len(probs))]
+    ctx = m.Context(0)
+    seg = m.Segment(ctx, hi)
+    pairs = [(a, b) for a in range(len(probs)) for b in range(len(probs)) if a != b]
+    qs = [m.Query(m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), ranker=m.SPH_RANK_BM25, max_matches=1000) for a, b in pairs]
+    batch = m.Batch(ctx, len(qs))
+    try:
+        res = {}
+        for name, path, inv in (("bm", 0, 64), ("pk", 0, 0), ("vlb", 1, 0)):
+            ctx.set("path", path)
+            ctx.set("bitmap_inv", inv)  # read at submit: the same segment serves all three paths
+            r1 = batch.search(seg, qs)
+            st = batch.stats()
+            r2 = batch.search(seg, qs)
+            for a_, b_ in zip(r1, r2):
+                assert a_.status == 0 and a_.total_found == b_.total_found and (a_.rowid == b_.rowid).all() and (a_.weight == b_.weight).all()
+            res[name] = (r1, st)
+        assert res["bm"][1]["n_items_bm"] > 0 and res["pk"][1]["n_items_bm"] == 0 and res["vlb"][1]["packed"] == 0
+        by_pair = {}
+        for i, (a, b) in enumerate(pairs):
+            g = res["bm"][0][i]
+            for other in (res["pk"][0][i], res["vlb"][0][i]):
+                assert g.total_found == other.total_found and (g.rowid == other.rowid).all() and (g.weight == other.weight).all()
+            check_order(g)
+            assert g.total_found <= min(docs[a], docs[b])
+            assert len(g.rowid) == min(1000, g.total_found)
+            by_pair[(a, b)] = g
+        for (a, b), g in by_pair.items():  # AND(a, b) and AND(b, a) find the same docs (weights may differ in tfidf sum order)
+            h = by_pair[(b, a)]
+            assert g.total_found == h.total_found
+        oi = orc_index_of(orc, hi)
+        for i, (a, b) in enumerate(pairs):
+            if min(docs[a], docs[b]) < 100_000 and max(docs[a], docs[b]) < 3_000_000:
+                want = to_orc(orc, qs[i]).run(oi)
+                g = res["bm"][0][i]
+                assert g.total_found == want.total_found and (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+    finally:
+        ctx.set("path", 0)
+        ctx.set("bitmap_inv", 64)
+        batch.close()
+        seg.close()
+        ctx.close()
