@@ -10,6 +10,44 @@
 
 using namespace mrk;
 
+// Fixed-capacity vector for the planner's scratch lists: planning runs per query on the submit path (a few hundred
+// nanoseconds each), heap allocations would dominate it.  Pushing past the capacity sets `overflow` (checked once per
+// query: such a query is declined) instead of growing.
+template <typename T, int N>
+struct SmallVec {
+  T v[N];
+  int n = 0;
+  bool overflow = false;
+  SmallVec() {}
+  explicit SmallVec(int count) : n(count <= N ? count : N), overflow(count > N) {
+    for (int i = 0; i < n; ++i) v[i] = T();
+  }
+  void push_back(const T& x) {
+    if (n < N)
+      v[n++] = x;
+    else
+      overflow = true;
+  }
+  size_t size() const { return (size_t)n; }
+  bool empty() const { return n == 0; }
+  T& operator[](size_t i) { return v[i]; }
+  const T& operator[](size_t i) const { return v[i]; }
+  T* begin() { return v; }
+  T* end() { return v + n; }
+  const T* begin() const { return v; }
+  const T* end() const { return v + n; }
+  T& back() { return v[n - 1]; }
+  const T& back() const { return v[n - 1]; }
+  T& front() { return v[0]; }
+  const T& front() const { return v[0]; }
+  void clear() { n = 0; }
+  void append(const T* b, const T* e) {
+    for (; b != e; ++b) push_back(*b);
+  }
+};
+constexpr int PLAN_CAP = 40; // keywords / nodes / children a plan may hold before the size checks decline the query
+typedef SmallVec<int, PLAN_CAP> IntVec;
+
 // planner: mrk_query -> DevQuery + work items
 // ----------------------------------------------------------------------------------------
 struct PlanKw { // one keyword occurrence of the query tree
@@ -28,15 +66,15 @@ struct PlanNode { // binary eval-tree node, post-order
 };
 
 struct PlanTree {
-  std::vector<PlanKw> kws;     // in GetQwords traversal order
-  std::vector<PlanNode> nodes; // post-order; root = last
+  SmallVec<PlanKw, PLAN_CAP> kws;     // in GetQwords traversal order
+  SmallVec<PlanNode, PLAN_CAP> nodes; // post-order; root = last
   bool multiand3_inner = false; // a 3-keyword ExtMultiAnd_T below the root (MergeHits3 quirk not restated there)
   bool phrase = false;          // root is a PHRASE (ExtNWay_T<FSMphrase_c>)
   bool ph_leaf = false;         // one PHRASE below other operators; its words are kws[ph_kw0 .. ph_kw0 + ph_n)
   int ph_kw0 = 0, ph_n = 0;
   int px_dist = 0;              // > 0: the phrase node is a PROXIMITY operator ('"a b"~N')
   bool force_tree = false;      // the query must run as a tree program even if it only holds TERM / AND nodes
-  std::vector<int> atoms;       // its words' query positions, phrase order
+  IntVec atoms;                 // its words' query positions, phrase order
 };
 
 // Mirrors ExtNode_i::Create (searchnode.cpp:1599-1811) for the operators the device path knows:
@@ -81,8 +119,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     if (n.n_children < 2 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
     if (n.opt != 1 && n.opt < n.n_children)
       return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum %d of %d (ExtQuorum_c) is not on the device path", qi, n.opt, n.n_children), -1;
-    std::vector<int32_t> kids(n.n_children);
-    std::vector<int> ord(n.n_children), docs(n.n_children);
+    IntVec kids(n.n_children), ord(n.n_children), docs(n.n_children);
     for (int i = 0; i < n.n_children; ++i) {
       kids[i] = q.children[n.first_child + i];
       if (kids[i] < 0 || kids[i] >= q.n_nodes || q.nodes[kids[i]].op != MRK_OP_TERM)
@@ -109,7 +146,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
   if (!nway && n.op != MRK_OP_AND && n.op != MRK_OP_OR && n.op != MRK_OP_MAYBE && n.op != MRK_OP_ANDNOT)
     return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, n.op), -1;
   if (n.n_children < 1 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
-  std::vector<int32_t> kids(n.n_children);
+  IntVec kids(n.n_children);
   bool all_terms = true;
   for (int i = 0; i < n.n_children; ++i) {
     kids[i] = q.children[n.first_child + i];
@@ -136,7 +173,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
                             T.atoms.back() - T.atoms.front(), PHRASE_STATES), -1;
   }
   if ((n.op == MRK_OP_AND || nway) && all_terms && n.n_children > 1) {
-    std::vector<int> ord(n.n_children), docs(n.n_children);
+    IntVec ord(n.n_children), docs(n.n_children);
     for (int i = 0; i < n.n_children; ++i) {
       const mrk_node& t = q.nodes[kids[i]];
       docs[i] = (t.term_id >= 0 && (uint32_t)t.term_id < seg->terms.size()) ? (int)seg->terms[t.term_id].docs : 0;
@@ -179,7 +216,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
 }
 
 // keywords whose doc streams together contain every possible match of the subtree
-static void cover_of(const PlanTree& T, int ni, std::vector<int>& out) {
+static void cover_of(const PlanTree& T, int ni, IntVec& out) {
   const PlanNode& n = T.nodes[ni];
   if (n.op == PN_TERM) {
     out.push_back(n.kw);
@@ -191,14 +228,14 @@ static void cover_of(const PlanTree& T, int ni, std::vector<int>& out) {
     return;
   }
   if (n.op == PN_AND) {
-    std::vector<int> a, b;
+    IntVec a, b;
     cover_of(T, n.l, a);
     cover_of(T, n.r, b);
     uint64_t ca = 0, cb = 0;
     for (int k : a) ca += (uint64_t)T.kws[k].docs;
     for (int k : b) cb += (uint64_t)T.kws[k].docs;
-    const std::vector<int>& w = (cb < ca || (cb == ca && b.size() < a.size())) ? b : a;
-    out.insert(out.end(), w.begin(), w.end());
+    const IntVec& w = (cb < ca || (cb == ca && b.size() < a.size())) ? b : a;
+    out.append(w.begin(), w.end());
     return;
   }
   cover_of(T, n.l, out); // MAYBE, ANDNOT, PHRASEFIX: the left side carries the docs
@@ -248,6 +285,8 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   int tree_err = MRK_OK;
   const int root = build_tree(seg, q, q.root, T, qi, 0, true, tree_err);
   if (root < 0) return tree_err;
+  if (T.kws.overflow || T.nodes.overflow || T.atoms.overflow)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
   const int n = (int)T.kws.size();
   if (n > MRK_MAX_AND_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d keywords (device path: <= %d)", qi, n, MRK_MAX_AND_TERMS);
   if (T.nodes.size() > 16) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
@@ -313,7 +352,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   }
 
   // IDFs: distinct words in GetQwords traversal order (searchnode.cpp:2029-2055, 3276-3286)
-  std::vector<int> words;
+  IntVec words;
   for (int i = 0; i < n; ++i) {
     bool seen = false;
     for (int w : words) seen |= T.kws[w].term_id == T.kws[i].term_id;
@@ -340,16 +379,16 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     dq.weights[f] = (q.field_weights && (int)f < q.n_weights) ? q.field_weights[f] : 1; // BindWeights default
 
   // ---- passes: one per driver keyword of the tree's candidate cover
-  std::vector<int> cover;
+  IntVec cover;
   if (pure_and)
     cover.push_back(0); // kws are already in ExtMultiAnd_T node order: the rarest keyword drives
   else
     cover_of(T, root, cover);
   {
-    std::vector<int> uniq;
+    IntVec uniq;
     for (int k : cover)
       if (std::find(uniq.begin(), uniq.end(), k) == uniq.end()) uniq.push_back(k);
-    cover.swap(uniq);
+    cover = uniq;
   }
   if ((int)cover.size() > MAX_PASSES)
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %zu driver keywords (device path: <= %d)", qi, cover.size(), MAX_PASSES);
@@ -489,22 +528,22 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       P->item_first = (uint32_t)items.size();
     }
     // keyword order of this pass: driver, then required keywords by ascending docs, then the rest
-    std::vector<int> order;
+    IntVec order;
     const int drv = cover[p];
     order.push_back(drv);
     if (pure_and)
       for (int k = 1; k < n; ++k) order.push_back(k);
     else {
-      std::vector<int> rq, rest;
+      IntVec rq, rest;
       for (int k = 0; k < n; ++k)
         if (k != drv) ((req >> k & 1u) ? rq : rest).push_back(k);
       auto by_docs = [&](int a, int b) { return T.kws[a].docs < T.kws[b].docs; };
       std::stable_sort(rq.begin(), rq.end(), by_docs);
       std::stable_sort(rest.begin(), rest.end(), by_docs);
-      order.insert(order.end(), rq.begin(), rq.end());
-      order.insert(order.end(), rest.begin(), rest.end());
+      order.append(rq.begin(), rq.end());
+      order.append(rest.begin(), rest.end());
     }
-    std::vector<int> slot(n);
+    IntVec slot(n);
     for (int i = 0; i < n; ++i) slot[order[i]] = i;
     P->n_terms = (uint32_t)n;
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
