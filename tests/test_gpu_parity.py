@@ -758,11 +758,12 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
     """Corpora of 1 .. 5000 docs (below / around one 128-doc block and one 2048-rowid window), every query shape the
     device accepts, dense and sparse keywords, dead rows, rowid bases: device == oracle."""
     m, ctx, batch = dev
-    rng = np.random.default_rng(424242)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("MRK_FUZZ_SEED", 424242)))
     packed = ctx_path(ctx) == 0
     n_checked = 0
-    for trial in range(28):
-        n_docs = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 257, 2047, 2048, 2049, 4097, 5000]))
+    for trial in range(int(os.environ.get("MRK_FUZZ_TRIALS", 28))):  # MRK_FUZZ_TRIALS=500 for a long soak
+        n_docs = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 257, 2047, 2048, 2049, 4097, 5000, 20000]))
         nt = int(rng.integers(3, 7))
         probs = [float(rng.choice([1.0, 0.7, 0.3, 0.1, 0.02, 0.6])) for _ in range(nt)]
         W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=int(rng.choice([4, 30])), end_markers=True)
@@ -774,10 +775,11 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
         qs = []
         for _ in range(14):
             k = int(rng.integers(1, min(4, nt) + 1))
-            ts = [int(t) for t in rng.choice(nt + 1, size=k, replace=False)]
+            ts = [int(t) for t in rng.choice(nt + 1, size=k, replace=bool(packed and rng.random() < 0.15))]
             masks = [0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)) for _ in ts]
             kws = [kw(m, t, i + 1, mk) for i, (t, mk) in enumerate(zip(ts, masks))]
-            shape = rng.choice(["and", "or", "andnot", "maybe", "phrase", "mixed"]) if (packed and k > 1) else "and"
+            shape = (rng.choice(["and", "or", "andnot", "maybe", "phrase", "mixed", "proximity", "quorum", "phrase_in_tree"])
+                     if (packed and k > 1) else "and")
             if k == 1:
                 root = kws[0]
             elif shape == "and":
@@ -790,6 +792,13 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
                 root = MAYBE(m, kws[0], kws[1])
             elif shape == "phrase":
                 root = PHRASE(m, *kws)
+            elif shape == "proximity":
+                root = PROXIMITY(m, int(rng.integers(1, 6)), *kws)
+            elif shape == "quorum":
+                root = m.XQNode(m.SPH_QUERY_QUORUM, kws, None, 0xFFFFFFFF, 1 if rng.random() < 0.5 else k)
+            elif shape == "phrase_in_tree" and k > 2:
+                ph = PHRASE(m, *kws[:2]) if rng.random() < 0.5 else PROXIMITY(m, 3, *kws[:2])
+                root = [OR(m, ph, *kws[2:]), m.XQNode.AND(ph, *kws[2:]), ANDNOT(m, kws[2], ph), MAYBE(m, ph, kws[2])][int(rng.integers(0, 4))]
             else:
                 root = m.XQNode.AND(OR(m, *kws[:2]), *kws[2:]) if k > 2 else OR(m, *kws)
             rk = [m.SPH_RANK_BM25, m.SPH_RANK_NONE] + ([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY, m.SPH_RANK_WORDCOUNT,
