@@ -82,6 +82,11 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
   const uint32_t* __restrict__ bmB = a.seg.bm + TB.bm_off;
   const uint32_t* __restrict__ dead = a.seg.dead;
   const uint32_t* __restrict__ attr = a.seg.pk_attr;
+  // SPH_RANK_NONE without field limits: every common doc matches with weight 1 and the sorter keeps the lowest
+  // rowids, so matches are counted straight off the match words, tf / field bytes are never fetched, and windows
+  // that lie wholly behind the pruning threshold are not even unpacked
+  const uint32_t field_all = nw >= 32u ? 0xFFFFFFFFu : (1u << nw) - 1u;
+  const bool none_fast = ranker == MRK_RANK_NONE && (TA.queried32 & field_all) == field_all && (TB.queried32 & field_all) == field_all;
 
   const uint32_t nwin = item.blk_end - item.blk_begin;
   const uint32_t per = (nwin + WAVES - 1) / WAVES;
@@ -146,12 +151,12 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     const uint32_t e = from + (valid ? lane : 0u);
     const uint32_t row = L.qrow[e], ra = L.qra[e], rb = L.qrb[e];
     // packed attr word of slot r: block r >> 7, word r & 63, byte pair (r >> 6) & 1
-    const uint32_t wa = attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)];
-    const uint32_t wb = attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)];
+    const uint32_t wa = none_fast ? 0x01010101u : attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)];
+    const uint32_t wb = none_fast ? 0x01010101u : attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)];
     const uint32_t sa = ((ra >> 6) & 1u) * 8u, sb = ((rb >> 6) & 1u) * 8u;
     const uint32_t tfa = (wa >> sa) & 0xffu, tfb = (wb >> sb) & 0xffu;
     const uint32_t fa = (wa >> (16u + sa)) & 0xffu & TA.queried32, fb = (wb >> (16u + sb)) & 0xffu & TB.queried32; // FitsFields
-    const bool live = valid && fa != 0 && fb != 0;
+    const bool live = valid && (none_fast || (fa != 0 && fb != 0));
     float ta = s.tfidf[0][tfa], tb = s.tfidf[1][tfb];
     if (tfa == 255u && live) ta = term_tfidf(exc_tf(a.seg, TA, row), TA.idf);
     if (tfb == 255u && live) tb = term_tfidf(exc_tf(a.seg, TB, row), TB.idf);
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     bool push = false;
     uint64_t key = 0;
     if (live) {
-      ++total;
+      if (!none_fast) ++total; // (counted off the match words otherwise)
       uint32_t weight;
       if (ranker == MRK_RANK_NONE)
         weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
@@ -211,6 +216,11 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       if ((uint32_t)i < nb) {
         const uint32_t aw = av[i], bw = bv[i];
         uint32_t m = aw & bw & ~dv[i];
+        if (none_fast) {
+          total += (uint32_t)__popc(m);
+          // the window's lowest rowid has its best bin: behind the threshold, nothing in it can enter the top K
+          if (bin_of(bin_mode, bin_lo, bin_shift, 1, a.seg.rowid_base + (wb + i) * 2048u) < tau_bin) m = 0;
+        }
         // ranks of the lane's first bit: one prefix sum carries both keywords' popcounts
         const uint32_t pc = (uint32_t)__popc(aw) | ((uint32_t)__popc(bw) << 16);
         const uint32_t incl = wave_incl_scan(pc);
