@@ -88,6 +88,7 @@ def main() -> None:
     ap.add_argument("--latency-samples", type=int, default=96)
     ap.add_argument("--strata", default="cc,sc,ss", help="subset of strata to run (profiling aid; the metric uses all three)")
     ap.add_argument("--path", type=int, default=0, help="0 = packed doclists (default), 1 = VLB-direct")
+    ap.add_argument("--attr-nibbles", action="store_true", help="build the one-byte tf/field plane (ctx key attr_nibbles)")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra 3-term AND/OR mix leg (BASELINE config 3)")
     args = ap.parse_args()
 
@@ -122,6 +123,8 @@ def main() -> None:
     if args.item_bytes:
         ctx.set("item_bytes", args.item_bytes)
     ctx.set("path", args.path)
+    if args.attr_nibbles:
+        ctx.set("attr_nibbles", 1)
     seg = m.Segment(ctx, hi, rowid_base=rank * shard_docs)
     batch = m.Batch(ctx, args.queries)
     sharded = world > 1 or force_dist

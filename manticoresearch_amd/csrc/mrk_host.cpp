@@ -204,6 +204,10 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
     c->pack = value != 0;
     return MRK_OK;
   }
+  if (!strcmp(key, "attr_nibbles")) {
+    c->attr_nibbles = value != 0;
+    return MRK_OK;
+  }
   if (!strcmp(key, "bm_target_items")) {
     if (value < 1 || value > (1 << 20)) return mrk_fail(MRK_E_INVAL, "bm_target_items must be 1 .. 2^20");
     c->bm_target_items = (int)value;
@@ -251,6 +255,7 @@ extern "C" void mrk_segment_destroy(mrk_segment* s) {
   if (s->d_pk_exc) (void)hipFree(s->d_pk_exc);
   if (s->d_pk_hit) (void)hipFree(s->d_pk_hit);
   if (s->d_pk_hbase) (void)hipFree(s->d_pk_hbase);
+  if (s->d_pk_attr1) (void)hipFree(s->d_pk_attr1);
   if (s->d_dead) (void)hipFree(s->d_dead);
   if (s->d_bm) (void)hipFree(s->d_bm);
   if (s->d_bm_dir) (void)hipFree(s->d_bm_dir);
@@ -373,6 +378,8 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
   std::vector<uint8_t> pk_w;
   std::vector<uint64_t> pk_exc;
   std::vector<uint32_t> bm_words, bm_dir;
+  std::vector<uint8_t> pk_attr1;
+  bool attr1_ok = ctx->attr_nibbles && d->n_fields <= 4;
   bool packed = ctx->pack && d->n_fields <= 8;
   if (packed) {
     std::vector<PackedTerm> pt(d->n_terms);
@@ -429,6 +436,8 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
           pk_attr.insert(pk_attr.end(), x.attr.begin(), x.attr.end());
           pk_exc.insert(pk_exc.end(), x.exc.begin(), x.exc.end());
           pk_hit.insert(pk_hit.end(), x.hit.begin(), x.hit.end());
+          attr1_ok = attr1_ok && x.attr1_ok;
+          if (attr1_ok) pk_attr1.insert(pk_attr1.end(), x.attr1.begin(), x.attr1.end());
           pk_hbase.insert(pk_hbase.end(), x.hbase.begin(), x.hbase.end());
           if (!x.bm.empty()) {
             h.bm_off = bm_words.size();
@@ -455,6 +464,13 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
         (rc = upload(&s->d_pk_hbase, pk_hbase.data(), pk_hbase.size() * 8, 64, ctx->stream)) != MRK_OK) {
       mrk_segment_destroy(s);
       return rc;
+    }
+    if (attr1_ok && !bm_words.empty() && pk_attr1.size() == pk_hit.size()) { // only the bitmap kernel reads it
+      if ((rc = upload(&s->d_pk_attr1, pk_attr1.data(), pk_attr1.size(), 64, ctx->stream)) != MRK_OK) {
+        mrk_segment_destroy(s);
+        return rc;
+      }
+      s->device_bytes += pk_attr1.size();
     }
     if (!bm_words.empty()) {
       if ((rc = upload(&s->d_bm, bm_words.data(), bm_words.size() * 4, 1024, ctx->stream)) != MRK_OK ||
@@ -489,6 +505,7 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
   s->dev.pk_exc = (const uint64_t*)s->d_pk_exc;
   s->dev.pk_hit = (const uint32_t*)s->d_pk_hit;
   s->dev.pk_hbase = (const uint64_t*)s->d_pk_hbase;
+  s->dev.pk_attr1 = (const uint8_t*)s->d_pk_attr1;
   s->dev.bm = (const uint32_t*)s->d_bm;
   s->dev.bm_dir = (const uint32_t*)s->d_bm_dir;
   s->dev.n_windows = (uint32_t)((d->total_docs + 2047) / 2048);

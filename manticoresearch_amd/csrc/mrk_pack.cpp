@@ -55,6 +55,7 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
   out.w.reserve(nblk);
   out.attr.assign((size_t)nblk * 64, 0);
   out.hit.assign((size_t)nblk * 128, 0);
+  out.attr1.assign((size_t)nblk * 128, 0);
   out.hbase.reserve(nblk);
   uint64_t hit_position = 0; // m_uHitPosition / m_iHitlistPos (sphinx.cpp:534, 542)
   out.delta.reserve((size_t)nblk * 32 + 8);
@@ -138,6 +139,8 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
       tf[i] = hits;
       fl[i] = fields;
       if (hits >= 255) out.exc.push_back(((uint64_t)rowid << 32) | hits);
+      if (fields > 15u) out.attr1_ok = false;
+      out.attr1[(size_t)b * 128 + i] = (uint8_t)((hits < 15u ? hits : 15u) | ((fields & 15u) << 4));
     }
     out.hbase[b] = hb;
     for (uint32_t i = n; i < 128; ++i) d[i] = 0, tf[i] = 0, fl[i] = 0;

@@ -16,6 +16,10 @@ struct PackedTerm {
   std::vector<uint32_t> delta; // this term's delta run
   std::vector<uint32_t> attr;  // 64 words per block
   std::vector<uint64_t> exc;   // rowid<<32 | tf for tf >= 255
+  // one byte per doc slot for the bitmap kernel's gathers (half the bytes of the attr words): tf in the low nibble
+  // (15 = look at the attr word), fields in the high one; attr1_ok = false when a doc has a field bit >= 4
+  std::vector<uint8_t> attr1;
+  bool attr1_ok = true;
   std::vector<uint32_t> hit;   // 128 per block: the inlined Hitpos_t (inline format, tf == 1) or the doc's
                                // hitlist offset in .spp relative to hbase[block]
   std::vector<uint64_t> hbase; // per block: .spp position of the block's first hitlist

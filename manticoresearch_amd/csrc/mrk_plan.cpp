@@ -504,7 +504,8 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     dq.tree_flags = TF_MULTIAND | TF_BITMAP;
     dq.item_first = (uint32_t)items_bm.size();
     const uint64_t nwin = seg->dev.n_windows;
-    const uint64_t bm_bytes = 2 * nwin * 256 + ((uint64_t)dq.t[0].nblocks + dq.t[1].nblocks) * 256; // bitmaps + attr words
+    // bitmaps + tf / field bytes of the docs (one byte each where the segment has the nibble plane, else the attr words)
+    const uint64_t bm_bytes = 2 * nwin * 256 + ((uint64_t)dq.t[0].nblocks + dq.t[1].nblocks) * (seg->dev.pk_attr1 ? 128 : 256);
     dev_bytes += bm_bytes - pbytes; // (pbytes was added above)
     // one entry for the whole window range; mrk_batch_submit cuts it once the batch's total is known (a wave's
     // fixed costs -- tables, final publish, atomics on the query's counters -- want long runs of windows)

@@ -35,9 +35,7 @@ constexpr int BM_BURST = MRK_BM_BURST;
 
 struct __align__(16) BmWaveLds {
   uint64_t cbuf[BM_CBUF];
-  uint32_t qrow[BM_QCAP];
-  uint32_t qra[BM_QCAP];
-  uint32_t qrb[BM_QCAP];
+  uint4 q[BM_QCAP]; // match queue: rowid, rank in A, rank in B, (pad) -- one 16-byte LDS access per entry
 };
 
 struct __align__(16) BmSmem {
@@ -82,6 +80,7 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
   const uint32_t* __restrict__ bmB = a.seg.bm + TB.bm_off;
   const uint32_t* __restrict__ dead = a.seg.dead;
   const uint32_t* __restrict__ attr = a.seg.pk_attr;
+  const uint8_t* __restrict__ attr1 = a.seg.pk_attr1;
   // SPH_RANK_NONE without field limits: every common doc matches with weight 1 and the sorter keeps the lowest
   // rowids, so matches are counted straight off the match words, tf / field bytes are never fetched, and windows
   // that lie wholly behind the pruning threshold are not even unpacked
@@ -149,13 +148,24 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     wave_lds_fence();
     const bool valid = lane < n;
     const uint32_t e = from + (valid ? lane : 0u);
-    const uint32_t row = L.qrow[e], ra = L.qra[e], rb = L.qrb[e];
+    const uint4 qe = L.q[e];
+    const uint32_t row = qe.x, ra = qe.y, rb = qe.z;
     // packed attr word of slot r: block r >> 7, word r & 63, byte pair (r >> 6) & 1
-    const uint32_t wa = none_fast ? 0x01010101u : attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)];
-    const uint32_t wb = none_fast ? 0x01010101u : attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)];
-    const uint32_t sa = ((ra >> 6) & 1u) * 8u, sb = ((rb >> 6) & 1u) * 8u;
-    const uint32_t tfa = (wa >> sa) & 0xffu, tfb = (wb >> sb) & 0xffu;
-    const uint32_t fa = (wa >> (16u + sa)) & 0xffu & TA.queried32, fb = (wb >> (16u + sb)) & 0xffu & TB.queried32; // FitsFields
+    uint32_t tfa, tfb, fa, fb;
+    if (attr1 && !none_fast) {
+      // nibble plane: one byte per doc (tf | fields << 4); tf 15 escapes to the attr word
+      const uint32_t ba = attr1[(uint64_t)TA.blk_first * 128 + ra], bb = attr1[(uint64_t)TB.blk_first * 128 + rb];
+      tfa = ba & 15u, tfb = bb & 15u;
+      fa = (ba >> 4) & TA.queried32, fb = (bb >> 4) & TB.queried32; // FitsFields
+      if (tfa == 15u) tfa = (attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)] >> (((ra >> 6) & 1u) * 8u)) & 0xffu;
+      if (tfb == 15u) tfb = (attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)] >> (((rb >> 6) & 1u) * 8u)) & 0xffu;
+    } else {
+      const uint32_t wa = none_fast ? 0x01010101u : attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)];
+      const uint32_t wb = none_fast ? 0x01010101u : attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)];
+      const uint32_t sa = ((ra >> 6) & 1u) * 8u, sb = ((rb >> 6) & 1u) * 8u;
+      tfa = (wa >> sa) & 0xffu, tfb = (wb >> sb) & 0xffu;
+      fa = (wa >> (16u + sa)) & 0xffu & TA.queried32, fb = (wb >> (16u + sb)) & 0xffu & TB.queried32; // FitsFields
+    }
     const bool live = valid && (none_fast || (fa != 0 && fb != 0));
     float ta = s.tfidf[0][tfa], tb = s.tfidf[1][tfb];
     if (tfa == 255u && live) ta = term_tfidf(exc_tf(a.seg, TA, row), TA.idf);
@@ -241,9 +251,7 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
           const uint32_t below = (1u << bit) - 1u;
           const uint32_t pos = qn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
           if (has) {
-            L.qrow[pos] = rowbase + bit;
-            L.qra[pos] = ra0 + (uint32_t)__popc(aw & below);
-            L.qrb[pos] = rb0 + (uint32_t)__popc(bw & below);
+            L.q[pos] = make_uint4(rowbase + bit, ra0 + (uint32_t)__popc(aw & below), rb0 + (uint32_t)__popc(bw & below), 0u);
           }
           qn += (uint32_t)__popcll(bal);
           m &= m - 1u;

@@ -644,6 +644,11 @@ def test_bitmap_and_kernel(orc, dev):
     ctx.set("item_bytes", 16 << 10)  # several work items per query
     try:
         check_batch(orc, dev, hi, qs)
+        ctx.set("attr_nibbles", 1)  # the one-byte tf/field plane (tf >= 15 escapes to the attr words)
+        try:
+            check_batch(orc, dev, hi, qs)
+        finally:
+            ctx.set("attr_nibbles", 0)
         seg = m.Segment(ctx, hi)
         batch.search(seg, qs[:8])
         assert batch.stats()["n_items_bm"] > 0  # the bitmap kernel did run
