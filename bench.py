@@ -317,7 +317,7 @@ def main() -> None:
         try:
             tj = json.load(open(tr_path))
             if (tj.get("docs") == args.docs and tj.get("queries") == nq and tj.get("skiplist_block") == args.skiplist_block
-                    and tj.get("kernel_tag") == kernel_tag):
+                    and tj.get("kernel_tag") == kernel_tag and not args.attr_nibbles):
                 traffic = tj.get("traffic_bytes_per_launch")
         except Exception:
             traffic = None
