@@ -54,9 +54,11 @@ __device__ __forceinline__ bool row_is_dead(const DevSegment& seg, uint32_t rowi
 constexpr uint32_t PK_WIDE = 0xFFu;
 constexpr int NBINS = 1024; // pruning histogram bins per query
 constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
-constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4, PN_PHRASEFIX = 5; // prog[] opcodes
+constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4, PN_PHRASEFIX = 5, PN_QUORUM = 6; // prog[] opcodes
+constexpr int QUORUM_EVENTS = 8; // keywords of a quorum node = doclists that can run dry and reorder its children
 constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
 constexpr uint32_t TF_BITMAP = 4;   // 2-keyword AND answered by the bitmap kernel (items are window ranges)
+constexpr uint32_t TF_QUORUM_HITS = 32; // the root is an ExtQuorum_c: its hits sort by position WITHOUT the end flag
 constexpr uint32_t TF_DUPES = 16;      // a keyword occurs more than once in the query (HasQwordDupes, sphinxsearch.cpp:4178)
 constexpr uint32_t TF_PHRASE_LEAF = 8; // one PHRASE below other operators: ph_mask = its words' slots in t[]
 constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[] = atom positions in phrase order
@@ -105,6 +107,12 @@ struct DevQuery {
   uint32_t prog[16];  // op | left node << 8 | right node << 16 | keyword << 24
   uint32_t ph_atoms[MAX_PROX_TERMS_]; // PHRASE: query positions of its words, in phrase order
   uint32_t ph_mask;                   // TF_PHRASE_LEAF: keyword slots of the phrase's words
+  // ExtQuorum_c: keyword slots, threshold, and the order of its children (4 bits per slot, 0xF = end) as a
+  // function of the rowid: qr_ord[0] up to qr_row[0], qr_ord[i + 1] for rowids beyond qr_row[i] (the keyword whose
+  // doclist ends there leaves m_dChildren by RemoveFast, searchnode.cpp:4478, 4531)
+  uint32_t qr_mask, qr_thr, qr_n;
+  uint32_t qr_row[QUORUM_EVENTS];
+  uint32_t qr_ord[QUORUM_EVENTS + 1];
   uint32_t px_dist;                   // 0 = exact PHRASE; else PROXIMITY ('"a b"~N'): XQNode_t::m_iOpArg
   uint32_t max_qpos, n_qwords;        // ExtRanker_c::m_iMaxQpos (largest query position) / m_iQwords (distinct words)
   int32_t weights[32];

@@ -426,6 +426,7 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
           PackedTerm& x = pt[t];
           HostTerm& h = s->terms[t];
           h.packed_bytes = x.packed_bytes;
+          h.last_rowid = x.last_rowid;
           h.exc_first = (uint32_t)pk_exc.size();
           h.exc_n = (uint32_t)x.exc.size();
           const uint32_t dbase = (uint32_t)pk_delta.size();

@@ -33,6 +33,7 @@ struct HostTerm {
   uint64_t packed_bytes = 0;
   uint32_t blk_first = 0, nblocks = 0, docs = 0, hits = 0;
   uint32_t exc_first = 0, exc_n = 0;
+  uint32_t last_rowid = 0; // rowid of the term's last doc (packed segments)
   uint64_t bm_off = ~0ull, dir_off = ~0ull; // word offsets of the term's bitmap / rank directory, ~0 = none
 };
 

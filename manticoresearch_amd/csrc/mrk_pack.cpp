@@ -178,6 +178,7 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
     return false;
   }
   out.packed_bytes = out.delta.size() * 4 + out.attr.size() * 4 + (uint64_t)nblk * 9;
+  out.last_rowid = rowid;
   if (!want_bm)
     out.bm.clear();
   else {

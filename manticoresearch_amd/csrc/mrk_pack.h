@@ -20,6 +20,7 @@ struct PackedTerm {
   // (15 = look at the attr word), fields in the high one; attr1_ok = false when a doc has a field bit >= 4
   std::vector<uint8_t> attr1;
   bool attr1_ok = true;
+  uint32_t last_rowid = 0; // rowid of the term's last doc
   std::vector<uint32_t> hit;   // 128 per block: the inlined Hitpos_t (inline format, tf == 1) or the doc's
                                // hitlist offset in .spp relative to hbase[block]
   std::vector<uint64_t> hbase; // per block: .spp position of the block's first hitlist

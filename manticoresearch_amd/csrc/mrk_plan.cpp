@@ -74,6 +74,9 @@ struct PlanTree {
   int ph_kw0 = 0, ph_n = 0;
   int px_dist = 0;              // > 0: the phrase node is a PROXIMITY operator ('"a b"~N')
   bool force_tree = false;      // the query must run as a tree program even if it only holds TERM / AND nodes
+  // one real ExtQuorum_c ('"a b c"/N', 1 < N < words): its keywords are kws[q_kw0 .. q_kw0 + q_n) in query-position order
+  bool quorum = false, quorum_root = false;
+  int q_kw0 = 0, q_n = 0, q_thr = 0;
   IntVec atoms;                 // its words' query positions, phrase order
 };
 
@@ -117,8 +120,10 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     // ExtNode_i::Create, SPH_QUERY_QUORUM (searchnode.cpp:1638-1686): threshold 1 = an ExtOr_c chain, threshold >= word
     // count = an ExtAnd_c chain, both over the words sorted by ascending doc count; a real ExtQuorum_c in between
     if (n.n_children < 2 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
-    if (n.opt != 1 && n.opt < n.n_children)
-      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum %d of %d (ExtQuorum_c) is not on the device path", qi, n.opt, n.n_children), -1;
+    if (n.opt < 1) return err = mrk_fail(MRK_E_INVAL, "query %u: quorum threshold %d", qi, n.opt), -1;
+    const bool real_quorum = n.opt != 1 && n.opt < n.n_children;
+    if (real_quorum && (T.quorum || n.n_children > QUORUM_EVENTS))
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum nodes on the device path: one per query, <= %d keywords", qi, QUORUM_EVENTS), -1;
     IntVec kids(n.n_children), ord(n.n_children), docs(n.n_children);
     for (int i = 0; i < n.n_children; ++i) {
       kids[i] = q.children[n.first_child + i];
@@ -134,6 +139,36 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
         std::swap(ord[j], ord[j - 1]);
       }
     const size_t kw0 = T.kws.size();
+    if (real_quorum) {
+      // ExtQuorum_c (searchnode.cpp:4342-4403): children in query-position order, no TERM nodes of their own in the
+      // program -- the node reads its keywords' presence bits itself
+      for (int i = 0; i < n.n_children; ++i) ord[i] = i;
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return q.nodes[kids[a]].atom_pos < q.nodes[kids[b]].atom_pos; });
+      const size_t nodes0 = T.nodes.size();
+      for (int i = 0; i < n.n_children; ++i) {
+        for (int j = 0; j < i; ++j)
+          if (q.nodes[kids[ord[j]]].term_id == q.nodes[kids[ord[i]]].term_id)
+            return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum with a repeated keyword (m_bHasDupes) is not on the device path", qi), -1;
+        (void)leaf(kids[ord[i]]);
+      }
+      T.nodes.n = (int)nodes0; // drop the TERM nodes leaf() appended; the keywords stay in T.kws
+      for (size_t k = kw0; k < T.kws.size(); ++k) {
+        T.kws[k].queried32 &= n.field_mask;
+        // where a keyword's stream ends is only known for unrestricted keywords (its last doc); see qr_row
+        const uint32_t all = seg->n_fields >= 32 ? 0xFFFFFFFFu : (1u << seg->n_fields) - 1u;
+        if ((T.kws[k].queried32 & all) != all)
+          return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: field-limited keywords in a quorum are not on the device path", qi), -1;
+      }
+      T.quorum = true;
+      T.quorum_root = is_root;
+      T.q_kw0 = (int)kw0;
+      T.q_n = n.n_children;
+      T.q_thr = n.opt;
+      PlanNode pn;
+      pn.op = PN_QUORUM;
+      T.nodes.push_back(pn);
+      return (int)T.nodes.size() - 1;
+    }
     int cur = leaf(kids[ord[0]]);
     for (int i = 1; i < n.n_children; ++i) {
       const int r = leaf(kids[ord[i]]);
@@ -218,6 +253,13 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
 // keywords whose doc streams together contain every possible match of the subtree
 static void cover_of(const PlanTree& T, int ni, IntVec& out) {
   const PlanNode& n = T.nodes[ni];
+  if (n.op == PN_QUORUM) { // a match holds >= thr of the n keywords, hence at least one of ANY n - thr + 1: the cheapest ones
+    IntVec k;
+    for (int i = 0; i < T.q_n; ++i) k.push_back(T.q_kw0 + i);
+    std::stable_sort(k.begin(), k.end(), [&](int a, int b) { return T.kws[a].docs < T.kws[b].docs; });
+    for (int i = 0; i < T.q_n - T.q_thr + 1; ++i) out.push_back(k[i]);
+    return;
+  }
   if (n.op == PN_TERM) {
     out.push_back(n.kw);
     return;
@@ -244,6 +286,7 @@ static void cover_of(const PlanTree& T, int ni, IntVec& out) {
 // keywords that must be present for the subtree to match
 static uint32_t required_of(const PlanTree& T, int ni) {
   const PlanNode& n = T.nodes[ni];
+  if (n.op == PN_QUORUM) return 0; // no single keyword is needed
   if (n.op == PN_TERM) return 1u << n.kw;
   if (n.op == PN_AND) return required_of(T, n.l) | required_of(T, n.r);
   if (n.op == PN_OR) return required_of(T, n.l) & required_of(T, n.r);
@@ -290,7 +333,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   const int n = (int)T.kws.size();
   if (n > MRK_MAX_AND_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d keywords (device path: <= %d)", qi, n, MRK_MAX_AND_TERMS);
   if (T.nodes.size() > 16) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
-  const bool single_word = T.nodes.size() == 1;
+  const bool single_word = T.nodes.size() == 1 && T.nodes[0].op == PN_TERM; // XQQuery_t::m_bSingleWord
   bool pure_and = !T.force_tree; // single keyword or one ExtMultiAnd_T: the kernel's N-way AND loop, no program
   for (const PlanNode& pn : T.nodes) pure_and &= pn.op == PN_TERM || pn.op == PN_AND;
   if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE || q.nodes[q.root].op == MRK_OP_PROXIMITY))
@@ -299,7 +342,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   if (!pure_and) { // the device evaluates the program on a TREE_STACK-deep register stack
     int sp = 0, deep = 0;
     for (const PlanNode& pn : T.nodes) {
-      sp += pn.op == PN_TERM ? 1 : pn.op == PN_PHRASEFIX ? 0 : -1;
+      sp += (pn.op == PN_TERM || pn.op == PN_QUORUM) ? 1 : pn.op == PN_PHRASEFIX ? 0 : -1;
       deep = std::max(deep, sp);
     }
     if (deep > TREE_STACK) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree nests deeper than the device path evaluates", qi);
@@ -307,6 +350,8 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
 
   uint32_t ranker;
   bool prox = false;       // a state ranker reads the hit streams
+  if (T.quorum && !T.quorum_root && q.ranker != MRK_RANK_NONE && q.ranker != MRK_RANK_BM25)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: a quorum below another operator with a hit ranker is not on the device path", qi);
   if (T.ph_leaf && n > MAX_PROX_TERMS)
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE in a tree of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
   if (T.phrase || T.ph_leaf) {
@@ -551,6 +596,38 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     P->req_mask = P->excl_mask = 0;
     P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0);
     P->px_dist = (uint32_t)T.px_dist;
+    P->qr_mask = P->qr_thr = P->qr_n = 0;
+    if (T.quorum) {
+      // m_dChildren over time: query-position order; a keyword leaves (RemoveFast: the last one takes its place) once the
+      // doc it sits on was its last -- keywords without docs right at the warmup (searchnode.cpp:4468-4483, 4517-4537)
+      P->qr_thr = (uint32_t)T.q_thr;
+      if (T.quorum_root && prox) P->tree_flags |= TF_QUORUM_HITS;
+      int list[QUORUM_EVENTS], ln = T.q_n;
+      for (int i = 0; i < ln; ++i) list[i] = T.q_kw0 + i, P->qr_mask |= 1u << slot[T.q_kw0 + i];
+      auto pack_order = [&]() {
+        uint32_t o = 0xFFFFFFFFu;
+        for (int i = ln - 1; i >= 0; --i) o = (o << 4) | (uint32_t)slot[list[i]];
+        return o;
+      };
+      auto last_of = [&](int k) -> int64_t { return T.kws[k].docs ? (int64_t)seg->terms[T.kws[k].term_id].last_rowid : -1; };
+      for (int i = 0; i < ln; ++i) // warmup: keywords that hold no doc at all
+        if (last_of(list[i]) < 0) {
+          list[i] = list[--ln];
+          --i;
+        }
+      P->qr_ord[0] = pack_order();
+      while (ln > 0 && P->qr_n < (uint32_t)QUORUM_EVENTS) {
+        int64_t r = INT64_MAX;
+        for (int i = 0; i < ln; ++i) r = std::min(r, last_of(list[i]));
+        for (int i = 0; i < ln; ++i)
+          if (last_of(list[i]) == r) {
+            list[i] = list[--ln];
+            --i;
+          }
+        P->qr_row[P->qr_n] = (uint32_t)r;
+        P->qr_ord[++P->qr_n] = pack_order();
+      }
+    }
     P->ph_mask = 0;
     for (int k = 0; k < T.ph_n; ++k) P->ph_mask |= 1u << slot[T.ph_kw0 + k];
     for (size_t i = 0; i < T.atoms.size(); ++i) P->ph_atoms[i] = (uint32_t)T.atoms[i];

@@ -429,6 +429,7 @@ struct HitCtx {
   int max_qpos, n_qwords; // ExtRanker_c::m_iMaxQpos / m_iQwords
   bool inline_hits, multi_and;
   bool dupes;             // repeated query keywords under a proximity ranker: RankerState_Proximity_fn<.., true>
+  bool quorum_hits;       // the root is an ExtQuorum_c: hits order by position without the end flag (QuorumCmpHitPos_fn)
 };
 
 // One doc's hit pass.  ref0..ref3 = where the doc sits in each keyword's packed arrays (block within the keyword << 7 |
@@ -470,6 +471,7 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
   RankState X;
   X.reset();
   const uint32_t dmask = smask & ~pmask; // keywords whose hits reach the ranker as they are
+  const uint32_t cmpmask = C.quorum_hits ? ~(1u << 23) : 0xFFFFFFFFu; // ExtQuorum_c sorts its hits without the end flag
   // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
   // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
   int phase = (C.multi_and && !pmask && C.nterms == 3 && (sm[0] & sm[1] & sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
@@ -531,7 +533,8 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
     uint32_t bh = 0, bq = 0, bmask = 0;
 #pragma unroll
     for (int t = 0; t < MAX_PROX_TERMS; ++t)
-      if (((dmask >> t) & 1u) && sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && sq[t] < bq)))
+      if (((dmask >> t) & 1u) && sc[t] &&
+          (best < 0 || (sc[t] & cmpmask) < (bh & cmpmask) || ((sc[t] & cmpmask) == (bh & cmpmask) && sq[t] < bq)))
         best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
     if (phave && (best < 0 || pcur < bh || (pcur == bh && (C.ap0 & 0xFFFFu) < (bq & 0xFFFFu)))) {
       X.update(C.ranker, C.dupes, pcur, false, C.ap0 & 0xFFFFu, pw, pspan, C.w_of, C.max_qpos);
@@ -735,6 +738,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   HC.w_of = s.rank;
   HC.max_qpos = (int)Q->max_qpos, HC.n_qwords = (int)Q->n_qwords;
   HC.inline_hits = inline_hits, HC.multi_and = multi_and;
+  HC.quorum_hits = (Q->tree_flags & TF_QUORUM_HITS) != 0;
   HC.dupes = (Q->tree_flags & TF_DUPES) != 0 && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY);
   auto drain_hits = [&](uint32_t from, uint32_t n) {
     if (!PROX) return;
@@ -1108,6 +1112,37 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
               s0.v[r] = m ? v : 0.0f;
               s0.f[r] = m ? f : 0u;
               s0.a[r] = m ? 1u << kw : 0u;
+            }
+          } else if (op == PN_QUORUM) {
+            // ExtQuorum_c (searchnode.cpp:4466-4545): at least qr_thr of its keywords hold the doc; tfidf adds up in the
+            // order m_dChildren has at this rowid (keywords whose doclists ended before it have left by RemoveFast)
+            s3 = s2;
+            s2 = s1;
+            s1 = s0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const uint32_t pm = pres[r] & Q->qr_mask;
+              const bool m = live[r] && (uint32_t)__popc(pm) >= Q->qr_thr;
+              uint32_t ord = Q->qr_ord[0];
+              for (uint32_t e = 0; e < Q->qr_n; ++e)
+                if (row[r] > Q->qr_row[e]) ord = Q->qr_ord[e + 1];
+              float v = 0.0f;
+              uint32_t f = 0;
+              bool first = true;
+#pragma unroll
+              for (int i = 0; i < QUORUM_EVENTS; ++i) {
+                const uint32_t sl = (ord >> (4 * i)) & 15u;
+                if (sl != 15u && ((pm >> sl) & 1u)) {
+                  const float x = L.kv[sl & 7u][lane + 64 * r];
+                  v = first ? x : v + x;
+                  first = false;
+                  f |= L.kf[sl & 7u][lane + 64 * r];
+                }
+              }
+              s0.m[r] = m;
+              s0.v[r] = m ? v : 0.0f;
+              s0.f[r] = m ? f : 0u;
+              s0.a[r] = m ? pm : 0u;
             }
           } else if (op == PN_PHRASEFIX) {
             // ExtNWay_T<FSMphrase_c> over the AND chain of its words just evaluated: the doc stays only if the

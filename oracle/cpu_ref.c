@@ -629,7 +629,7 @@ static void hv_push(hitvec* v, const hit_t* h) {
   v->p[v->n++] = *h;
 }
 
-enum { EN_TERM, EN_MULTIAND, EN_AND, EN_OR, EN_MAYBE, EN_ANDNOT, EN_PHRASE };
+enum { EN_TERM, EN_MULTIAND, EN_AND, EN_OR, EN_MAYBE, EN_ANDNOT, EN_PHRASE, EN_QUORUM };
 
 typedef struct {
   qword qw;
@@ -676,6 +676,12 @@ struct enode {
   fsm_state* states;
   int n_states, cap_states;
   hitvec myhits;
+  /* QUORUM proper (ExtQuorum_c, no duplicate keywords): kids in query-position order; q_list = m_dChildren (indices into
+     kids, reordered by RemoveFast as the keywords' doclists run dry) */
+  enode** kids;
+  int n_kids, q_thresh;
+  int q_list[32], q_n;
+  int* kid_ok;
   /* PROXIMITY (ExtNWay_T<FSMproximity_c>): same node, other state machine */
   int is_proximity;
   int max_distance;          /* m_iMaxDistance = XQNode_t::m_iOpArg */
@@ -1191,6 +1197,71 @@ static void phrase_hits(enode* e, hitvec* out) {
   for (int i = 0; i < e->myhits.n; i++) hv_push(out, &e->myhits.p[i]);
 }
 
+/* ---- ExtQuorum_c (searchnode.cpp:4342-4403, 4466-4545, 4567-4572, 4602-4617), m_bHasDupes == false ---- */
+static int cmp_quorum_hit(const void* pa, const void* pb) { /* QuorumCmpHitPos_fn :4548-4564: positions WITHOUT the end flag */
+  const hit_t* a = (const hit_t*)pa;
+  const hit_t* b = (const hit_t*)pb;
+  uint32_t x = ORC_HIT_POSWITHFIELD(a->hitpos), y = ORC_HIT_POSWITHFIELD(b->hitpos);
+  if (x != y) return x < y ? -1 : 1;
+  if (a->qpos != b->qpos) return a->qpos < b->qpos ? -1 : 1;
+  return 0;
+}
+
+static void quorum_remove_fast(enode* e, int i) { e->q_list[i] = e->q_list[--e->q_n]; }
+
+static int quorum_next(enode* e) {
+  if (!e->started) { /* warmup :4468-4483 */
+    e->started = 1;
+    for (int i = 0; i < e->q_n; i++) {
+      int c = e->q_list[i];
+      e->kid_ok[c] = en_next(e->kids[c]);
+      if (!e->kid_ok[c]) {
+        quorum_remove_fast(e, i);
+        i--;
+      }
+    }
+  }
+  for (;;) {
+    if (e->q_n < e->q_thresh) return 0; /* iQuorumLeft >= m_iThresh */
+    /* find the min rowid, count occurrences; tfidf adds up in m_dChildren order */
+    uint32_t cand = ORC_INVALID_ROWID, fields = 0;
+    float tfidf = 0.0f;
+    int quorum = 0;
+    for (int i = 0; i < e->q_n; i++) {
+      enode* k = e->kids[e->q_list[i]];
+      if (k->rowid < cand) {
+        cand = k->rowid, fields = k->fields, tfidf = k->tfidf;
+        quorum = 1;
+      } else if (k->rowid == cand) {
+        fields |= k->fields;
+        tfidf += k->tfidf;
+        quorum++;
+      }
+    }
+    int matched = quorum >= e->q_thresh;
+    if (matched) { /* CollectMatchingHits :4604-4617 + CollectHits' sort */
+      e->myhits.n = 0;
+      for (int i = 0; i < e->q_n; i++) {
+        enode* k = e->kids[e->q_list[i]];
+        if (k->rowid == cand) en_hits(k, &e->myhits);
+      }
+      qsort(e->myhits.p, (size_t)e->myhits.n, sizeof(hit_t), cmp_quorum_hit);
+      e->rowid = cand, e->fields = fields, e->tfidf = tfidf;
+    }
+    /* advance the children that sit on the candidate :4517-4537 */
+    for (int i = 0; i < e->q_n; i++) {
+      int c = e->q_list[i];
+      if (e->kids[c]->rowid != cand) continue;
+      e->kid_ok[c] = en_next(e->kids[c]);
+      if (!e->kid_ok[c]) {
+        quorum_remove_fast(e, i);
+        i--;
+      }
+    }
+    if (matched) return 1;
+  }
+}
+
 /* ---- dispatch ---- */
 static int en_next(enode* e) {
   int ok;
@@ -1201,6 +1272,7 @@ static int en_next(enode* e) {
     case EN_OR: ok = or_next(e); break;
     case EN_MAYBE: ok = maybe_next(e); break;
     case EN_ANDNOT: ok = andnot_next(e); break;
+    case EN_QUORUM: ok = quorum_next(e); break;
     default: ok = phrase_next(e); break;
   }
   if (!ok) e->rowid = ORC_INVALID_ROWID;
@@ -1215,6 +1287,9 @@ static void en_hits(enode* e, hitvec* out) {
     case EN_OR:
     case EN_MAYBE: or_hits(e, out); break;
     case EN_ANDNOT: en_hits(e->l, out); break; /* :3686-3694 */
+    case EN_QUORUM:
+      for (int i = 0; i < e->myhits.n; i++) hv_push(out, &e->myhits.p[i]);
+      break;
     default: phrase_hits(e, out); break;
   }
 }
@@ -1252,6 +1327,9 @@ static void en_free(enode* e) {
   free(e->states);
   free(e->px_prox);
   free(e->px_deltas);
+  for (int i = 0; i < e->n_kids; i++) en_free(e->kids[i]);
+  free(e->kids);
+  free(e->kid_ok);
   free(e->myhits.p);
   free(e->tmp.p);
   free(e->tmp2.p);
@@ -1404,9 +1482,9 @@ static enode* build_node(build_ctx* bc, int ni) {
         return NULL;
       }
       const int thr = qn->opt;
-      if (thr != 1 && thr < k) {
+      if (thr < 1) {
         bc->error = 1;
-        fail("ExtQuorum_c (1 < threshold < words) not restated in the oracle");
+        fail("quorum threshold must be >= 1");
         return NULL;
       }
       enode* terms[32];
@@ -1424,6 +1502,30 @@ static enode* build_node(build_ctx* bc, int ni) {
         terms[i] = build_term(bc, &w);
         key[i] = en_docs_count(terms[i]);
         pos[i] = i;
+      }
+      if (thr != 1 && thr < k) { /* a real ExtQuorum_c: children stay in query-position order (QuorumNodeAtomPos_fn) */
+        for (int i = 0; i < k; i++)
+          for (int j = i + 1; j < k; j++)
+            if (q->nodes[q->children[qn->first_child + i]].term_id == q->nodes[q->children[qn->first_child + j]].term_id) {
+              bc->error = 1;
+              fail("ExtQuorum_c with duplicate keywords (m_bHasDupes) not restated in the oracle");
+              for (int t = 0; t < k; t++) en_free(terms[t]);
+              return NULL;
+            }
+        enode* e = en_new(bc, EN_QUORUM);
+        e->kids = (enode**)malloc((size_t)k * sizeof(enode*));
+        e->kid_ok = (int*)calloc((size_t)k, sizeof(int));
+        for (int i = 1; i < k; i++) /* insertion sort by atom position (stable; positions are distinct) */
+          for (int j = i; j > 0 && terms[j - 1]->atom > terms[j]->atom; j--) {
+            enode* t = terms[j];
+            terms[j] = terms[j - 1];
+            terms[j - 1] = t;
+          }
+        for (int i = 0; i < k; i++) e->kids[i] = terms[i], e->q_list[i] = i;
+        e->n_kids = e->q_n = k;
+        e->q_thresh = thr;
+        e->atom = terms[0]->atom;
+        return e;
       }
       sph_isort_idx(pos, k, key); /* dTerms.Sort ( ExtNodeTF_fn() ) */
       enode* cur = terms[pos[0]];
@@ -1555,6 +1657,9 @@ static void collect_qwords(enode* e, qw_hash* h, int* dupes) {
       for (int i = 0; i < e->n_m; i++) collect_mnode(&e->m[i], h, dupes);
       break;
     case EN_PHRASE: collect_qwords(e->inner, h, dupes); break;
+    case EN_QUORUM:
+      for (int i = 0; i < e->n_kids; i++) collect_qwords(e->kids[i], h, dupes);
+      break;
     default:
       collect_qwords(e->l, h, dupes);
       collect_qwords(e->r, h, dupes);
@@ -1574,6 +1679,9 @@ static void set_idf(enode* e, const qw_hash* h) {
       for (int i = 0; i < e->n_m; i++) set_mnode_idf(&e->m[i], h);
       break;
     case EN_PHRASE: set_idf(e->inner, h); break;
+    case EN_QUORUM:
+      for (int i = 0; i < e->n_kids; i++) set_idf(e->kids[i], h);
+      break;
     default:
       set_idf(e->l, h);
       set_idf(e->r, h);

@@ -863,3 +863,49 @@ def test_candidate_overflow_is_rerun(orc, dev):
         finally:
             seg.close()
     ctx.set("bitmap_inv", 64)
+
+
+# ------------------------------------------------------------------ ExtQuorum_c proper ('"a b c d"/N', 1 < N < words)
+def QUORUM(m, thr, *k, mask=0xFFFFFFFF):
+    return m.XQNode(m.SPH_QUERY_QUORUM, list(k), None, mask, thr)
+
+
+@pytest.mark.parametrize("block,fmt", [(128, 1), (32, 0)])
+def test_quorum_node(orc, dev, block, fmt):
+    """A real quorum node: docs holding at least N of the keywords, tfidf summed in the order ExtQuorum_c's child list
+    has at that rowid (rare keywords' doclists end early and reorder it), hits sorted without the end flag."""
+    _tree_only(dev)
+    m, ctx, batch = dev
+    rng = np.random.default_rng(606 + block + fmt)
+    n_docs = 40000
+    probs = [0.5, 0.3, 0.12, 0.05, 0.02, 0.004, 0.0008, 0.9]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=30, end_markers=True)
+    # make a few keywords stop early, so that the child list is reordered well before the corpus ends
+    keep = ~(((W == 3) & (R > 9000)) | ((W == 5) & (R > 21000)) | ((W == 2) & (R > 33000)))
+    W, R, H = W[keep], R[keep], H[keep]
+    nt = len(probs) + 1  # last keyword has no postings
+    hi = m.index_from_hits(W, R, H, n_terms=nt, total_docs=n_docs, skiplist_block_size=block, hit_format=fmt, n_fields=3)
+    qs = []
+    for i in range(90):
+        k = int(rng.integers(3, 7))
+        ts = [int(t) for t in rng.choice(nt, size=k, replace=False)]
+        thr = int(rng.integers(max(2, k - 2), k))  # k - thr + 1 driver keywords (<= 4 per query on the device path)
+        kws = [kw(m, t, j + 1) for j, t in enumerate(ts)]
+        if rng.random() < 0.3:
+            rng.shuffle(kws)  # children arrive in any order; the node sorts them by query position
+        root = QUORUM(m, thr, *kws)
+        rk = int(rng.choice([m.SPH_RANK_BM25, m.SPH_RANK_NONE]))
+        if k <= 4 and i % 2:
+            rk = int(rng.choice([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY, m.SPH_RANK_WORDCOUNT, m.SPH_RANK_SPH04]))
+        if i % 5 == 0 and rk in (m.SPH_RANK_BM25, m.SPH_RANK_NONE):  # below other operators (weight-sum rankers only)
+            extra = kw(m, [t for t in range(nt) if t not in ts][0], k + 1)
+            root = [m.XQNode.AND(root, extra), OR(m, root, extra), ANDNOT(m, root, extra)][i % 3]
+        qs.append(m.Query(root, ranker=rk, max_matches=int(rng.choice([10, 1000])),
+                          field_weights=[int(x) for x in rng.integers(-2, 9, 3)] if rng.random() < 0.4 else None))
+    check_batch(orc, dev, hi, qs)
+    # declined shapes stay loud: a field-limited keyword, a repeated keyword
+    seg = m.Segment(ctx, hi)
+    r = batch.search(seg, [m.Query(QUORUM(m, 2, kw(m, 0, 1, 0b01), kw(m, 1, 2), kw(m, 2, 3)), ranker=m.SPH_RANK_BM25),
+                           m.Query(QUORUM(m, 2, kw(m, 0, 1), kw(m, 0, 2), kw(m, 2, 3)), ranker=m.SPH_RANK_BM25)])
+    assert r[0].status == -2 and r[1].status == -2
+    seg.close()

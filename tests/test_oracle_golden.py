@@ -213,3 +213,27 @@ def test_reference_byte_vectors(orc):
     idx = orc.build_index(np.ones(len(hits), np.uint64), np.zeros(len(hits), np.uint32), np.array(hits, np.uint32),
                           total_docs=1, n_terms=1)
     assert bytes(idx.spp) == bytes(GOLDEN["hitlist_bytes"]["spp"])
+
+
+# ------------------------------------------------------------------ ExtQuorum_c proper: no golden in the reference tree
+def test_quorum_node_against_set_arithmetic(orc):
+    """'"a b c d"/N' with 1 < N < words is a real ExtQuorum_c (searchnode.cpp:4342-4617).  The reference holds no golden
+    for it (its test_019 quorum queries take the OR / AND rewrites), so the restatement is checked against what the
+    operator means: a doc matches iff it holds at least N of the keywords; and N = words - 1 over two-word subsets."""
+    from helpers import synth_postings
+
+    rng = np.random.default_rng(11)
+    n_docs, probs = 4000, [0.5, 0.3, 0.2, 0.1, 0.05]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=2, max_pos=30)
+    idx = orc.build_index(W, R, H, total_docs=n_docs, n_fields=2, n_terms=len(probs))
+    have = np.zeros((len(probs), n_docs), bool)
+    for t in range(len(probs)):
+        have[t, idx.decode_doclist(t)[0]] = True
+    for words in ([0, 1, 2], [4, 2, 0, 1], [0, 1, 2, 3, 4]):
+        for thr in range(2, len(words)):
+            root = orc.op(orc.OP_QUORUM, *[orc.term(t, i + 1) for i, t in enumerate(words)], opt=thr)
+            for ranker in (orc.RANK_BM25, orc.RANK_PROXIMITY_BM25, orc.RANK_WORDCOUNT):
+                r = orc.search(idx, root, ranker=ranker, max_matches=n_docs)
+                want = np.nonzero(have[words].sum(0) >= thr)[0]
+                assert r.total_found == len(want)
+                assert sorted(int(x) for x in r.rowid) == [int(x) for x in want]
