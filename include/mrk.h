@@ -268,6 +268,39 @@ const uint8_t* mrk_host_index_spp(const mrk_host_index* h, uint64_t* len);
 const uint8_t* mrk_host_index_spe(const mrk_host_index* h, uint64_t* len);
 const mrk_dict_entry* mrk_host_index_dict(const mrk_host_index* h, uint32_t* n_terms);
 
+/* ------------------------------------------------------------------------------------
+ * Real index ingestion: the files a Manticore 3.x indexer / RT disk chunk wrote,
+ * format versions 54..62, read from disk into the same host-side object.  Replaces CSphIndex_VLN::LoadHeader
+ * (sphinx.cpp:13252-13388), CWordlist::Preread + the dictionary block readers (indexformat.cpp:279-344, 425-470,
+ * 641-691) and DeadRowMap_Disk_c (killlist.cpp:171-184) for what the match -> rank -> top-K path needs.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t version;             /* .sph format version (54..62) */
+  uint32_t n_fields, n_attrs;   /* schema */
+  uint32_t skiplist_block_size; /* 128 before v56, else the stored setting */
+  uint32_t hit_format;          /* MRK_HITFMT_* (ESphHitFormat) */
+  uint32_t hitless;             /* ESphHitless; only 0 (none) can be searched here */
+  uint32_t word_dict;           /* 1 = dict=keywords, 0 = dict=crc */
+  uint32_t min_prefix_len, min_infix_len;
+  uint32_t index_sp, index_field_lens;
+  uint32_t n_checkpoints;
+  uint64_t total_docs, total_bytes; /* m_tStats */
+  uint64_t n_dead;                  /* bits set in the .spm dead-row map */
+} mrk_index_info;
+
+/* path_prefix + ".sph" / ".spi" / ".spd" / ".spp" / ".spe" (/ ".spm", optional).  Term ids of the result are the
+   dictionary's entries in file order (sorted by keyword for dict=keywords, by word id for dict=crc). */
+int mrk_index_open(const char* path_prefix, mrk_host_index** out);
+int mrk_host_index_info(const mrk_host_index* h, mrk_index_info* out); /* MRK_E_INVAL unless opened from files */
+const char* mrk_host_index_field_name(const mrk_host_index* h, uint32_t field);
+/* dict=keywords: term id of a keyword (sphDictCmpStrictly order, sphinxint.h), -1 = not in the dictionary */
+int32_t mrk_host_index_find_word(const mrk_host_index* h, const char* word, int32_t len);
+const char* mrk_host_index_word(const mrk_host_index* h, uint32_t term_id, uint32_t* len);
+/* dict=crc: term id of a word id, -1 = absent */
+int32_t mrk_host_index_find_wordid(const mrk_host_index* h, uint64_t wordid);
+/* .spm bitmap (bit rowid & 31 of word rowid >> 5), as mrk_segment_set_dead_rows takes it; NULL = no map */
+const uint32_t* mrk_host_index_dead_rows(const mrk_host_index* h, uint64_t* n_rows);
+
 #ifdef __cplusplus
 }
 #endif

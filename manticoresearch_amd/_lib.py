@@ -61,6 +61,15 @@ class BatchStats(C.Structure):
                 ("n_items_bm", C.c_uint64), ("plan_ms", C.c_float), ("submit_ms", C.c_float)]
 
 
+class IndexInfo(C.Structure):
+    """mrk_index_info (include/mrk.h)"""
+    _fields_ = [("version", C.c_uint32), ("n_fields", C.c_uint32), ("n_attrs", C.c_uint32),
+                ("skiplist_block_size", C.c_uint32), ("hit_format", C.c_uint32), ("hitless", C.c_uint32),
+                ("word_dict", C.c_uint32), ("min_prefix_len", C.c_uint32), ("min_infix_len", C.c_uint32),
+                ("index_sp", C.c_uint32), ("index_field_lens", C.c_uint32), ("n_checkpoints", C.c_uint32),
+                ("total_docs", C.c_uint64), ("total_bytes", C.c_uint64), ("n_dead", C.c_uint64)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_docs", C.c_uint64), ("shard", C.c_uint32), ("term_prob", C.POINTER(C.c_double)),
                 ("n_terms", C.c_uint32), ("n_fields", C.c_uint32), ("title_frac", C.c_double), ("max_pos", C.c_uint32),
@@ -102,6 +111,13 @@ SYMBOLS = [
     ("mrk_host_index_spp", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("mrk_host_index_spe", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("mrk_host_index_dict", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("mrk_index_open", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    ("mrk_host_index_info", C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),
+    ("mrk_host_index_field_name", C.c_char_p, [C.c_void_p, C.c_uint32]),
+    ("mrk_host_index_find_word", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int32]),
+    ("mrk_host_index_word", C.c_void_p, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("mrk_host_index_find_wordid", C.c_int32, [C.c_void_p, C.c_uint64]),
+    ("mrk_host_index_dead_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
 ]
 
 

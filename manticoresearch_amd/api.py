@@ -12,6 +12,7 @@ HIP kernels of csrc/mrk_kernels.hip.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
@@ -84,6 +85,43 @@ def _take_host_index(h, total_docs: int, skiplist_block_size: int, hit_format: i
         C.memmove(d.ctypes.data, p, nt.value * DICT_DTYPE.itemsize)
     hi = HostIndex(out["spd"], out["spp"], out["spe"], d, total_docs, skiplist_block_size, hit_format, n_fields)
     hi._owner = owner
+    return hi
+
+
+def open_index(path_prefix: str) -> HostIndex:
+    """Read the files of a real Manticore 3.x index / RT disk chunk (<prefix>.sph .spi .spd .spp .spe [.spm]).
+
+    The result carries what the header says (`info`, `fields`), the keywords (`words`, dict=keywords), `find_word()`
+    -- the dictionary lookup DiskIndexQwordSetup_c::Setup does (sphinx.cpp:12953-13060) -- and the dead-row bitmap
+    of the .spm file (`dead_bitmap` for Segment.set_dead_rows(), `dead_rows` as rowids; None when no row is dead)."""
+    L = lib()
+    h = C.c_void_p()
+    check(L.mrk_index_open(os.fsencode(path_prefix), C.byref(h)))
+    info = _lib.IndexInfo()
+    check(L.mrk_host_index_info(h, C.byref(info)))
+    hi = _take_host_index(h, int(info.total_docs), int(info.skiplist_block_size), int(info.hit_format), int(info.n_fields))
+    hi.info = {k: int(getattr(info, k)) for k, _ in _lib.IndexInfo._fields_}
+    hi.fields = [L.mrk_host_index_field_name(h, i).decode() for i in range(info.n_fields)]
+    hi.words = []
+    if info.word_dict:
+        n = C.c_uint32()
+        for t in range(len(hi.dict)):
+            p = L.mrk_host_index_word(h, t, C.byref(n))
+            hi.words.append(C.string_at(p, n.value).decode("utf-8", "surrogateescape"))
+    nrows = C.c_uint64()
+    p = L.mrk_host_index_dead_rows(h, C.byref(nrows))
+    hi.dead_bitmap = hi.dead_rows = None
+    if p and info.n_dead:
+        hi.dead_bitmap = np.frombuffer((C.c_uint32 * ((nrows.value + 31) // 32)).from_address(p), dtype=np.uint32).copy()
+        bits = np.unpackbits(hi.dead_bitmap.view(np.uint8), bitorder="little")[: nrows.value]
+        hi.dead_rows = np.flatnonzero(bits).astype(np.uint32)
+
+    def find_word(word, _h=h, _owner=hi._owner):
+        b = word.encode() if isinstance(word, str) else bytes(word)
+        return int(L.mrk_host_index_find_word(_h, b, len(b)))
+
+    hi.find_word = find_word
+    hi.find_wordid = lambda wid, _h=h, _owner=hi._owner: int(L.mrk_host_index_find_wordid(_h, wid))
     return hi
 
 
@@ -348,5 +386,5 @@ def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool =
 __all__ = ["SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
            "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM",
-           "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Matches", "Context",
+           "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Matches", "Context",
            "Segment", "Batch", "prepare", "idf", "MrkError"]

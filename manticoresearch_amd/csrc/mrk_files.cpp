@@ -1,0 +1,417 @@
+// mrk_files.cpp -- real index ingestion: reads the files a Manticore 3.x indexer (or an RT disk chunk save) wrote and
+// hands them to the device path as a mrk_host_index.  Host only; nothing here touches the GPU.
+//
+//   .sph  header, format versions 54..62 (CSphIndex_VLN::LoadHeader, sphinx.cpp:13252-13388; ReadSchema :8722-8781;
+//         LoadIndexSettings :13207-13249; CSphTokenizerSettings::Load / CSphDictSettings::Load /
+//         CSphFieldFilterSettings::Load, indexsettings.cpp:303-334, 405-458, 506-515; CSphSavedFile::Read,
+//         fileutils.cpp:114-119).  Everything is parsed -- the fields sit behind variable-length strings -- but only
+//         what the match -> rank -> top-K path consumes is kept (mrk_index_info).
+//   .spi  dictionary (doc/internals-index-format.txt:97-170).  dict=keywords: checkpoints {dword len, keyword, qword
+//         offset} (CWordlist::Preread, indexformat.cpp:331-344), blocks of front-coded keywords
+//         (KeywordsBlockReader_c::UnpackWord, :641-691).  dict=crc: checkpoints {qword wordid, qword offset}, blocks
+//         of delta-coded {wordid, doclist offset, docs, hits, [skiplist offset]} (CWordlist::GetWord, :425-470).
+//         The whole dictionary is expanded into the flat table the C-ABI takes: the lookup the reference does per
+//         query (checkpoint search + block scan, DiskIndexQwordSetup_c::Setup, sphinx.cpp:12953-13060) becomes a
+//         binary search over that table.
+//   .spd / .spp / .spe   taken as they are.
+//   .spm  dead-row map: one bit per row, DWORD words (DeadRowMap_c::IsSet, killlist.h:39-46).
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mrk_hostindex.h"
+
+int mrk_fail(int code, const char* fmt, ...);
+
+namespace {
+
+constexpr uint32_t SPH_MAGIC = 0x58485053u; // "SPHX"
+constexpr uint32_t MIN_VERSION = 54, MAX_VERSION = 62;
+constexpr uint32_t DOCLIST_HINT_THRESH = 256; // indexformat.h:20
+constexpr uint32_t HITLESS_FLAG = 0x80000000u;
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out, bool optional = false) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) {
+    if (!optional) mrk_fail(MRK_E_FORMAT, "cannot open %s", path.c_str());
+    return false;
+  }
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  const size_t got = out.empty() ? 0 : fread(out.data(), 1, out.size(), f);
+  fclose(f);
+  if (got != out.size()) {
+    mrk_fail(MRK_E_FORMAT, "short read on %s", path.c_str());
+    return false;
+  }
+  return true;
+}
+
+// posting files go straight into the malloc'd, slack-padded buffers the host index owns
+bool read_postings(const std::string& path, uint8_t*& buf, uint64_t& len) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) {
+    mrk_fail(MRK_E_FORMAT, "cannot open %s", path.c_str());
+    return false;
+  }
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  len = n > 0 ? (uint64_t)n : 0;
+  buf = (uint8_t*)calloc(len + 64, 1);
+  if (!buf) {
+    fclose(f);
+    mrk_fail(MRK_E_NOMEM, "out of memory reading %s", path.c_str());
+    return false;
+  }
+  const size_t got = len ? fread(buf, 1, len, f) : 0;
+  fclose(f);
+  if (got != len) {
+    mrk_fail(MRK_E_FORMAT, "short read on %s", path.c_str());
+    return false;
+  }
+  return true;
+}
+
+// CSphReader's getters over a byte buffer (fileio.cpp): little-endian fixed ints, dword-length strings, VLB
+struct Reader {
+  const uint8_t* p;
+  size_t n, at = 0;
+  bool bad = false;
+  Reader(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
+  bool need(size_t k) {
+    if (bad || n - at < k) bad = true;
+    return !bad;
+  }
+  uint8_t byte() { return need(1) ? p[at++] : 0; }
+  uint32_t dword() {
+    if (!need(4)) return 0;
+    uint32_t v;
+    memcpy(&v, p + at, 4);
+    at += 4;
+    return v;
+  }
+  uint64_t offset() {
+    if (!need(8)) return 0;
+    uint64_t v;
+    memcpy(&v, p + at, 8);
+    at += 8;
+    return v;
+  }
+  std::string str() {
+    const uint32_t len = dword();
+    if (!need(len)) return std::string();
+    std::string s((const char*)p + at, len);
+    at += len;
+    return s;
+  }
+  uint64_t zint() { // sphUnzipInt / sphUnzipOffset / sphUnzipWordid: 7-bit groups, most significant first
+    uint64_t v = 0;
+    for (;;) {
+      const uint8_t b = byte();
+      if (bad) return 0;
+      v = (v << 7) | (b & 0x7fu);
+      if (!(b & 0x80u)) return v;
+    }
+  }
+  void saved_file() { // CSphSavedFile::Read: size, ctime, mtime, crc32
+    offset(), offset(), offset(), dword();
+  }
+};
+
+void schema_column(Reader& r, uint32_t version) { // ReadSchemaColumn
+  r.str();
+  r.dword(), r.dword(), r.dword(), r.dword(); // type, rowitem, bit offset, bit count
+  r.byte();                                   // payload
+  if (version >= 61) r.dword();               // attr flags
+}
+
+int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_index* h, uint64_t& cp_offset) {
+  Reader r(sph.data(), sph.size());
+  mrk_index_info& I = h->info;
+  if (r.dword() != SPH_MAGIC) return mrk_fail(MRK_E_FORMAT, "%s: not an index header (magic)", name);
+  I.version = r.dword();
+  if (I.version < MIN_VERSION || I.version > MAX_VERSION)
+    return mrk_fail(MRK_E_FORMAT, "%s is v.%u, this reader covers v.%u..%u", name, I.version, MIN_VERSION, MAX_VERSION);
+  // schema: full-text fields, then attributes
+  I.n_fields = r.dword();
+  if (I.n_fields > 256) return mrk_fail(MRK_E_FORMAT, "%s: %u fields", name, I.n_fields);
+  for (uint32_t i = 0; i < I.n_fields && !r.bad; ++i) {
+    if (I.version >= 57) { // ReadSchemaField
+      h->fields.push_back(r.str());
+      r.dword(); // field flags
+      r.byte();  // payload
+    } else {
+      const size_t at = r.at;
+      std::string nm = r.str();
+      r.at = at;
+      schema_column(r, I.version);
+      h->fields.push_back(nm);
+    }
+  }
+  I.n_attrs = r.dword();
+  if (I.n_attrs > 65536) return mrk_fail(MRK_E_FORMAT, "%s: %u attributes", name, I.n_attrs);
+  for (uint32_t i = 0; i < I.n_attrs && !r.bad; ++i) schema_column(r, I.version);
+  // dictionary header
+  cp_offset = r.offset();
+  I.n_checkpoints = r.dword();
+  r.byte();  // infix codepoint bytes
+  r.dword(); // infix blocks offset
+  r.dword(); // infix blocks words size
+  // index stats
+  I.total_docs = r.dword();
+  I.total_bytes = r.offset();
+  // LoadIndexSettings
+  I.min_prefix_len = r.dword();
+  I.min_infix_len = r.dword();
+  r.dword(); // max substring len
+  r.byte();  // html strip
+  r.str(), r.str();
+  r.byte(); // index exact words
+  I.hitless = r.dword();
+  I.hit_format = r.dword();
+  I.index_sp = r.byte();
+  r.str();                                    // zones
+  r.dword(), r.dword(), r.dword(), r.dword(); // boundary / stopword / overshort steps, embedded limit
+  r.byte();                                   // bigram index
+  r.str();                                    // bigram words
+  I.index_field_lens = r.byte();
+  r.byte();   // preprocessor
+  r.str();    // was: RLP context
+  r.str();    // index token filter
+  r.offset(); // blob update space
+  I.skiplist_block_size = I.version < 56 ? 128u : r.dword();
+  if (I.version >= 60) r.str(); // hitless files
+  // tokenizer settings
+  r.byte(); // type
+  r.str();  // case folding
+  r.dword();
+  if (r.byte()) { // embedded synonyms
+    const uint32_t ns = r.dword();
+    for (uint32_t i = 0; i < ns && !r.bad; ++i) r.str();
+  }
+  r.str();
+  r.saved_file();
+  r.str(), r.str();
+  r.dword();
+  r.str(), r.str(), r.str();
+  // dictionary settings
+  r.str(), r.str();
+  const bool emb_stop = r.byte() != 0;
+  if (emb_stop) {
+    const uint32_t ns = r.dword();
+    for (uint32_t i = 0; i < ns && !r.bad; ++i) r.zint();
+  }
+  r.str();
+  const uint32_t n_stop_files = r.dword();
+  for (uint32_t i = 0; i < n_stop_files && !r.bad; ++i) {
+    r.str();
+    r.saved_file();
+  }
+  if (r.byte()) { // embedded wordforms
+    const uint32_t nw = r.dword();
+    for (uint32_t i = 0; i < nw && !r.bad; ++i) r.str();
+  }
+  const uint32_t n_wf = r.dword();
+  for (uint32_t i = 0; i < n_wf && !r.bad; ++i) {
+    r.str();
+    r.saved_file();
+  }
+  r.dword(); // min stemming len
+  I.word_dict = r.byte() != 0;
+  r.byte(); // stopwords unstemmed
+  r.str();  // morphology fingerprint
+  r.offset(), r.offset(), r.offset(); // docinfo, docinfo index, min-max index
+  const uint32_t n_re = r.dword();
+  for (uint32_t i = 0; i < n_re && !r.bad; ++i) r.str();
+  if (I.index_field_lens)
+    for (uint32_t i = 0; i < I.n_fields; ++i) r.offset();
+  if (r.bad) return mrk_fail(MRK_E_FORMAT, "%s: failed to parse header (unexpected eof)", name);
+  if (I.skiplist_block_size == 0 || I.skiplist_block_size > (1u << 20))
+    return mrk_fail(MRK_E_FORMAT, "%s: skiplist block size %u", name, I.skiplist_block_size);
+  if (I.hit_format > 1) return mrk_fail(MRK_E_FORMAT, "%s: hit format %u", name, I.hit_format);
+  return MRK_OK;
+}
+
+int parse_dict(const std::vector<uint8_t>& spi, const char* name, uint64_t cp_offset, mrk_host_index* h, std::vector<uint64_t>& wordids) {
+  const mrk_index_info& I = h->info;
+  if (I.n_checkpoints == 0) return MRK_OK; // empty index
+  if (cp_offset == 0 || cp_offset >= spi.size()) return mrk_fail(MRK_E_FORMAT, "%s: checkpoints offset past the file", name);
+  Reader cp(spi.data(), spi.size());
+  cp.at = (size_t)cp_offset;
+  std::vector<uint64_t> blocks(I.n_checkpoints);
+  for (uint32_t i = 0; i < I.n_checkpoints; ++i) {
+    if (I.word_dict)
+      cp.str(); // dword length + the block's first keyword
+    else
+      cp.offset(); // the block's first word id
+    blocks[i] = cp.offset();
+  }
+  if (cp.bad) return mrk_fail(MRK_E_FORMAT, "%s: truncated checkpoints", name);
+  char word[3 * 42 + 4 + 128] = {0}; // MAX_KEYWORD_BYTES-sized scratch, generously
+  for (uint32_t b = 0; b < I.n_checkpoints; ++b) {
+    if (blocks[b] == 0 || blocks[b] >= cp_offset) return mrk_fail(MRK_E_FORMAT, "%s: checkpoint %u points outside the word blocks", name, b);
+    Reader r(spi.data(), (size_t)cp_offset);
+    r.at = (size_t)blocks[b];
+    uint64_t last_id = 0, last_off = 0;
+    uint32_t wlen = 0;
+    for (;;) {
+      mrk_dict_entry e{};
+      if (I.word_dict) {
+        const uint8_t pack = r.byte();
+        if (r.bad || !pack) break; // block end
+        uint32_t match, delta;
+        if (pack & 0x80u)
+          delta = ((pack >> 4) & 7u) + 1u, match = pack & 15u;
+        else
+          delta = pack & 127u, match = r.byte();
+        if (match > wlen || match + delta >= sizeof(word) - 1 || !r.need(delta))
+          return mrk_fail(MRK_E_FORMAT, "%s: broken keyword entry in block %u", name, b);
+        memcpy(word + match, r.p + r.at, delta);
+        r.at += delta;
+        wlen = match + delta;
+        word[wlen] = 0;
+        e.doclist_off = r.zint();
+        e.docs = (uint32_t)r.zint();
+        e.hits = (uint32_t)r.zint();
+        if (e.docs >= DOCLIST_HINT_THRESH) r.byte(); // doclist size hint
+        e.skiplist_off = (e.docs & ~HITLESS_FLAG) > I.skiplist_block_size ? r.zint() : 0;
+        h->word_off.push_back((uint32_t)h->words.size());
+        h->words.insert(h->words.end(), word, word + wlen + 1);
+      } else {
+        const uint64_t dw = r.zint();
+        if (r.bad || !dw) break; // block end (followed by the last doclist's length)
+        last_id += dw;
+        last_off += r.zint();
+        e.wordid = last_id;
+        e.doclist_off = last_off;
+        e.docs = (uint32_t)r.zint();
+        e.hits = (uint32_t)r.zint();
+        e.skiplist_off = (e.docs & ~HITLESS_FLAG) > I.skiplist_block_size ? r.zint() : 0;
+        wordids.push_back(last_id);
+      }
+      if (r.bad) return mrk_fail(MRK_E_FORMAT, "%s: truncated dictionary block %u", name, b);
+      if (e.docs & HITLESS_FLAG) return mrk_fail(MRK_E_UNSUPPORTED, "%s: hitless keywords are not on the device path", name);
+      if (!e.docs || !e.hits || !e.doclist_off) return mrk_fail(MRK_E_FORMAT, "%s: dictionary entry without postings in block %u", name, b);
+      h->dict.push_back(e);
+    }
+    if (r.bad) return mrk_fail(MRK_E_FORMAT, "%s: dictionary block %u runs past the checkpoints", name, b);
+  }
+  return MRK_OK;
+}
+
+} // namespace
+
+extern "C" int mrk_index_open(const char* path_prefix, mrk_host_index** out) {
+  if (!path_prefix || !out) return mrk_fail(MRK_E_INVAL, "mrk_index_open: null argument");
+  *out = nullptr;
+  const std::string base(path_prefix);
+  mrk_host_index* h = new (std::nothrow) mrk_host_index();
+  if (!h) return mrk_fail(MRK_E_NOMEM, "out of memory");
+  h->from_files = true;
+  std::vector<uint8_t> sph, spi, spm;
+  std::vector<uint64_t> wordids;
+  uint64_t cp_offset = 0;
+  int rc = MRK_OK;
+  if (!read_file(base + ".sph", sph) || !read_file(base + ".spi", spi)) rc = MRK_E_FORMAT;
+  if (rc == MRK_OK) rc = parse_header(sph, (base + ".sph").c_str(), h, cp_offset);
+  if (rc == MRK_OK && h->info.hitless != 0) rc = mrk_fail(MRK_E_UNSUPPORTED, "%s: hitless index (hitless_words) is not on the device path", path_prefix);
+  if (rc == MRK_OK) rc = parse_dict(spi, (base + ".spi").c_str(), cp_offset, h, wordids);
+  if (rc == MRK_OK && (!read_postings(base + ".spd", h->spd, h->spd_len) || !read_postings(base + ".spp", h->spp, h->spp_len) ||
+                       !read_postings(base + ".spe", h->spe, h->spe_len)))
+    rc = MRK_E_FORMAT;
+  if (rc == MRK_OK) {
+    // m_iDoclistLength: doclists lie back to back in .spd (in word-id order, not in dictionary order), each ends with its 0
+    std::vector<uint32_t> by_off(h->dict.size());
+    for (uint32_t i = 0; i < by_off.size(); ++i) by_off[i] = i;
+    std::sort(by_off.begin(), by_off.end(), [&](uint32_t a, uint32_t b) { return h->dict[a].doclist_off < h->dict[b].doclist_off; });
+    for (size_t i = 0; i < by_off.size() && rc == MRK_OK; ++i) {
+      mrk_dict_entry& e = h->dict[by_off[i]];
+      const uint64_t end = i + 1 < by_off.size() ? h->dict[by_off[i + 1]].doclist_off : h->spd_len;
+      if (end <= e.doclist_off || end > h->spd_len || h->spd[end - 1] != 0)
+        rc = mrk_fail(MRK_E_FORMAT, "%s.spd: doclist at %llu does not end where the next one starts", path_prefix, (unsigned long long)e.doclist_off);
+      e.doclist_len = end - e.doclist_off;
+      if (e.skiplist_off >= h->spe_len && e.docs > h->info.skiplist_block_size)
+        rc = mrk_fail(MRK_E_FORMAT, "%s.spe: skiplist offset %llu past the file", path_prefix, (unsigned long long)e.skiplist_off);
+    }
+  }
+  if (rc == MRK_OK && !h->info.word_dict)
+    for (size_t i = 0; i < h->dict.size(); ++i) h->dict[i].wordid = wordids[i];
+  if (rc == MRK_OK && read_file(base + ".spm", spm, true)) {
+    h->dead.assign((spm.size() + 3) / 4, 0u);
+    if (!spm.empty()) memcpy(h->dead.data(), spm.data(), spm.size());
+    const uint64_t rows = h->info.total_docs;
+    for (uint64_t r = 0; r < rows && (r >> 5) < h->dead.size(); ++r) h->info.n_dead += (h->dead[r >> 5] >> (r & 31u)) & 1u;
+    if (h->dead.size() * 32ull < rows) rc = mrk_fail(MRK_E_FORMAT, "%s.spm: %zu bytes for %llu rows", path_prefix, spm.size(), (unsigned long long)rows);
+  }
+  if (rc != MRK_OK) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return MRK_OK;
+}
+
+extern "C" int mrk_host_index_info(const mrk_host_index* h, mrk_index_info* out) {
+  if (!h || !out || !h->from_files) return mrk_fail(MRK_E_INVAL, "mrk_host_index_info: not an index opened from files");
+  *out = h->info;
+  return MRK_OK;
+}
+
+extern "C" const char* mrk_host_index_field_name(const mrk_host_index* h, uint32_t field) {
+  return (h && field < h->fields.size()) ? h->fields[field].c_str() : nullptr;
+}
+
+extern "C" const char* mrk_host_index_word(const mrk_host_index* h, uint32_t term_id, uint32_t* len) {
+  if (!h || term_id >= h->word_off.size()) return nullptr;
+  const char* w = h->words.data() + h->word_off[term_id];
+  if (len) *len = (uint32_t)strlen(w);
+  return w;
+}
+
+// sphDictCmpStrictly: bytes first, then length
+extern "C" int32_t mrk_host_index_find_word(const mrk_host_index* h, const char* word, int32_t len) {
+  if (!h || !word || len <= 0 || h->word_off.empty()) return -1;
+  size_t lo = 0, hi = h->word_off.size();
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    const char* w = h->words.data() + h->word_off[mid];
+    const int32_t wl = (int32_t)strlen(w);
+    int c = memcmp(word, w, (size_t)std::min(len, wl));
+    if (c == 0) c = len - wl;
+    if (c == 0) return (int32_t)mid;
+    if (c < 0)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  return -1;
+}
+
+extern "C" int32_t mrk_host_index_find_wordid(const mrk_host_index* h, uint64_t wordid) {
+  if (!h || !h->from_files || h->info.word_dict) return -1;
+  size_t lo = 0, hi = h->dict.size();
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    if (h->dict[mid].wordid == wordid) return (int32_t)mid;
+    if (h->dict[mid].wordid < wordid)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return -1;
+}
+
+extern "C" const uint32_t* mrk_host_index_dead_rows(const mrk_host_index* h, uint64_t* n_rows) {
+  if (!h || h->dead.empty()) return nullptr;
+  if (n_rows) *n_rows = h->info.total_docs;
+  return h->dead.data();
+}

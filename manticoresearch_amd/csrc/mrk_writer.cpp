@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/mrk.h"
+#include "mrk_hostindex.h"
 
 int mrk_fail(int code, const char* fmt, ...);
 
@@ -153,16 +154,6 @@ void encode_doclist(const WordPostings& w, bool inline_fmt, uint32_t block, uint
 
 } // namespace
 
-struct mrk_host_index {
-  uint8_t *spd = nullptr, *spp = nullptr, *spe = nullptr; // malloc'd, 64 zero bytes of slack each
-  uint64_t spd_len = 0, spp_len = 0, spe_len = 0;
-  std::vector<mrk_dict_entry> dict;
-  ~mrk_host_index() {
-    free(spd);
-    free(spp);
-    free(spe);
-  }
-};
 
 namespace {
 

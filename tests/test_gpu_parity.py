@@ -909,3 +909,63 @@ def test_quorum_node(orc, dev, block, fmt):
                            m.Query(QUORUM(m, 2, kw(m, 0, 1), kw(m, 0, 2), kw(m, 2, 3)), ranker=m.SPH_RANK_BM25)])
     assert r[0].status == -2 and r[1].status == -2
     seg.close()
+
+
+# ------------------------------------------------------------------ real index files
+def test_index_files_on_device(orc, dev, tmp_path):
+    """Indexes opened from files -- the reference's own fixtures and a larger one written in the documented layout
+    (tests/test_index_files.py) -- searched on the device with their .spm dead rows installed."""
+    import os
+    from test_index_files import IDX, synth, write_index
+    m, ctx, batch = dev
+    # 1. reference fixtures: one row each, every keyword and keyword pair under every ranker
+    for name in ("t250_plain2", "t233_test", "t233_reload", "t406_index0"):
+        hi = m.open_index(os.path.join(IDX, name))
+        qs = []
+        ws = list(range(len(hi.words)))
+        for rk in (m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_WORDCOUNT, m.SPH_RANK_SPH04, m.SPH_RANK_PROXIMITY):
+            hit_rk = rk not in (m.SPH_RANK_BM25, m.SPH_RANK_NONE)
+            if hit_rk and ctx_path(ctx) != 0:
+                continue
+            for a in ws:
+                qs.append(m.Query(kw(m, a, 1), ranker=rk))
+                for b in ws:
+                    if a != b:
+                        qs.append(m.Query(m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), ranker=rk))
+                        if hit_rk:
+                            qs.append(m.Query(PHRASE(m, kw(m, a, 1), kw(m, b, 2)), ranker=rk))
+                        elif ctx_path(ctx) == 0:
+                            qs.append(m.Query(OR(m, kw(m, a, 1), kw(m, b, 2)), ranker=rk))
+        check_batch(orc, dev, hi, qs)
+    # 2. a written index: dictionary lookups by keyword, dead rows from the .spm file
+    src = synth(m, n_terms=60, n_docs=20000, block=32)
+    words = sorted("kw%04d" % (t * 37 % 1009) for t in range(len(src.dict)))
+    dead = [int(r) for r in np.random.default_rng(4).choice(20000, 700, replace=False)]
+    prefix = str(tmp_path / "idx")
+    write_index(prefix, src, words, dead_rows=dead)
+    hi = m.open_index(prefix)
+    assert hi.info["n_dead"] == 700
+    seg = m.Segment(ctx, hi)
+    seg.set_dead_rows(hi.dead_bitmap)
+    oi = orc_index_of(orc, hi)
+    oi.dead_rows = hi.dead_bitmap
+    rng = np.random.default_rng(5)
+    qs = []
+    for _ in range(40):
+        a, b, c = (hi.find_word(words[int(t)]) for t in rng.choice(len(words), 3, replace=False))
+        assert min(a, b, c) >= 0
+        rk = int(rng.choice([m.SPH_RANK_BM25, m.SPH_RANK_NONE] + ([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_SPH04] if ctx_path(ctx) == 0 else [])))
+        root = m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)) if rng.random() < 0.6 or ctx_path(ctx) != 0 else m.XQNode.AND(OR(m, kw(m, a, 1), kw(m, b, 2)), kw(m, c, 3))
+        qs.append(m.Query(root, ranker=rk, max_matches=200))
+    try:
+        got = batch.search(seg, qs)
+        n_found = 0
+        for q, g in zip(qs, got):
+            want = to_orc(orc, q).run(oi)
+            assert g.status == 0 and g.total_found == want.total_found
+            assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+            assert not set(g.rowid.tolist()) & set(dead)
+            n_found += g.total_found
+        assert n_found > 1000
+    finally:
+        seg.close()

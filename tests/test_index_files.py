@@ -1,0 +1,245 @@
+"""Real index ingestion: mrk_index_open over index files the reference's own tests hold, plus a
+round trip through files this test writes in the documented layout (doc/internals-index-format.txt:97-170 and the
+readers cited in csrc/mrk_files.cpp).
+
+Fixtures (tests/golden/indexes/, data files copied from the reference tree -- bytes its indexer wrote):
+  t250_plain2   test/test_250/data/plain2.*     v54, rows (3 'third'), (4 'fourth')            (test_250/test.xml)
+  t233_test     test/test_233/data/test.*       v54, row  (3 'RELOAD INDEX')                   (test_233/model.bin)
+  t233_reload   test/test_233/data/reload.*     v54, row  (2 'RELOAD INDEX FROM')              (test_233/model.bin)
+  t406_index0   test/test_406/data/index.0.*    v57 RT disk chunk, row (1 'doc one')           (test_406/model.bin)
+No GPU: the library's host side only; the oracle decodes the posting bytes."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+IDX = os.path.join(HERE, "golden", "indexes")
+
+EXPECT = {
+    # name: (version, skiplist block, field, total_docs, total_bytes, [(keyword, [positions in the one doc that holds it], rowid)])
+    "t250_plain2": (54, 128, "text", 2, 11, [("fourth", [1], 1), ("third", [1], 0)]),
+    "t233_test": (54, 128, "title", 1, 12, [("index", [2], 0), ("reload", [1], 0)]),
+    "t233_reload": (54, 128, "title", 1, 17, [("from", [3], 0), ("index", [2], 0), ("reload", [1], 0)]),
+    "t406_index0": (57, 32, "title", 1, 7, [("doc", [1], 0), ("one", [2], 0)]),
+}
+
+
+def orc_index(orc, hi):
+    return orc.Index(hi.spd, hi.spp, hi.spe, hi.dict.view(orc.DICT_DTYPE), hi.total_docs, hi.skiplist_block_size,
+                     hi.hit_format, hi.n_fields)
+
+
+@pytest.mark.parametrize("name", sorted(EXPECT))
+def test_reference_index_files(orc, name):
+    import manticoresearch_amd as m
+
+    version, block, fld, total_docs, total_bytes, words = EXPECT[name]
+    hi = m.open_index(os.path.join(IDX, name))
+    assert hi.info["version"] == version and hi.info["word_dict"] == 1 and hi.info["hitless"] == 0
+    assert hi.skiplist_block_size == block and hi.hit_format == m.SPH_HIT_FORMAT_INLINE
+    assert hi.fields == [fld] and hi.n_fields == 1
+    assert hi.total_docs == total_docs and hi.info["total_bytes"] == total_bytes
+    assert hi.words == [w for w, _, _ in words]  # dictionary order
+    assert hi.dead_rows is None and hi.info["n_dead"] == 0
+    oi = orc_index(orc, hi)
+    for t, (w, pos, rowid) in enumerate(words):
+        assert hi.find_word(w) == t
+        e = hi.dict[t]
+        assert int(e["docs"]) == 1 and int(e["hits"]) == len(pos) and int(e["doclist_len"]) == 5
+        r, f, nh, _ = oi.decode_doclist(t)
+        assert list(r) == [rowid] and list(f) == [1] and list(nh) == [len(pos)]
+    assert hi.find_word("zz") == -1 and hi.find_word(words[0][0][:-1]) == -1 and hi.find_word(words[0][0] + "x") == -1
+    # doclists tile .spd: dummy byte + 5 bytes per keyword
+    assert len(hi.spd) == 1 + 5 * len(words) and len(hi.spp) == 1 and len(hi.spe) == 1
+    assert sorted(int(e["doclist_off"]) for e in hi.dict) == [1 + 5 * i for i in range(len(words))]
+
+
+def test_reference_index_positions_through_the_rankers(orc):
+    """'RELOAD INDEX FROM': the words sit at positions 1, 2, 3 of one field, 'from' closes the field."""
+    import manticoresearch_amd as m
+
+    hi = m.open_index(os.path.join(IDX, "t233_reload"))
+    oi = orc_index(orc, hi)
+    t = {w: hi.find_word(w) for w in ("reload", "index", "from")}
+    kw = lambda w, p: orc.term(t[w], p)
+    # N = n = 1: IDF 0, so PROXIMITY_BM25 = 1000 * LCS + 500
+    r = orc.search(oi, orc.op(orc.OP_AND, kw("reload", 1), kw("index", 2), kw("from", 3)), ranker=orc.RANK_PROXIMITY_BM25)
+    assert list(r.rowid) == [0] and list(r.weight) == [3500]
+    r = orc.search(oi, orc.op(orc.OP_AND, kw("index", 1), kw("reload", 2)), ranker=orc.RANK_PROXIMITY_BM25)
+    assert list(r.weight) == [1500]
+    assert orc.search(oi, orc.op(orc.OP_PHRASE, kw("reload", 1), kw("index", 2)), ranker=orc.RANK_PROXIMITY_BM25).total_found == 1
+    assert orc.search(oi, orc.op(orc.OP_PHRASE, kw("index", 1), kw("reload", 2)), ranker=orc.RANK_PROXIMITY_BM25).total_found == 0
+    assert orc.search(oi, orc.op(orc.OP_PHRASE, kw("reload", 1), kw("from", 2)), ranker=orc.RANK_PROXIMITY_BM25).total_found == 0
+    # SPH04: 'reload index from' is the whole field => exact-match bonus: 4 * lcs + 2 (head) + 1 (exact)
+    r = orc.search(oi, orc.op(orc.OP_AND, kw("reload", 1), kw("index", 2), kw("from", 3)), ranker=orc.RANK_SPH04)
+    assert list(r.weight) == [(4 * 3 + 2 + 1) * 1000 + 500]
+
+
+# ------------------------------------------------------------------ files written here, in the documented layout
+def zint(v):
+    out = [v & 0x7F]
+    v >>= 7
+    while v:
+        out.append(0x80 | (v & 0x7F))
+        v >>= 7
+    return bytes(reversed(out))
+
+
+def sph_str(s):
+    b = s.encode()
+    return struct.pack("<I", len(b)) + b
+
+
+def write_index(prefix, hi, words, version=62, word_dict=True, wordids=None, dead_rows=(), checkpoint_every=64):
+    """.sph/.spi/.spd/.spp/.spe/.spm for the postings of `hi` (term t <-> words[t] / wordids[t], already sorted)."""
+    n_fields = hi.n_fields
+    spi = bytearray(b"\x01")
+    cps = []
+    block = hi.skiplist_block_size
+    for t in range(len(hi.dict)):
+        e = hi.dict[t]
+        docs, hits, off, skip = int(e["docs"]), int(e["hits"]), int(e["doclist_off"]), int(e["skiplist_off"])
+        if t % checkpoint_every == 0:
+            if t:
+                spi += b"\x00" if word_dict else b"\x00" + zint(int(hi.dict[t - 1]["doclist_len"]))
+            cps.append((words[t] if word_dict else wordids[t], len(spi)))
+            prev_w, prev_id, prev_off = b"", 0, 0
+        if word_dict:
+            w = words[t].encode()
+            match = 0
+            while match < min(len(w), len(prev_w)) and w[match] == prev_w[match]:
+                match += 1
+            delta = len(w) - match
+            if delta <= 8 and match <= 15:
+                spi.append(0x80 | ((delta - 1) << 4) | match)
+            else:
+                spi.append(delta)
+                spi.append(match)
+            spi += w[match:] + zint(off) + zint(docs) + zint(hits)
+            if docs >= 256:
+                spi.append(0x42)  # doclist size hint
+            if docs > block:
+                spi += zint(skip)
+            prev_w = w
+        else:
+            spi += zint(wordids[t] - prev_id) + zint(off - prev_off) + zint(docs) + zint(hits)
+            if docs > block:
+                spi += zint(skip)
+            prev_id, prev_off = wordids[t], off
+    spi += b"\x00" if word_dict else b"\x00" + zint(int(hi.dict[-1]["doclist_len"]))
+    cp_off = len(spi)
+    for key, off in cps:
+        spi += (sph_str(key) if word_dict else struct.pack("<Q", key)) + struct.pack("<Q", off)
+    h = bytearray(struct.pack("<II", 0x58485053, version))
+    h += struct.pack("<I", n_fields)
+    for f in range(n_fields):
+        if version >= 57:
+            h += sph_str("f%d" % f) + struct.pack("<IB", 1, 0)
+        else:
+            h += sph_str("f%d" % f) + struct.pack("<IIIIB", 0, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0) + (b"" if version < 61 else struct.pack("<I", 0))
+    h += struct.pack("<I", 1) + sph_str("id") + struct.pack("<IIIIB", 6, 0, 0, 64, 0) + (struct.pack("<I", 0) if version >= 61 else b"")
+    h += struct.pack("<QIBII", cp_off, len(cps), 0, 0, 0)
+    h += struct.pack("<IQ", hi.total_docs, 12345)
+    # index settings
+    h += struct.pack("<III", 0, 0, 0) + b"\x00" + sph_str("") + sph_str("") + b"\x00" + struct.pack("<II", 0, hi.hit_format) + b"\x00"
+    h += sph_str("") + struct.pack("<IIII", 15, 1, 1, 16384) + b"\x00" + sph_str("") + b"\x00" + b"\x00" + sph_str("") + sph_str("")
+    h += struct.pack("<Q", 0)
+    if version >= 56:
+        h += struct.pack("<I", block)
+    if version >= 60:
+        h += sph_str("")
+    # tokenizer: embedded synonyms present to exercise that branch
+    h += b"\x01" + sph_str("non_cjk") + struct.pack("<I", 1) + b"\x01" + struct.pack("<I", 2) + sph_str("a => b") + sph_str("c => d")
+    h += sph_str("exc.txt") + struct.pack("<QQQI", 14, 1, 2, 3) + sph_str("") + sph_str("") + struct.pack("<I", 0) + sph_str("") + sph_str("") + sph_str("")
+    # dictionary: embedded stopwords (zipped ids), one stopword file, embedded wordforms + one wordform file
+    h += sph_str("stem_en") + sph_str("") + b"\x01" + struct.pack("<I", 2) + zint(1 << 40) + zint(77)
+    h += sph_str("stop.txt") + struct.pack("<I", 1) + sph_str("stop.txt") + struct.pack("<QQQI", 1, 2, 3, 4)
+    h += b"\x01" + struct.pack("<I", 1) + sph_str("walks > walk") + struct.pack("<I", 1) + sph_str("wf.txt") + struct.pack("<QQQI", 5, 6, 7, 8)
+    h += struct.pack("<I", 1) + (b"\x01" if word_dict else b"\x00") + b"\x00" + sph_str("")
+    h += struct.pack("<QQQ", 0, 0, 0) + struct.pack("<I", 0)
+    for ext, data in (("sph", bytes(h)), ("spi", bytes(spi)), ("spd", bytes(hi.spd)), ("spp", bytes(hi.spp)), ("spe", bytes(hi.spe))):
+        with open(prefix + "." + ext, "wb") as f:
+            f.write(data)
+    bm = np.zeros((hi.total_docs + 31) // 32, np.uint32)
+    for r in dead_rows:
+        bm[r >> 5] |= np.uint32(1 << (r & 31))
+    with open(prefix + ".spm", "wb") as f:
+        f.write(bm.tobytes())
+
+
+def synth(m, n_terms=150, n_docs=3000, block=32, fmt=1):
+    probs = [min(0.5, 0.9 / (1 + t) ** 0.7) for t in range(n_terms)]
+    return m.synth_index(n_docs, probs, seed=77, n_fields=3, max_pos=40, skiplist_block_size=block, hit_format=fmt, end_markers=True, n_threads=2)
+
+
+@pytest.mark.parametrize("version,word_dict,block,fmt", [(62, True, 32, 1), (54, True, 128, 0), (58, False, 32, 1), (62, False, 128, 1)])
+def test_written_index_round_trip(tmp_path, orc, version, word_dict, block, fmt):
+    import manticoresearch_amd as m
+
+    hi = synth(m, block=block, fmt=fmt)
+    n = len(hi.dict)
+    assert int(hi.dict["docs"].max()) >= 256 and int((hi.dict["docs"] > block).sum()) > 10  # hint bytes and skiplists occur
+    words = sorted("w%05d%s" % (t * 7919 % 100003, "x" * (t % 23)) for t in range(n))  # shared prefixes, some > 15 bytes
+    wordids = [1000 + 17 * t + (t * t) % 13 for t in range(n)]
+    dead = [0, 31, 32, 2999]
+    prefix = str(tmp_path / "idx")
+    write_index(prefix, hi, words, version=version, word_dict=word_dict, wordids=wordids, dead_rows=dead)
+    got = m.open_index(prefix)
+    assert got.info["version"] == version and got.info["word_dict"] == int(word_dict) and got.info["n_checkpoints"] == 3
+    assert got.skiplist_block_size == (128 if version < 56 else block) == block and got.hit_format == fmt and got.n_fields == 3
+    assert got.total_docs == hi.total_docs and got.fields == ["f0", "f1", "f2"]
+    for col in ("doclist_off", "doclist_len", "docs", "hits"):
+        assert (got.dict[col] == hi.dict[col]).all(), col
+    big = hi.dict["docs"] > block
+    assert (got.dict["skiplist_off"][big] == hi.dict["skiplist_off"][big]).all() and (got.dict["skiplist_off"][~big] == 0).all()
+    assert bytes(got.spd) == bytes(hi.spd) and bytes(got.spp) == bytes(hi.spp) and bytes(got.spe) == bytes(hi.spe)
+    if word_dict:
+        assert got.words == words
+        assert [got.find_word(w) for w in words[::7]] == list(range(0, n, 7))
+        assert got.find_word("w") == -1 and got.find_word(words[3] + "y") == -1
+    else:
+        assert [int(x) for x in got.dict["wordid"]] == wordids
+        assert [got.find_wordid(w) for w in wordids[::5]] == list(range(0, n, 5)) and got.find_wordid(7) == -1
+    assert list(got.dead_rows) == dead and got.info["n_dead"] == 4
+    assert [int(r) for r in np.flatnonzero(np.unpackbits(got.dead_bitmap.view(np.uint8), bitorder="little"))] == dead
+    # the same answers as from the index the files were written from
+    a, b = orc_index(orc, hi), orc_index(orc, got)
+    root = orc.op(orc.OP_AND, orc.term(3, 1), orc.term(9, 2))
+    ra, rb = orc.search(a, root, ranker=orc.RANK_PROXIMITY_BM25), orc.search(b, root, ranker=orc.RANK_PROXIMITY_BM25)
+    assert ra.total_found == rb.total_found > 0 and (ra.rowid == rb.rowid).all() and (ra.weight == rb.weight).all()
+
+
+def test_open_errors(tmp_path):
+    import manticoresearch_amd as m
+
+    src = os.path.join(IDX, "t233_reload")
+    def variant(name, **patch):
+        p = str(tmp_path / name)
+        for ext in ("sph", "spi", "spd", "spp", "spe", "spm"):
+            data = open(src + "." + ext, "rb").read()
+            if ext in patch:
+                data = patch[ext](data)
+            if data is not None:
+                open(p + "." + ext, "wb").write(data)
+        return p
+
+    with pytest.raises(m.MrkError, match="cannot open"):
+        m.open_index(str(tmp_path / "none"))
+    with pytest.raises(m.MrkError, match="magic"):
+        m.open_index(variant("magic", sph=lambda d: b"XXXX" + d[4:]))
+    with pytest.raises(m.MrkError, match="v.63"):
+        m.open_index(variant("new", sph=lambda d: d[:4] + struct.pack("<I", 63) + d[8:]))
+    with pytest.raises(m.MrkError, match="v.53"):
+        m.open_index(variant("old", sph=lambda d: d[:4] + struct.pack("<I", 53) + d[8:]))
+    with pytest.raises(m.MrkError, match="unexpected eof"):
+        m.open_index(variant("short", sph=lambda d: d[:200]))
+    with pytest.raises(m.MrkError, match="cannot open"):
+        m.open_index(variant("nospd", spd=lambda d: None))
+    with pytest.raises(m.MrkError, match="does not end"):
+        m.open_index(variant("cutspd", spd=lambda d: d[:-2]))
+    with pytest.raises(m.MrkError, match="checkpoint"):
+        m.open_index(variant("cutspi", spi=lambda d: d[:30]))
+    hi = m.open_index(variant("nospm", spm=lambda d: None))  # the dead-row map is optional
+    assert hi.dead_rows is None and hi.words == ["from", "index", "reload"]
