@@ -657,6 +657,7 @@ struct enode {
   int started;
   /* TERM */
   mnode t;
+  int tp_kind, tp_max; /* ExtTermPos_T (ExtConditional_T over ExtTerm_T): keeps the docs that hold an acceptable hit */
   /* MULTIAND */
   mnode* m;
   int n_m;
@@ -700,8 +701,8 @@ static int en_next(enode* e);
 static void en_hits(enode* e, hitvec* out);
 static void en_hint(enode* e, uint32_t rowid);
 
-static int en_docs_count(const enode* e) { /* GetDocsCount, searchnode.cpp:194, searchnode.h:83 */
-  return e->kind == EN_TERM ? e->t.qw.docs : INT_MAX;
+static int en_docs_count(const enode* e) { /* GetDocsCount, searchnode.cpp:194, searchnode.h:83 (ExtConditional_T has no override) */
+  return e->kind == EN_TERM && !e->tp_kind ? e->t.qw.docs : INT_MAX;
 }
 
 /* FitsFields, searchnode.cpp:2727-2747 / 1925-1929 (32-field path) */
@@ -721,26 +722,7 @@ static inline float term_tfidf(uint32_t hits, float idf) {
 }
 
 /* ---- TERM: ExtTerm_T (searchnode.cpp:1876-2020) ---- */
-static int term_next(enode* e) {
-  mnode* n = &e->t;
-  if (!n->qw.docs) return 0;
-  for (;;) {
-    qw_read_next(&n->qw);
-    if (n->qw.rowid == ORC_INVALID_ROWID) {
-      n->qw.docs = 0;
-      return 0;
-    }
-    if (!fits_fields(n)) continue;
-    e->rowid = n->qw.rowid;
-    e->fields = n->qw.fields32 & n->queried32;
-    e->tfidf = term_tfidf(n->qw.match_hits, n->idf);
-    n->stored_hitpos = n->qw.hitlist_pos;
-    if (e->p_fetched_docs) (*e->p_fetched_docs)++;
-    return 1;
-  }
-}
-
-static void term_hits(enode* e, hitvec* out) {
+static void term_raw_hits(enode* e, hitvec* out) {
   mnode* n = &e->t;
   qw_seek_hitlist(&n->qw, n->stored_hitpos);
   for (;;) {
@@ -758,6 +740,55 @@ static void term_hits(enode* e, hitvec* out) {
     hv_push(out, &t);
     if (e->p_fetched_hits) (*e->p_fetched_hits)++;
   }
+}
+
+/* TermAcceptor_T<>::IsAcceptableHit (searchnode.cpp:2264-2285) */
+static inline int termpos_accepts(int kind, int max_pos, uint32_t hitpos) {
+  const int pos = (int)ORC_HIT_POS(hitpos), end = (hitpos >> 23) & 1u;
+  switch (kind) {
+    case ORC_TERMPOS_START: return pos == 1;
+    case ORC_TERMPOS_END: return end;
+    case ORC_TERMPOS_STARTEND: return pos == 1 && end;
+    case ORC_TERMPOS_LIMIT: return pos <= max_pos;
+    default: return 1;
+  }
+}
+
+static int term_next(enode* e) {
+  mnode* n = &e->t;
+  if (!n->qw.docs) return 0;
+  for (;;) {
+    qw_read_next(&n->qw);
+    if (n->qw.rowid == ORC_INVALID_ROWID) {
+      n->qw.docs = 0;
+      return 0;
+    }
+    if (!fits_fields(n)) continue;
+    e->rowid = n->qw.rowid;
+    e->fields = n->qw.fields32 & n->queried32;
+    e->tfidf = term_tfidf(n->qw.match_hits, n->idf);
+    n->stored_hitpos = n->qw.hitlist_pos;
+    if (e->p_fetched_docs) (*e->p_fetched_docs)++;
+    if (e->tp_kind) {
+      /* ExtConditional_T::GetDocsChunk (searchnode.cpp:2332-2405): the doc passes as the term emitted it (fields, tfidf of
+         ALL its hits) once one hit is acceptable; only the acceptable hits travel on */
+      e->tmp.n = 0;
+      term_raw_hits(e, &e->tmp);
+      e->myhits.n = 0;
+      for (int i = 0; i < e->tmp.n; i++)
+        if (termpos_accepts(e->tp_kind, e->tp_max, e->tmp.p[i].hitpos)) hv_push(&e->myhits, &e->tmp.p[i]);
+      if (!e->myhits.n) continue;
+    }
+    return 1;
+  }
+}
+
+static void term_hits(enode* e, hitvec* out) {
+  if (e->tp_kind) {
+    for (int i = 0; i < e->myhits.n; i++) hv_push(out, &e->myhits.p[i]);
+    return;
+  }
+  term_raw_hits(e, out);
 }
 
 /* ---- MULTIAND: ExtMultiAnd_T (searchnode.cpp:2716-3223) ---- */
@@ -1371,6 +1402,8 @@ static enode* build_term(build_ctx* bc, const orc_node* qn) {
   enode* e = en_new(bc, EN_TERM);
   mnode_init(bc, &e->t, qn, 0);
   e->atom = qn->atom_pos;
+  e->tp_kind = qn->term_pos; /* ExtNode_i::Create :1141-1166 */
+  e->tp_max = qn->field_max_pos;
   return e;
 }
 
@@ -1412,6 +1445,12 @@ static enode* build_phrase(build_ctx* bc, const orc_node* qn) {
     const orc_node* c = &bc->q->nodes[bc->q->children[qn->first_child + i]];
     orc_node w = *c;
     w.field_mask = qn->field_mask & c->field_mask; /* words inherit the phrase node's field spec */
+    if (w.term_pos) {
+      bc->error = 1;
+      fail("position modifiers on the words of a phrase are not restated in the oracle");
+      for (int j = 0; j < i; j++) en_free(terms[j]);
+      return NULL;
+    }
     terms[i] = build_term(bc, &w);
     key[i] = en_docs_count(terms[i]);
     pos[i] = i;
@@ -1491,7 +1530,7 @@ static enode* build_node(build_ctx* bc, int ni) {
       int key[32], pos[32];
       for (int i = 0; i < k; i++) {
         const orc_node* c = &q->nodes[q->children[qn->first_child + i]];
-        if (c->op != ORC_OP_TERM) {
+        if (c->op != ORC_OP_TERM || c->term_pos) {
           bc->error = 1;
           fail("quorum over plain keywords only");
           for (int j = 0; j < i; j++) en_free(terms[j]);
@@ -1542,6 +1581,24 @@ static enode* build_node(build_ctx* bc, int ni) {
       int all_terms = 1;
       for (int i = 0; i < k; i++)
         if (q->nodes[q->children[qn->first_child + i]].op != ORC_OP_TERM) all_terms = 0;
+      int any_termpos = 0;
+      for (int i = 0; i < k; i++)
+        if (q->nodes[q->children[qn->first_child + i]].term_pos) any_termpos = 1;
+      if (all_terms && k > 1 && any_termpos) {
+        /* a keyword with a position modifier rules the multi-and node out (:1724-1735): terms sorted by ExtNodeTF_fn -- the
+           modified ones count INT_MAX docs -- and chained with ExtAnd_c (:1743-1762) */
+        enode* terms[32];
+        int key[32], pos[32];
+        for (int i = 0; i < k; i++) {
+          terms[i] = build_term(bc, &q->nodes[q->children[qn->first_child + i]]);
+          key[i] = en_docs_count(terms[i]);
+          pos[i] = i;
+        }
+        sph_isort_idx(pos, k, key);
+        enode* cur = terms[pos[0]];
+        for (int i = 1; i < k; i++) cur = build_twofer(bc, EN_AND, cur, terms[pos[i]]);
+        return cur;
+      }
       if (all_terms && k > 1) {
         /* CreateMultiAndNode (:1118-1138, 1774) + ExtMultiAnd_T ctor (:2772-2798) */
         enode* e = en_new(bc, EN_MULTIAND);

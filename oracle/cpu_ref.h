@@ -115,7 +115,12 @@ typedef struct {
   float boost;         /* m_fBoost */
   int opt;             /* proximity distance / quorum threshold */
   int not_weighted;
+  int term_pos;        /* ORC_TERMPOS_*: XQKeyword_t::m_bFieldStart / m_bFieldEnd, XQLimitSpec_t::m_iFieldMaxPos */
+  int field_max_pos;   /* m_iFieldMaxPos for ORC_TERMPOS_LIMIT */
 } orc_node;
+
+/* TermPosFilter_e (searchnode.cpp:875-878, 1145-1146) */
+enum { ORC_TERMPOS_NONE = 0, ORC_TERMPOS_START = 1, ORC_TERMPOS_END = 2, ORC_TERMPOS_STARTEND = 3, ORC_TERMPOS_LIMIT = 4 };
 
 typedef struct {
   const orc_node* nodes;

@@ -50,7 +50,7 @@ class _Index(C.Structure):
 class _Node(C.Structure):
     _fields_ = [("op", C.c_int), ("n_children", C.c_int), ("first_child", C.c_int), ("term_id", C.c_int32),
                 ("atom_pos", C.c_int), ("field_mask", C.c_uint32), ("boost", C.c_float), ("opt", C.c_int),
-                ("not_weighted", C.c_int)]
+                ("not_weighted", C.c_int), ("term_pos", C.c_int), ("field_max_pos", C.c_int)]
 
 
 class _Query(C.Structure):
@@ -217,10 +217,16 @@ class QNode:
     field_mask: int = ALL_FIELDS
     boost: float = 1.0
     opt: int = 0  # XQNode_t::m_iOpArg (proximity distance, quorum threshold)
+    term_pos: int = 0  # TERMPOS_*: '^word', 'word$', '@field[N] word'
+    field_max_pos: int = 0
 
 
-def term(term_id: int, atom_pos: int, field_mask: int = ALL_FIELDS, boost: float = 1.0) -> QNode:
-    return QNode(OP_TERM, [], term_id, atom_pos, field_mask, boost)
+TERMPOS_NONE, TERMPOS_START, TERMPOS_END, TERMPOS_STARTEND, TERMPOS_LIMIT = 0, 1, 2, 3, 4
+
+
+def term(term_id: int, atom_pos: int, field_mask: int = ALL_FIELDS, boost: float = 1.0, term_pos: int = 0,
+         field_max_pos: int = 0) -> QNode:
+    return QNode(OP_TERM, [], term_id, atom_pos, field_mask, boost, term_pos=term_pos, field_max_pos=field_max_pos)
 
 
 def op(kind: int, *children: QNode, field_mask: int = ALL_FIELDS, opt: int = 0) -> QNode:
@@ -261,6 +267,7 @@ class FlatQuery:
             kids.extend(n._kids)  # type: ignore[attr-defined]
             cn.term_id, cn.atom_pos, cn.field_mask, cn.boost = n.term_id, n.atom_pos, n.field_mask, n.boost
             cn.opt = n.opt
+            cn.term_pos, cn.field_max_pos = n.term_pos, n.field_max_pos
         self.children = (C.c_int * max(1, len(kids)))(*kids)
         q = _Query()
         q.nodes, q.n_nodes = self.nodes, len(nodes)

@@ -12,8 +12,13 @@ import os
 ALL = 0xFFFFFFFF
 
 
-def T(word, pos, mask=ALL):
-    return {"word": word, "pos": pos, "mask": mask}
+def T(word, pos, mask=ALL, tp=None, max_pos=0):
+    """keyword leaf; tp = position modifier: "start" ('^word'), "end" ('word$'), "startend", "limit" ('@field[N] word')"""
+    d = {"word": word, "pos": pos, "mask": mask}
+    if tp:
+        d["tp"] = tp
+        d["max_pos"] = max_pos
+    return d
 
 
 def OP(op, *kids, mask=ALL, opt=0):
@@ -56,6 +61,19 @@ G = {
                                   [{"count": 510, "fields": ["e x f"]},
                                    {"count": 1, "fields": ["e x f x x x e x f x x e x f x x"]},
                                    {"count": 1, "fields": [" y y i x j" * 532]}]},
+        # test_055 (position anchors): rows 10..19 are doubled six times by INSERT .. SELECT document_id+N
+        "test_055": {"source": "test/test_055/test.xml + model.bin", "min_word_len": 1,
+                     "ids": [1, 2, 3, 4, 9] + list(range(10, 650)) + [2000, 1000, 1001],
+                     "docs_spec": [{"count": 1, "fields": ["", t]} for t in
+                                   ("one", "one and two", "one but not the other one", "two and one", "other three")] +
+                                  [{"count": 640, "fields": ["", "three"]},
+                                   {"count": 1, "fields": ["badger " * 600, "badger badger mushroom"]},
+                                   {"count": 1, "fields": ["", "other"]}, {"count": 1, "fields": ["", "other three blind mice"]}]},
+        # test_080: index "main" after "indexer --merge main delta"; the delta row is built in a loop:
+        # 299992 x "C", then "B A A A" (a field given as {"runs": [[text, count], ...]} is the texts repeated and joined)
+        "test_080": {"source": "test/test_080/test.xml (custom_insert) + model.bin", "min_word_len": 1, "ids": [2, 1],
+                     "docs_spec": [{"count": 1, "fields": ["X", "Y"]},
+                                   {"count": 1, "fields": ["", {"runs": [["C ", 299992], ["B A A A", 1]]}]}]},
         "test_322": {"source": "test/test_322/test.xml + model.bin", "min_word_len": 1, "ids": [1, 2, 3, 100],
                      "docs": [["|sample program", "|program flow direct", "|sample program flow"],
                               ["|one sample program", "|program rev flow", "|one rev flow"],
@@ -117,6 +135,31 @@ G["cases"] += [
      "ranker": "wordcount", "expect": [[521, 3]] + [[i, 1] for i in range(11, 30)], "limit": 20, "total_found": 511},
     {"name": "116 \"i j\"~2 wordcount", "corpus": "test_116", "query": OP("proximity", T("i", 1), T("j", 2), opt=2),
      "ranker": "wordcount", "expect": [[522, 532]], "total_found": 1},
+]
+G["cases"] += [  # test_055: '^' and '$' (ExtTermPos_T, searchnode.cpp:2259-2405)
+    {"name": "055 ^one two", "corpus": "test_055", "query": OP("and", T("one", 1, tp="start"), T("two", 2)),
+     "ranker": "proximity_bm25", "expect": [[2, 1690]], "total_found": 1},
+    {"name": "055 ^other three", "corpus": "test_055", "query": OP("and", T("other", 1, tp="start"), T("three", 2)),
+     "ranker": "proximity_bm25", "expect": [[9, 2509], [1001, 2509]], "total_found": 2},
+    {"name": "055 three$", "corpus": "test_055", "query": T("three", 1, tp="end"), "ranker": "proximity_bm25",
+     "expect": [[i, 1341] for i in range(9, 29)], "limit": 20, "total_found": 641},
+    {"name": "055 ^badger", "corpus": "test_055", "query": T("badger", 1, tp="start"), "ranker": "proximity_bm25",
+     "expect": [[2000, 2998]], "total_found": 1},
+]
+G["cases"] += [  # test_080: '@field[N]' position limits at the far end of a 299996-word field, '$' on a repeated keyword
+    {"name": "080 C", "corpus": "test_080", "query": T("c", 1), "ranker": "proximity_bm25", "expect": [[1, 1815]], "total_found": 1},
+    {"name": "080 @second[299992] B", "corpus": "test_080", "query": T("b", 1, 0b10, tp="limit", max_pos=299992),
+     "ranker": "proximity_bm25", "expect": [], "total_found": 0},
+    {"name": "080 @second[299993] B", "corpus": "test_080", "query": T("b", 1, 0b10, tp="limit", max_pos=299993),
+     "ranker": "proximity_bm25", "expect": [[1, 1643]], "total_found": 1},
+    {"name": "080 @second[299994] B", "corpus": "test_080", "query": T("b", 1, 0b10, tp="limit", max_pos=299994),
+     "ranker": "proximity_bm25", "expect": [[1, 1643]], "total_found": 1},
+    {"name": "080 \"C B A A A\"", "corpus": "test_080", "query": OP("phrase", T("c", 1), T("b", 2), T("a", 3), T("a", 4), T("a", 5)),
+     "ranker": "proximity_bm25", "expect": [[1, 5728]], "total_found": 1},
+    {"name": "080 A", "corpus": "test_080", "query": T("a", 1), "ranker": "proximity_bm25", "expect": [[1, 1725]], "total_found": 1},
+    {"name": "080 A$", "corpus": "test_080", "query": T("a", 1, tp="end"), "ranker": "proximity_bm25", "expect": [[1, 1725]], "total_found": 1},
+    {"name": "080 X", "corpus": "test_080", "query": T("x", 1), "ranker": "proximity_bm25", "expect": [[2, 1643]], "total_found": 1},
+    {"name": "080 Y", "corpus": "test_080", "query": T("y", 1), "ranker": "proximity_bm25", "expect": [[2, 1643]], "total_found": 1},
 ]
 G["cases"] += [  # the rest of test_019's query list, as far as its trees can be written down without the query parser
     {"name": "019 \"test that\"~3 | basic", "corpus": "test_019",

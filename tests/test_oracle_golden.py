@@ -20,9 +20,13 @@ from helpers import mini_index
 
 GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json"),
                         encoding="utf-8"))
+def _field_text(f):  # a field the reference builds in a loop is stored as {"runs": [[text, count], ...]}
+    return f if isinstance(f, str) else "".join(t * n for t, n in f["runs"])
+
+
 for _c in GOLDEN["corpora"].values():  # corpora the reference builds in a loop are stored as (count, row) runs
     if "docs_spec" in _c:
-        _c["docs"] = [list(run["fields"]) for run in _c["docs_spec"] for _ in range(run["count"])]
+        _c["docs"] = [[_field_text(f) for f in run["fields"]] for run in _c["docs_spec"] for _ in range(run["count"])]
 
 
 # ------------------------------------------------------------------ VLB bytes
@@ -190,7 +194,8 @@ def test_dead_rows_skip_the_sorter(orc):
 # ------------------------------------------------------------------ tests/golden/reference_vectors.json, every case
 def _golden_tree(orc, v, q):
     if "word" in q:
-        return orc.term(v.get(q["word"], -1), q["pos"], field_mask=q["mask"])  # -1: keyword not in the dictionary
+        tp = {None: 0, "start": orc.TERMPOS_START, "end": orc.TERMPOS_END, "startend": orc.TERMPOS_STARTEND, "limit": orc.TERMPOS_LIMIT}[q.get("tp")]
+        return orc.term(v.get(q["word"], -1), q["pos"], field_mask=q["mask"], term_pos=tp, field_max_pos=q.get("max_pos", 0))  # -1: keyword not in the dictionary
     return orc.op(getattr(orc, "OP_" + q["op"].upper()), *[_golden_tree(orc, v, k) for k in q["kids"]], field_mask=q["mask"],
                   opt=q.get("opt", 0))
 
