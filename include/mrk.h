@@ -112,7 +112,13 @@ typedef struct {
   float boost;         /* XQKeyword_t::m_fBoost */
   int32_t opt;         /* XQNode_t::m_iOpArg */
   int32_t not_weighted;
+  int32_t term_pos;      /* leaf: MRK_TERMPOS_* position modifier (ExtTermPos_T, searchnode.cpp:2259-2405) */
+  int32_t field_max_pos; /* leaf: XQLimitSpec_t::m_iFieldMaxPos for MRK_TERMPOS_LIMIT ('@field[N] word') */
 } mrk_node;
+
+/* TermPosFilter_e as ExtNode_i::Create derives it (searchnode.cpp:875-878, 1145-1146): '^word' = START, 'word$' = END,
+   both = STARTEND, a field position limit = LIMIT (and wins over the anchors) */
+enum { MRK_TERMPOS_NONE = 0, MRK_TERMPOS_START = 1, MRK_TERMPOS_END = 2, MRK_TERMPOS_STARTEND = 3, MRK_TERMPOS_LIMIT = 4 };
 
 /* CSphQuery fields that reach the ranker + the query tree */
 typedef struct {

@@ -39,7 +39,7 @@ class SegmentDesc(C.Structure):
 class Node(C.Structure):
     _fields_ = [("op", C.c_int32), ("n_children", C.c_int32), ("first_child", C.c_int32), ("term_id", C.c_int32),
                 ("atom_pos", C.c_int32), ("field_mask", C.c_uint32), ("boost", C.c_float), ("opt", C.c_int32),
-                ("not_weighted", C.c_int32)]
+                ("not_weighted", C.c_int32), ("term_pos", C.c_int32), ("field_max_pos", C.c_int32)]
 
 
 class Query(C.Structure):

@@ -155,6 +155,8 @@ class XQKeyword:
     term_id: int              # dictionary slot of m_sWord (< 0: not in the dictionary)
     atom_pos: int             # m_iAtomPos
     boost: float = 1.0        # m_fBoost
+    field_start: bool = False  # m_bFieldStart: '^word'
+    field_end: bool = False    # m_bFieldEnd: 'word$'
 
 
 @dataclass
@@ -164,10 +166,21 @@ class XQNode:
     word: Optional[XQKeyword] = None
     field_mask: int = ALL_FIELDS   # m_dSpec.m_dFieldMask (low dword)
     opt: int = 0                   # m_iOpArg
+    field_max_pos: int = 0         # m_dSpec.m_iFieldMaxPos: '@field[N] word'
 
     @staticmethod
-    def keyword(term_id: int, atom_pos: int, field_mask: int = ALL_FIELDS, boost: float = 1.0) -> "XQNode":
-        return XQNode(SPH_QUERY_TERM, [], XQKeyword(term_id, atom_pos, boost), field_mask)
+    def keyword(term_id: int, atom_pos: int, field_mask: int = ALL_FIELDS, boost: float = 1.0, field_start: bool = False,
+                field_end: bool = False, field_max_pos: int = 0) -> "XQNode":
+        return XQNode(SPH_QUERY_TERM, [], XQKeyword(term_id, atom_pos, boost, field_start, field_end), field_mask,
+                      field_max_pos=field_max_pos)
+
+    def term_pos(self) -> int:
+        """TermPosFilter_e as ExtNode_i::Create derives it (searchnode.cpp:875-878, 1145-1146)."""
+        if self.word is None:
+            return 0
+        if self.field_max_pos:
+            return 4
+        return (1 if self.word.field_start else 0) | (2 if self.word.field_end else 0)
 
     @staticmethod
     def AND(*kids: "XQNode") -> "XQNode":
@@ -215,6 +228,7 @@ class _CQueries:
                 cn[i].field_mask, cn[i].opt = n.field_mask, n.opt
                 if n.word is not None:
                     cn[i].term_id, cn[i].atom_pos, cn[i].boost = n.word.term_id, n.word.atom_pos, n.word.boost
+                    cn[i].term_pos, cn[i].field_max_pos = n.term_pos(), n.field_max_pos
                 else:
                     cn[i].term_id, cn[i].boost = -1, 1.0
             ch = (C.c_int32 * max(1, len(flat)))(*flat)

@@ -58,6 +58,7 @@ constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT =
 constexpr int QUORUM_EVENTS = 8; // keywords of a quorum node = doclists that can run dry and reorder its children
 constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
 constexpr uint32_t TF_BITMAP = 4;   // 2-keyword AND answered by the bitmap kernel (items are window ranges)
+constexpr uint32_t TF_TERMPOS = 64;     // some keyword carries a position modifier (ExtTermPos_T)
 constexpr uint32_t TF_QUORUM_HITS = 32; // the root is an ExtQuorum_c: its hits sort by position WITHOUT the end flag
 constexpr uint32_t TF_DUPES = 16;      // a keyword occurs more than once in the query (HasQwordDupes, sphinxsearch.cpp:4178)
 constexpr uint32_t TF_PHRASE_LEAF = 8; // one PHRASE below other operators: ph_mask = its words' slots in t[]
@@ -82,6 +83,8 @@ struct DevTerm {
   uint32_t exc_n;
   uint64_t bm_off;    // word offset of the term's bitmap in DevSegment::bm (~0 = none)
   uint64_t dir_off;   // word offset of its rank directory in DevSegment::bm_dir
+  uint32_t tp_kind;   // MRK_TERMPOS_*: only docs with an acceptable hit hold the keyword, only acceptable hits travel on
+  uint32_t tp_max;    // MRK_TERMPOS_LIMIT: largest acceptable position within the field
 };
 
 struct DevQuery {

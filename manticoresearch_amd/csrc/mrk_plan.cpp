@@ -57,6 +57,7 @@ struct PlanKw { // one keyword occurrence of the query tree
   float boost, idf;
   uint32_t queried32;
   int atom_pos;
+  int tp_kind, tp_max; // MRK_TERMPOS_*
   bool weighted_first; // first node of its word in GetQwords order gets the IDF, later dupes get 0
 };
 
@@ -76,6 +77,7 @@ struct PlanTree {
   bool force_tree = false;      // the query must run as a tree program even if it only holds TERM / AND nodes
   // one real ExtQuorum_c ('"a b c"/N', 1 < N < words): its keywords are kws[q_kw0 .. q_kw0 + q_n) in query-position order
   bool quorum = false, quorum_root = false;
+  bool termpos = false;         // some keyword carries a position modifier ('^word', 'word$', '@field[N] word')
   int q_kw0 = 0, q_n = 0, q_thr = 0;
   IntVec atoms;                 // its words' query positions, phrase order
 };
@@ -97,6 +99,9 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     k.boost = t.boost;
     k.queried32 = t.field_mask;
     k.atom_pos = t.atom_pos;
+    k.tp_kind = t.term_pos;
+    k.tp_max = t.field_max_pos;
+    if (t.term_pos) T.termpos = T.force_tree = true; // ExtTermPos_T never sits inside an ExtMultiAnd_T (searchnode.cpp:1724-1735)
     T.kws.push_back(k);
     PlanNode pn;
     pn.op = PN_TERM;
@@ -127,7 +132,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     IntVec kids(n.n_children), ord(n.n_children), docs(n.n_children);
     for (int i = 0; i < n.n_children; ++i) {
       kids[i] = q.children[n.first_child + i];
-      if (kids[i] < 0 || kids[i] >= q.n_nodes || q.nodes[kids[i]].op != MRK_OP_TERM)
+      if (kids[i] < 0 || kids[i] >= q.n_nodes || q.nodes[kids[i]].op != MRK_OP_TERM || q.nodes[kids[i]].term_pos)
         return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum over plain keywords only", qi), -1;
       const mrk_node& t = q.nodes[kids[i]];
       docs[i] = (t.term_id >= 0 && (uint32_t)t.term_id < seg->terms.size()) ? (int)seg->terms[t.term_id].docs : 0;
@@ -209,17 +214,23 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
   }
   if ((n.op == MRK_OP_AND || nway) && all_terms && n.n_children > 1) {
     IntVec ord(n.n_children), docs(n.n_children);
+    bool any_tp = false;
     for (int i = 0; i < n.n_children; ++i) {
       const mrk_node& t = q.nodes[kids[i]];
       docs[i] = (t.term_id >= 0 && (uint32_t)t.term_id < seg->terms.size()) ? (int)seg->terms[t.term_id].docs : 0;
       ord[i] = i;
+      if (t.term_pos) { // ExtConditional_T keeps ExtNode_i's GetDocsCount() = INT_MAX (searchnode.h:83): sorted last
+        if (nway) return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: position modifiers on the words of a phrase", qi), -1;
+        docs[i] = INT_MAX;
+        any_tp = true;
+      }
     }
     for (int i = 1; i < n.n_children; ++i)
       for (int j = i; j > 0; --j) {
         if (docs[ord[j - 1]] < docs[ord[j]]) break;
         std::swap(ord[j], ord[j - 1]);
       }
-    if (n.op == MRK_OP_AND && n.n_children == 3 && !is_root) T.multiand3_inner = true;
+    if (n.op == MRK_OP_AND && n.n_children == 3 && !is_root && !any_tp) T.multiand3_inner = true;
     const int kw0 = (int)T.kws.size();
     int cur = leaf(kids[ord[0]]);
     for (int i = 1; i < n.n_children; ++i) {
@@ -298,6 +309,8 @@ static void fill_term(const mrk_segment* seg, const PlanKw& k, DevTerm& dt) {
   dt.queried32 = k.queried32;
   dt.idf = k.weighted_first ? k.idf : 0.0f;
   dt.qpos = (uint32_t)k.atom_pos;
+  dt.tp_kind = (uint32_t)k.tp_kind;
+  dt.tp_max = (uint32_t)k.tp_max;
   if (!k.docs) return; // keyword without postings: nblocks = 0, never present
   const HostTerm& h = seg->terms[k.term_id];
   dt.blk_first = h.blk_first;
@@ -354,6 +367,14 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: a quorum below another operator with a hit ranker is not on the device path", qi);
   if (T.ph_leaf && n > MAX_PROX_TERMS)
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE in a tree of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+  if (T.termpos) { // whether a keyword holds a doc is decided over its hits: the hit-reading kernel, <= 4 hit streams
+    if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: position modifiers run on the packed path only", qi);
+    if (n > MAX_PROX_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: position modifiers in a query of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+    if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+    for (const PlanKw& k : T.kws)
+      if (k.tp_kind < 0 || k.tp_kind > MRK_TERMPOS_LIMIT || (k.tp_kind == MRK_TERMPOS_LIMIT && k.tp_max <= 0))
+        return mrk_fail(MRK_E_INVAL, "query %u: bad position modifier", qi);
+  }
   if (T.phrase || T.ph_leaf) {
     if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE runs on the packed path only", qi);
     if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
@@ -538,7 +559,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   }
   algo_bytes += bytes;
   dev_bytes += use_packed ? pbytes : bytes;
-  prox_out = prox_out || prox || T.phrase || T.ph_leaf;
+  prox_out = prox_out || prox || T.phrase || T.ph_leaf || T.termpos;
   tree_out = tree_out || !pure_and;
 
   // two dense keywords: the bitmap kernel (mrk_scan_bm.hip) walks 2048-rowid windows instead of blocks
@@ -594,7 +615,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     P->n_terms = (uint32_t)n;
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
     P->req_mask = P->excl_mask = 0;
-    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0);
+    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0);
     P->px_dist = (uint32_t)T.px_dist;
     P->qr_mask = P->qr_thr = P->qr_n = 0;
     if (T.quorum) {

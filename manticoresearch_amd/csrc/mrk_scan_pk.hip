@@ -159,6 +159,17 @@ __device__ __forceinline__ bool field_queried(uint32_t qmask, uint32_t hitpos) {
   return f < 32 ? ((qmask >> f) & 1u) != 0 : qmask == 0xFFFFFFFFu;
 }
 
+// TermAcceptor_T<>::IsAcceptableHit (searchnode.cpp:2264-2285): '^word' / 'word$' / '^word$' / '@field[N] word'
+__device__ __forceinline__ bool tp_accept(uint32_t kind, uint32_t max_pos, uint32_t hitpos) {
+  const uint32_t pos = hitpos & 0x7FFFFFu;
+  const bool end = ((hitpos >> 23) & 1u) != 0;
+  return kind == MRK_TERMPOS_START      ? pos == 1u
+         : kind == MRK_TERMPOS_END      ? end
+         : kind == MRK_TERMPOS_STARTEND ? (pos == 1u && end)
+         : kind == MRK_TERMPOS_LIMIT    ? pos <= max_pos
+                                        : true;
+}
+
 // FSMphrase_c (searchnode.cpp:3884-3947): live states = (index of the last word read, expected position of the
 // next one).  A first-word hit opens a state; states whose expected position was passed die; a state that reads
 // its last word completes an occurrence and resets the machine.
@@ -429,6 +440,7 @@ struct HitCtx {
   int max_qpos, n_qwords; // ExtRanker_c::m_iMaxQpos / m_iQwords
   bool inline_hits, multi_and;
   bool dupes;             // repeated query keywords under a proximity ranker: RankerState_Proximity_fn<.., true>
+  bool termpos;           // some keyword carries a position modifier: its stream yields acceptable hits only
   bool quorum_hits;       // the root is an ExtQuorum_c: hits order by position without the end flag (QuorumCmpHitPos_fn)
 };
 
@@ -440,11 +452,13 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
   // .spp cursor (0 = inlined hit / exhausted), current Hitpos_t (0 = exhausted), query position, field limit
   uint64_t sp[MAX_PROX_TERMS];
   uint32_t sc[MAX_PROX_TERMS], sq[MAX_PROX_TERMS], sm[MAX_PROX_TERMS];
+  uint32_t tpk[MAX_PROX_TERMS], tpm[MAX_PROX_TERMS]; // ExtTermPos_T: the keyword's acceptor
 #pragma unroll
   for (int t = 0; t < MAX_PROX_TERMS; ++t) {
-    sp[t] = 0, sc[t] = 0, sq[t] = 0, sm[t] = 0;
+    sp[t] = 0, sc[t] = 0, sq[t] = 0, sm[t] = 0, tpk[t] = 0, tpm[t] = 0;
     if ((uint32_t)t < C.nterms && ((smask >> t) & 1u)) {
       const DevTerm& Tt = C.Q->t[t];
+      if (C.termpos) tpk[t] = Tt.tp_kind, tpm[t] = Tt.tp_max;
       const uint32_t h = t == 0 ? ref0 : t == 1 ? ref1 : t == 2 ? ref2 : ref3;
       const uint32_t gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu), idx = h & 127u;
       const bool lone = (h >> 31) != 0;
@@ -457,6 +471,8 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
         sp[t] = C.hbase[gblk] + hv;
         hit_advance(C.spp, sp[t], sc[t]);
       }
+      if (C.termpos)
+        while (sc[t] && !tp_accept(tpk[t], tpm[t], sc[t])) hit_advance(C.spp, sp[t], sc[t]);
     }
   }
   // the phrase as a stream of folded hits: position = first word's, weight = word count, spanlen = span + 1
@@ -550,6 +566,11 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
       uint64_t ap = best == 0 ? sp[0] : best == 1 ? sp[1] : best == 2 ? sp[2] : sp[3];
       uint32_t ac = best == 0 ? sc[0] : best == 1 ? sc[1] : best == 2 ? sc[2] : sc[3];
       hit_advance(C.spp, ap, ac);
+      if (C.termpos) {
+        const uint32_t ak = best == 0 ? tpk[0] : best == 1 ? tpk[1] : best == 2 ? tpk[2] : tpk[3];
+        const uint32_t am = best == 0 ? tpm[0] : best == 1 ? tpm[1] : best == 2 ? tpm[2] : tpm[3];
+        while (ac && !tp_accept(ak, am, ac)) hit_advance(C.spp, ap, ac);
+      }
 #pragma unroll
       for (int t = 0; t < MAX_PROX_TERMS; ++t)
         if (t == best) sp[t] = ap, sc[t] = ac;
@@ -557,6 +578,26 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
   }
   if (rank) rk_out = X.finalize(C.ranker, C.nw, C.Q->weights, C.w_of, C.n_qwords);
   if (F.over) atomicOr(C.flags, QF_FSM);
+}
+
+// ExtConditional_T::GetDocsChunk (searchnode.cpp:2332-2405): the keyword holds the doc iff one of its hits -- inside the
+// keyword's field limit -- is acceptable.  ref = where the doc sits in the keyword's packed arrays (as for hit_pass).
+__device__ __forceinline__ bool termpos_any(const HitCtx& C, const DevTerm& Tt, uint32_t ref) {
+  const uint32_t gblk = Tt.blk_first + ((ref >> 7) & 0xFFFFFFu), idx = ref & 127u;
+  const uint32_t hv = C.hit[(uint64_t)gblk * DEVBLK + idx];
+  uint64_t sp = 0;
+  uint32_t sc = 0;
+  if (ref >> 31)
+    sc = hv;
+  else {
+    sp = C.hbase[gblk] + hv;
+    hit_advance(C.spp, sp, sc);
+  }
+  while (sc) {
+    if (field_queried(Tt.queried32, sc) && tp_accept(Tt.tp_kind, Tt.tp_max, sc)) return true;
+    hit_advance(C.spp, sp, sc);
+  }
+  return false;
 }
 
 template <bool PROX, bool TREE>
@@ -739,6 +780,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   HC.max_qpos = (int)Q->max_qpos, HC.n_qwords = (int)Q->n_qwords;
   HC.inline_hits = inline_hits, HC.multi_and = multi_and;
   HC.quorum_hits = (Q->tree_flags & TF_QUORUM_HITS) != 0;
+  HC.termpos = PROX && (Q->tree_flags & TF_TERMPOS) != 0;
   HC.dupes = (Q->tree_flags & TF_DUPES) != 0 && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY);
   auto drain_hits = [&](uint32_t from, uint32_t n) {
     if (!PROX) return;
@@ -1073,6 +1115,26 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         } else {
           live[0] = live[0] && hit[0];
           live[1] = live[1] && hit[1];
+        }
+      }
+
+      // ---- keywords with a position modifier: the doc holds them only through an acceptable hit
+      if (TREE && PROX && HC.termpos && __ballot(live[0] || live[1])) {
+        wave_lds_fence();
+        for (uint32_t j = 0; j < nterms && j < (uint32_t)MAX_PROX_TERMS; ++j) {
+          const DevTerm& Tj = Q->t[j];
+          if (!Tj.tp_kind) continue;
+          const bool rq = ((req_mask >> j) & 1u) != 0;
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            if (live[r] && ((pres[r] >> j) & 1u)) {
+              const uint32_t dref = ((inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u) ? 0x80000000u : 0u) | (b << 7) | (lane + 64 * r);
+              const uint32_t ref = j == 0 ? dref : L.href[j - 1][lane + 64 * r];
+              if (!termpos_any(HC, Tj, ref)) {
+                pres[r] &= ~(1u << j);
+                if (rq) live[r] = false;
+              }
+            }
         }
       }
 
