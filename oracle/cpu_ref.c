@@ -629,7 +629,7 @@ static void hv_push(hitvec* v, const hit_t* h) {
   v->p[v->n++] = *h;
 }
 
-enum { EN_TERM, EN_MULTIAND, EN_AND, EN_OR, EN_MAYBE, EN_ANDNOT, EN_PHRASE, EN_QUORUM };
+enum { EN_TERM, EN_MULTIAND, EN_AND, EN_OR, EN_MAYBE, EN_ANDNOT, EN_PHRASE, EN_QUORUM, EN_ORDER };
 
 typedef struct {
   qword qw;
@@ -683,6 +683,9 @@ struct enode {
   int n_kids, q_thresh;
   int q_list[32], q_n;
   int* kid_ok;
+  /* ORDER (ExtOrder_c): kids in query order; per-kid hits of the current candidate doc */
+  hitvec* kid_hits;
+  int ord_done;
   /* PROXIMITY (ExtNWay_T<FSMproximity_c>): same node, other state machine */
   int is_proximity;
   int max_distance;          /* m_iMaxDistance = XQNode_t::m_iOpArg */
@@ -1294,6 +1297,108 @@ static int quorum_next(enode* e) {
 }
 
 /* ---- dispatch ---- */
+
+/* ---- ExtOrder_c, the BEFORE operator (searchnode.cpp:4657-4936) ---- */
+/* GetMatchingHits (:4734-4829): the hits of all children in ascending position (ties: the lowest child), two trackers --
+   the longest in-order subsequence so far and the most recently started one; a full subsequence is flushed to the output */
+static int order_matching_hits(enode* e) {
+  const int n = e->n_kids;
+  hit_t acc_l[32], acc_r[32];
+  int len_l = 0, len_r = 0, pos_l = 0, pos_r = 0, field = -1;
+  int cur[32];
+  for (int i = 0; i < n; i++) cur[i] = 0;
+  const int old = e->myhits.n;
+  for (;;) {
+    uint32_t best_pos = UINT_MAX; /* GetChildIdWithNextHit :4706-4731 */
+    int c = -1;
+    for (int i = 0; i < n; i++)
+      if (cur[i] < e->kid_hits[i].n && ORC_HIT_POSWITHFIELD(e->kid_hits[i].p[cur[i]].hitpos) < best_pos) {
+        best_pos = ORC_HIT_POSWITHFIELD(e->kid_hits[i].p[cur[i]].hitpos);
+        c = i;
+      }
+    if (c < 0) break;
+    const hit_t* h = &e->kid_hits[c].p[cur[c]];
+    const int hfield = (int)ORC_HIT_FIELD(h->hitpos), hpos = (int)ORC_HIT_POS(h->hitpos);
+    if (hfield != field) { /* new field: both trackers start over */
+      len_l = len_r = 0;
+      if (c == 0) {
+        acc_l[len_l++] = *h;
+        pos_l = hpos + h->spanlen;
+        field = hfield;
+      }
+    } else if (c == len_l && hpos >= pos_l) {
+      acc_l[len_l++] = *h;
+      pos_l = hpos + h->spanlen;
+      if (len_l == n) {
+        for (int i = 0; i < len_l; i++) hv_push(&e->myhits, &acc_l[i]);
+        len_l = len_r = 0;
+        pos_r = pos_l;
+      }
+    } else if (c == 0) {
+      len_r = 0;
+      acc_r[len_r++] = *h;
+      pos_r = hpos + h->spanlen;
+      if (!len_l) {
+        acc_l[len_l++] = *h;
+        pos_l = hpos + h->spanlen;
+      }
+    } else if (c == len_r && hpos >= pos_r) {
+      acc_r[len_r++] = *h;
+      pos_r = hpos + h->spanlen;
+      if (len_r == len_l) {
+        for (int i = 0; i < len_r; i++) acc_l[i] = acc_r[i];
+        len_r = 0;
+        pos_l = pos_r;
+      }
+    }
+    cur[c]++;
+  }
+  return old != e->myhits.n;
+}
+
+static int order_next(enode* e) { /* GetDocsChunk :4832-4929 */
+  if (e->ord_done) return 0;
+  if (!e->started) {
+    e->started = 1;
+    for (int i = 0; i < e->n_kids; i++)
+      if (!en_next(e->kids[i])) {
+        e->ord_done = 1;
+        return 0;
+      }
+  }
+  for (;;) {
+    uint32_t rowid = e->kids[0]->rowid;
+    int i = 1;
+    while (i < e->n_kids) {
+      while (e->kids[i]->rowid < rowid)
+        if (!en_next(e->kids[i])) {
+          e->ord_done = 1;
+          return 0;
+        }
+      if (e->kids[i]->rowid > rowid) {
+        rowid = e->kids[i]->rowid;
+        i = 0;
+        continue;
+      }
+      i++;
+    }
+    for (int k = 0; k < e->n_kids; k++) {
+      e->kid_hits[k].n = 0;
+      en_hits(e->kids[k], &e->kid_hits[k]);
+    }
+    e->myhits.n = 0;
+    const int matched = order_matching_hits(e);
+    if (matched) { /* m_dDocs[iDoc++] = *m_dChildDoc[0]: the first child's doc, as it is */
+      e->rowid = rowid;
+      e->fields = e->kids[0]->fields;
+      e->tfidf = e->kids[0]->tfidf;
+    }
+    if (!en_next(e->kids[0])) e->ord_done = 1;
+    if (matched) return 1;
+    if (e->ord_done) return 0;
+  }
+}
+
 static int en_next(enode* e) {
   int ok;
   switch (e->kind) {
@@ -1304,6 +1409,7 @@ static int en_next(enode* e) {
     case EN_MAYBE: ok = maybe_next(e); break;
     case EN_ANDNOT: ok = andnot_next(e); break;
     case EN_QUORUM: ok = quorum_next(e); break;
+    case EN_ORDER: ok = order_next(e); break;
     default: ok = phrase_next(e); break;
   }
   if (!ok) e->rowid = ORC_INVALID_ROWID;
@@ -1319,6 +1425,7 @@ static void en_hits(enode* e, hitvec* out) {
     case EN_MAYBE: or_hits(e, out); break;
     case EN_ANDNOT: en_hits(e->l, out); break; /* :3686-3694 */
     case EN_QUORUM:
+    case EN_ORDER:
       for (int i = 0; i < e->myhits.n; i++) hv_push(out, &e->myhits.p[i]);
       break;
     default: phrase_hits(e, out); break;
@@ -1359,6 +1466,9 @@ static void en_free(enode* e) {
   free(e->px_prox);
   free(e->px_deltas);
   for (int i = 0; i < e->n_kids; i++) en_free(e->kids[i]);
+  if (e->kid_hits)
+    for (int i = 0; i < e->n_kids; i++) free(e->kid_hits[i].p);
+  free(e->kid_hits);
   free(e->kids);
   free(e->kid_ok);
   free(e->myhits.p);
@@ -1571,6 +1681,32 @@ static enode* build_node(build_ctx* bc, int ni) {
       for (int i = 1; i < k; i++) cur = build_twofer(bc, thr == 1 ? EN_OR : EN_AND, cur, terms[pos[i]]);
       return cur;
     }
+    case ORC_OP_BEFORE: { /* CreateOrderNode (searchnode.cpp:1044-1073): children as they come, in query order */
+      int k = qn->n_children;
+      if (k < 2 || k > 32) {
+        bc->error = 1;
+        fail("order node requires 2..32 children");
+        return NULL;
+      }
+      enode* e = en_new(bc, EN_ORDER);
+      e->kids = (enode**)calloc((size_t)k, sizeof(enode*));
+      e->kid_hits = (hitvec*)calloc((size_t)k, sizeof(hitvec));
+      for (int i = 0; i < k; i++) {
+        e->kids[i] = build_node(bc, q->children[qn->first_child + i]);
+        e->n_kids = i + 1;
+        if (!e->kids[i]) {
+          if (!bc->error) {
+            bc->error = 1;
+            fail("order node: a child could not be created");
+          }
+          e->n_kids = i;
+          en_free(e);
+          return NULL;
+        }
+      }
+      e->atom = e->kids[0]->atom;
+      return e;
+    }
     case ORC_OP_AND: {
       int k = qn->n_children;
       if (k < 1 || k > 32) {
@@ -1715,6 +1851,7 @@ static void collect_qwords(enode* e, qw_hash* h, int* dupes) {
       break;
     case EN_PHRASE: collect_qwords(e->inner, h, dupes); break;
     case EN_QUORUM:
+    case EN_ORDER:
       for (int i = 0; i < e->n_kids; i++) collect_qwords(e->kids[i], h, dupes);
       break;
     default:
@@ -1737,6 +1874,7 @@ static void set_idf(enode* e, const qw_hash* h) {
       break;
     case EN_PHRASE: set_idf(e->inner, h); break;
     case EN_QUORUM:
+    case EN_ORDER:
       for (int i = 0; i < e->n_kids; i++) set_idf(e->kids[i], h);
       break;
     default:

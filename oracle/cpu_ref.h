@@ -55,7 +55,8 @@ enum {
   ORC_OP_ANDNOT = 4,
   ORC_OP_PHRASE = 5,
   ORC_OP_PROXIMITY = 6,
-  ORC_OP_QUORUM = 7
+  ORC_OP_QUORUM = 7,
+  ORC_OP_BEFORE = 8 /* 'a << b << c' (ExtOrder_c) */
 };
 
 /* ---- VLB codec (src/sphinxstd.h:5545-5567, src/fileio.cpp:31-45) ---- */

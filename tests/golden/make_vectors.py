@@ -61,6 +61,9 @@ G = {
                                   [{"count": 510, "fields": ["e x f"]},
                                    {"count": 1, "fields": ["e x f x x x e x f x x e x f x x"]},
                                    {"count": 1, "fields": [" y y i x j" * 532]}]},
+        "test_052": {"source": "test/test_052/test.xml (index test: rows 1..5) + model.bin", "min_word_len": 1, "ids": [1, 2, 3, 4, 5],
+                     "docs": [["aaa bbb", "ccc ddd"], ["xxx", "ccc ddd eee fff ggg"], ["yyy", "one one one two three"],
+                              ["zzz", "one two three one three one two four one two three four"], ["", "a b c d e f g"]]},
         # test_055 (position anchors): rows 10..19 are doubled six times by INSERT .. SELECT document_id+N
         "test_055": {"source": "test/test_055/test.xml + model.bin", "min_word_len": 1,
                      "ids": [1, 2, 3, 4, 9] + list(range(10, 650)) + [2000, 1000, 1001],
@@ -135,6 +138,43 @@ G["cases"] += [
      "ranker": "wordcount", "expect": [[521, 3]] + [[i, 1] for i in range(11, 30)], "limit": 20, "total_found": 511},
     {"name": "116 \"i j\"~2 wordcount", "corpus": "test_116", "query": OP("proximity", T("i", 1), T("j", 2), opt=2),
      "ranker": "wordcount", "expect": [[522, 532]], "total_found": 1},
+]
+G["cases"] += [  # test_052: the BEFORE operator '<<' (ExtOrder_c, searchnode.cpp:4657-4936); keywords count 1, 2, 3.. in query text order
+    {"name": "052 " + n, "corpus": "test_052", "query": q, "ranker": "proximity_bm25", "expect": e, "total_found": len(e)}
+    for n, q, e in [
+        ("aaa << ccc", OP("before", T("aaa", 1), T("ccc", 2)), []),
+        ("aaa << bbb << ccc", OP("before", T("aaa", 1), T("bbb", 2), T("ccc", 3)), []),
+        ("aaa << ccc << ddd", OP("before", T("aaa", 1), T("ccc", 2), T("ddd", 3)), []),
+        ("ccc << ddd", OP("before", T("ccc", 1), T("ddd", 2)), [[1, 2543], [2, 2543]]),
+        ("ccc << eee << fff", OP("before", T("ccc", 1), T("eee", 2), T("fff", 3)), [[2, 2529]]),
+        ("ccc << ddd << ggg", OP("before", T("ccc", 1), T("ddd", 2), T("ggg", 3)), [[2, 2529]]),
+        ("ccc << ddd << xxx", OP("before", T("ccc", 1), T("ddd", 2), T("xxx", 3)), []),
+        ("eee << ddd << ggg", OP("before", T("eee", 1), T("ddd", 2), T("ggg", 3)), []),
+        ("one << two << three", OP("before", T("one", 1), T("two", 2), T("three", 3)), [[4, 3549], [3, 2546]]),
+        ("one << three", OP("before", T("one", 1), T("three", 2)), [[4, 2574], [3, 1569]]),
+        ("one << one << three", OP("before", T("one", 1), T("one", 2), T("three", 3)), [[4, 2574], [3, 2569]]),
+        ("one << one << one << three", OP("before", T("one", 1), T("one", 2), T("one", 3), T("three", 4)), [[3, 3569], [4, 1574]]),
+        ("one << one << one << one << three", OP("before", T("one", 1), T("one", 2), T("one", 3), T("one", 4), T("three", 5)), [[4, 1574]]),
+        ("one << two << three << four", OP("before", T("one", 1), T("two", 2), T("three", 3), T("four", 4)), [[4, 4537]]),
+        ("\"a b c\" << b << c << d", OP("before", OP("phrase", T("a", 1), T("b", 2), T("c", 3)), T("b", 4), T("c", 5), T("d", 6)), []),
+        ("\"a b c\" << c << d << e", OP("before", OP("phrase", T("a", 1), T("b", 2), T("c", 3)), T("c", 4), T("d", 5), T("e", 6)), []),
+        ("\"a b c\" << e << f << g", OP("before", OP("phrase", T("a", 1), T("b", 2), T("c", 3)), T("e", 4), T("f", 5), T("g", 6)), [[5, 3602]]),
+        ("a << \"b c d\" << e", OP("before", T("a", 1), OP("phrase", T("b", 2), T("c", 3), T("d", 4)), T("e", 5)), [[5, 4540]]),
+        ("\"a b c d\" << \"d e f\"", OP("before", OP("phrase", T("a", 1), T("b", 2), T("c", 3), T("d", 4)),
+                                          OP("phrase", T("d", 5), T("e", 6), T("f", 7))), []),
+        ("\"a b c d\" << \"e f g\"", OP("before", OP("phrase", T("a", 1), T("b", 2), T("c", 3), T("d", 4)),
+                                          OP("phrase", T("e", 5), T("f", 6), T("g", 7))), [[5, 4616]]),
+        ("(ccc | \"ddd eee\") << (ddd | ggg)", OP("before", OP("or", T("ccc", 1), OP("phrase", T("ddd", 2), T("eee", 3))),
+                                                  OP("or", T("ddd", 4), T("ggg", 5))), [[2, 1594], [1, 1521]]),
+        ("ccc << ddd$", OP("before", T("ccc", 1), T("ddd", 2, tp="end")), [[1, 2543]]),
+        ("^one << two << three$", OP("before", T("one", 1, tp="start"), T("two", 2), T("three", 3, tp="end")), [[3, 2546]]),
+        ("^one << \"one one\" << two << three$", OP("before", T("one", 1, tp="start"), OP("phrase", T("one", 2), T("one", 3)), T("two", 4),
+                                                    T("three", 5, tp="end")), [[3, 5546]]),
+        # the threshold "1" is itself a keyword-sized token here (min_word_len = 1) and takes query position 3
+        # (XQParser_t::ParseNumeric, sphinxquery.cpp:1160-1170): the next keyword stands at 4
+        ("\"zzz aaa\"/1 << bbb", OP("before", OP("quorum", T("zzz", 1), T("aaa", 2), opt=1), T("bbb", 4)), [[1, 1568]]),
+        ("\"zzz aaa\"/1 << ddd", OP("before", OP("quorum", T("zzz", 1), T("aaa", 2), opt=1), T("ddd", 4)), []),
+    ]
 ]
 G["cases"] += [  # test_055: '^' and '$' (ExtTermPos_T, searchnode.cpp:2259-2405)
     {"name": "055 ^one two", "corpus": "test_055", "query": OP("and", T("one", 1, tp="start"), T("two", 2)),
