@@ -54,10 +54,11 @@ __device__ __forceinline__ bool row_is_dead(const DevSegment& seg, uint32_t rowi
 constexpr uint32_t PK_WIDE = 0xFFu;
 constexpr int NBINS = 1024; // pruning histogram bins per query
 constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
-constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4, PN_PHRASEFIX = 5, PN_QUORUM = 6; // prog[] opcodes
+constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4, PN_PHRASEFIX = 5, PN_QUORUM = 6, PN_ORDERFIX = 7; // prog[] opcodes
 constexpr int QUORUM_EVENTS = 8; // keywords of a quorum node = doclists that can run dry and reorder its children
 constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
 constexpr uint32_t TF_BITMAP = 4;   // 2-keyword AND answered by the bitmap kernel (items are window ranges)
+constexpr uint32_t TF_ORDER = 128;      // the TF_PHRASE_LEAF node is a BEFORE operator (ExtOrder_c) over the keywords of ph_mask
 constexpr uint32_t TF_TERMPOS = 64;     // some keyword carries a position modifier (ExtTermPos_T)
 constexpr uint32_t TF_QUORUM_HITS = 32; // the root is an ExtQuorum_c: its hits sort by position WITHOUT the end flag
 constexpr uint32_t TF_DUPES = 16;      // a keyword occurs more than once in the query (HasQwordDupes, sphinxsearch.cpp:4178)

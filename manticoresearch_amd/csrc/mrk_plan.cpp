@@ -77,6 +77,7 @@ struct PlanTree {
   bool force_tree = false;      // the query must run as a tree program even if it only holds TERM / AND nodes
   // one real ExtQuorum_c ('"a b c"/N', 1 < N < words): its keywords are kws[q_kw0 .. q_kw0 + q_n) in query-position order
   bool quorum = false, quorum_root = false;
+  bool order = false;           // the ph_leaf node is a BEFORE operator (ExtOrder_c), not a PHRASE
   bool termpos = false;         // some keyword carries a position modifier ('^word', 'word$', '@field[N] word')
   int q_kw0 = 0, q_n = 0, q_thr = 0;
   IntVec atoms;                 // its words' query positions, phrase order
@@ -182,6 +183,35 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     for (size_t k = kw0; k < T.kws.size(); ++k) T.kws[k].queried32 &= n.field_mask; // Create ( word, pNode, .. )
     T.force_tree = true; // an ExtAnd_c chain is not an ExtMultiAnd_T (no MergeHits3 quirk): always the tree program
     return cur;
+  }
+  if (n.op == MRK_OP_BEFORE) {
+    // ExtOrder_c (CreateOrderNode, searchnode.cpp:1044-1073): children in query order, no sorting; the doc is the FIRST
+    // child's doc (fields, tfidf) once all children hold it and their hits line up in order inside one field
+    if (T.phrase || T.ph_leaf)
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: more than one PHRASE / BEFORE node (device path: one per query)", qi), -1;
+    if (n.n_children < 2 || n.n_children > MAX_PROX_TERMS || n.first_child < 0)
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: BEFORE over %d nodes (device path: 2..%d plain keywords)", qi, n.n_children, MAX_PROX_TERMS), -1;
+    const int kw0 = (int)T.kws.size();
+    int cur = -1;
+    for (int i = 0; i < n.n_children; ++i) {
+      const int32_t ki = q.children[n.first_child + i];
+      if (ki < 0 || ki >= q.n_nodes) return err = mrk_fail(MRK_E_INVAL, "query %u: child index out of range", qi), -1;
+      if (q.nodes[ki].op != MRK_OP_TERM)
+        return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: BEFORE over plain keywords only on the device path", qi), -1;
+      T.atoms.push_back(q.nodes[ki].atom_pos);
+      if (i && T.atoms[i] <= T.atoms[i - 1]) return err = mrk_fail(MRK_E_INVAL, "query %u: BEFORE operands' query positions must ascend", qi), -1;
+      const int l = leaf(ki);
+      cur = cur < 0 ? l : join(PN_AND, cur, l);
+    }
+    T.ph_leaf = T.order = T.force_tree = true;
+    T.ph_kw0 = kw0;
+    T.ph_n = n.n_children;
+    PlanNode pn;
+    pn.op = PN_ORDERFIX;
+    pn.l = cur;
+    pn.kw = kw0; // the first child: its doc is the node's doc
+    T.nodes.push_back(pn);
+    return (int)T.nodes.size() - 1;
   }
   if (!nway && n.op != MRK_OP_AND && n.op != MRK_OP_OR && n.op != MRK_OP_MAYBE && n.op != MRK_OP_ANDNOT)
     return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, n.op), -1;
@@ -355,7 +385,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   if (!pure_and) { // the device evaluates the program on a TREE_STACK-deep register stack
     int sp = 0, deep = 0;
     for (const PlanNode& pn : T.nodes) {
-      sp += (pn.op == PN_TERM || pn.op == PN_QUORUM) ? 1 : pn.op == PN_PHRASEFIX ? 0 : -1;
+      sp += (pn.op == PN_TERM || pn.op == PN_QUORUM) ? 1 : (pn.op == PN_PHRASEFIX || pn.op == PN_ORDERFIX) ? 0 : -1;
       deep = std::max(deep, sp);
     }
     if (deep > TREE_STACK) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree nests deeper than the device path evaluates", qi);
@@ -615,7 +645,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     P->n_terms = (uint32_t)n;
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
     P->req_mask = P->excl_mask = 0;
-    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0);
+    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0) | (T.order ? TF_ORDER : 0);
     P->px_dist = (uint32_t)T.px_dist;
     P->qr_mask = P->qr_thr = P->qr_n = 0;
     if (T.quorum) {

@@ -440,6 +440,9 @@ struct HitCtx {
   int max_qpos, n_qwords; // ExtRanker_c::m_iMaxQpos / m_iQwords
   bool inline_hits, multi_and;
   bool dupes;             // repeated query keywords under a proximity ranker: RankerState_Proximity_fn<.., true>
+  uint64_t apack;         // ap0..ap3, 16 bits each: indexed by shifting (a select over the four fields would be
+                          // turned into an indexed load and push the whole struct to scratch)
+  bool order;             // the keywords of pmask form a BEFORE node (ExtOrder_c), not a PHRASE
   bool termpos;           // some keyword carries a position modifier: its stream yields acceptable hits only
   bool quorum_hits;       // the root is an ExtQuorum_c: hits order by position without the end flag (QuorumCmpHitPos_fn)
 };
@@ -484,6 +487,12 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
     F.reset();
   bool phave = false, pdone = pmask == 0, first = true;
   uint32_t pcur = 0, pfield = 0, pw = 0, pspan = 0;
+  // BEFORE (ExtOrder_c::GetMatchingHits, searchnode.cpp:4734-4829): the longest in-order run of the children's hits so far
+  // and the most recently started one (entry i = child i's hit); a full run is flushed to the ranker hit by hit
+  uint32_t ol0 = 0, ol1 = 0, ol2 = 0, ol3 = 0, or0 = 0, or1 = 0, or2 = 0, or3 = 0; // trackers
+  uint32_t oe0 = 0, oe1 = 0, oe2 = 0, oe3 = 0;                                     // flushed run waiting for the ranker
+  uint32_t olen_l = 0, olen_r = 0, opos_l = 0, opos_r = 0, ofield = 0xFFFFFFFFu, opend_i = 0, opend_n = 0, pq = C.ap0 & 0xFFFFu;
+  bool pend_is_end = false;
   RankState X;
   X.reset();
   const uint32_t dmask = smask & ~pmask; // keywords whose hits reach the ranker as they are
@@ -492,7 +501,99 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
   // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
   int phase = (C.multi_and && !pmask && C.nterms == 3 && (sm[0] & sm[1] & sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
   for (;;) {
-    if (!pdone && !phave) { // pull the next occurrence out of the phrase's word streams
+    if (!pdone && !phave && C.order && opend_i < opend_n) { // the next hit of the run flushed last
+      const uint32_t h = opend_i == 1 ? oe1 : opend_i == 2 ? oe2 : oe3;
+      pcur = h & ~(1u << 23), pend_is_end = ((h >> 23) & 1u) != 0;
+      pq = (uint32_t)(C.apack >> (16u * opend_i)) & 0xFFFFu;
+      pw = 1u, pspan = 0u;
+      ++opend_i;
+      phave = true;
+    }
+    if (!pdone && !phave && C.order) {
+      for (;;) {
+        int best = -1;
+        uint32_t bh = 0, bkey = 0, bci = 0, bmask = 0;
+#pragma unroll
+        for (int t = 0; t < MAX_PROX_TERMS; ++t) { // GetChildIdWithNextHit (:4706-4731): least position, ties to the first child
+          const uint32_t q16 = sq[t] & 0xFFFFu;
+          const uint32_t ci = q16 == ((uint32_t)C.apack & 0xFFFFu)           ? 0u
+                              : q16 == ((uint32_t)(C.apack >> 16) & 0xFFFFu) ? 1u
+                              : q16 == ((uint32_t)(C.apack >> 32) & 0xFFFFu) ? 2u
+                                                                             : 3u;
+          const uint32_t key = sc[t] & ~(1u << 23);
+          if (((pmask >> t) & 1u) && sc[t] && (best < 0 || key < bkey || (key == bkey && ci < bci)))
+            best = t, bh = sc[t], bkey = key, bci = ci, bmask = sm[t];
+        }
+        if (best < 0) {
+          pdone = true;
+          break;
+        }
+        bool flushed = false;
+        if (field_queried(bmask, bh)) {
+          const uint32_t hf = bh >> 24, hpos = bh & 0x7FFFFFu;
+          if (hf != ofield) { // new field: both trackers start over
+            olen_l = olen_r = 0;
+            if (bci == 0) {
+              ol0 = bh, olen_l = 1, opos_l = hpos + 1u;
+              ofield = hf;
+            }
+          } else if (bci == olen_l && hpos >= opos_l) { // it extends the longest run
+            if (bci == 0) ol0 = bh;
+            if (bci == 1) ol1 = bh;
+            if (bci == 2) ol2 = bh;
+            if (bci == 3) ol3 = bh;
+            ++olen_l, opos_l = hpos + 1u;
+            if (olen_l == C.nph) {
+              oe0 = ol0, oe1 = ol1, oe2 = ol2, oe3 = ol3;
+              opend_n = olen_l, opend_i = 1;
+              olen_l = olen_r = 0;
+              opos_r = opos_l;
+              flushed = true;
+            }
+          } else if (bci == 0) { // it restarts the most recent run
+            or0 = bh, olen_r = 1, opos_r = hpos + 1u;
+            if (!olen_l) ol0 = bh, olen_l = 1, opos_l = hpos + 1u;
+          } else if (bci == olen_r && hpos >= opos_r) { // it extends the most recent run
+            if (bci == 1) or1 = bh;
+            if (bci == 2) or2 = bh;
+            if (bci == 3) or3 = bh;
+            ++olen_r, opos_r = hpos + 1u;
+            if (olen_r == olen_l) { // which just became the longest
+              ol0 = or0, ol1 = or1, ol2 = or2, ol3 = or3;
+              olen_r = 0;
+              opos_l = opos_r;
+            }
+          }
+        }
+        {
+          uint64_t ap = best == 0 ? sp[0] : best == 1 ? sp[1] : best == 2 ? sp[2] : sp[3];
+          uint32_t ac = best == 0 ? sc[0] : best == 1 ? sc[1] : best == 2 ? sc[2] : sc[3];
+          hit_advance(C.spp, ap, ac);
+          if (C.termpos) {
+            const uint32_t ak = best == 0 ? tpk[0] : best == 1 ? tpk[1] : best == 2 ? tpk[2] : tpk[3];
+            const uint32_t am = best == 0 ? tpm[0] : best == 1 ? tpm[1] : best == 2 ? tpm[2] : tpm[3];
+            while (ac && !tp_accept(ak, am, ac)) hit_advance(C.spp, ap, ac);
+          }
+#pragma unroll
+          for (int t = 0; t < MAX_PROX_TERMS; ++t)
+            if (t == best) sp[t] = ap, sc[t] = ac;
+        }
+        if (flushed) {
+          phave = true;
+          pcur = oe0 & ~(1u << 23), pend_is_end = ((oe0 >> 23) & 1u) != 0;
+          pq = C.ap0 & 0xFFFFu;
+          pw = 1u, pspan = 0u;
+          pfield = oe0 >> 24;
+          break;
+        }
+      }
+      if (first) {
+        ph_found = phave;
+        ph_field = pfield;
+        first = false;
+      }
+    }
+    if (!pdone && !phave && !C.order) { // pull the next occurrence out of the phrase's word streams
       for (;;) {
         int best = -1;
         uint32_t bh = 0, bq = 0, bmask = 0;
@@ -552,8 +653,10 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
       if (((dmask >> t) & 1u) && sc[t] &&
           (best < 0 || (sc[t] & cmpmask) < (bh & cmpmask) || ((sc[t] & cmpmask) == (bh & cmpmask) && sq[t] < bq)))
         best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
-    if (phave && (best < 0 || pcur < bh || (pcur == bh && (C.ap0 & 0xFFFFu) < (bq & 0xFFFFu)))) {
-      X.update(C.ranker, C.dupes, pcur, false, C.ap0 & 0xFFFFu, pw, pspan, C.w_of, C.max_qpos);
+    // (a BEFORE node hands on plain hits: against its siblings they order by the raw position, end flag included)
+    const uint32_t pkey = pcur | (pend_is_end ? 1u << 23 : 0u);
+    if (phave && (best < 0 || pkey < bh || (pkey == bh && pq < (bq & 0xFFFFu)))) {
+      X.update(C.ranker, C.dupes, pcur, pend_is_end, pq, pw, pspan, C.w_of, C.max_qpos);
       phave = false;
       continue;
     }
@@ -780,9 +883,11 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   HC.max_qpos = (int)Q->max_qpos, HC.n_qwords = (int)Q->n_qwords;
   HC.inline_hits = inline_hits, HC.multi_and = multi_and;
   HC.quorum_hits = (Q->tree_flags & TF_QUORUM_HITS) != 0;
-  HC.termpos = PROX && (Q->tree_flags & TF_TERMPOS) != 0;
+  HC.termpos = PROX && TREE && (Q->tree_flags & TF_TERMPOS) != 0; // both only occur in tree programs: the plain-AND variant drops the code
+  HC.order = PROX && TREE && (Q->tree_flags & TF_ORDER) != 0;
+  HC.apack = (uint64_t)(ap0 & 0xFFFFu) | ((uint64_t)(ap1 & 0xFFFFu) << 16) | ((uint64_t)(ap2 & 0xFFFFu) << 32) | ((uint64_t)(ap3 & 0xFFFFu) << 48);
   HC.dupes = (Q->tree_flags & TF_DUPES) != 0 && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY);
-  auto drain_hits = [&](uint32_t from, uint32_t n) {
+  auto drain_hits = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
     if (!PROX) return;
     wave_lds_fence();
     const bool valid = lane < n;
@@ -1205,6 +1310,17 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
               s0.v[r] = m ? v : 0.0f;
               s0.f[r] = m ? f : 0u;
               s0.a[r] = m ? pm : 0u;
+            }
+          } else if (op == PN_ORDERFIX) {
+            // ExtOrder_c over the AND chain of its keywords just evaluated: the doc stays only if their hits line up in
+            // order; it is the FIRST child's doc -- that keyword's tfidf and fields alone (searchnode.cpp:4907-4908)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const bool m = s0.m[r] && ph_ok[r];
+              s0.m[r] = m;
+              s0.v[r] = m ? L.kv[kw][lane + 64 * r] : 0.0f;
+              s0.f[r] = m ? (uint32_t)L.kf[kw][lane + 64 * r] : 0u;
+              s0.a[r] = m ? s0.a[r] : 0u;
             }
           } else if (op == PN_PHRASEFIX) {
             // ExtNWay_T<FSMphrase_c> over the AND chain of its words just evaluated: the doc stays only if the

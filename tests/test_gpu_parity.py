@@ -730,7 +730,7 @@ def test_golden_vectors_on_device(dev):
     rankers = {"proximity_bm25": m.SPH_RANK_PROXIMITY_BM25, "bm25": m.SPH_RANK_BM25, "none": m.SPH_RANK_NONE,
                "wordcount": m.SPH_RANK_WORDCOUNT, "sph04": m.SPH_RANK_SPH04}
     ops = {"and": m.SPH_QUERY_AND, "or": m.SPH_QUERY_OR, "andnot": m.SPH_QUERY_ANDNOT, "phrase": m.SPH_QUERY_PHRASE,
-           "proximity": m.SPH_QUERY_PROXIMITY, "quorum": m.SPH_QUERY_QUORUM}
+           "proximity": m.SPH_QUERY_PROXIMITY, "quorum": m.SPH_QUERY_QUORUM, "before": m.SPH_QUERY_BEFORE}
 
     def tree(v, q):
         if "word" in q:
@@ -758,9 +758,14 @@ def test_golden_vectors_on_device(dev):
                 assert r.total_found == c["total_found"]
             n_ok += 1
         seg.close()
-    # packed path: every case but the five-word phrase (device path: <= 4 words); VLB path: keyword / AND cases under BM25 / NONE
+    # packed path: every case but those with more than four keywords / phrase words, and BEFORE over anything but plain
+    # keywords (declined loudly); VLB path: keyword / AND cases under BM25 / NONE
     if ctx_path(ctx) == 0:
-        assert declined == ['080 "C B A A A"'] and n_ok == len(GOLDEN["cases"]) - 1, (declined, n_ok)
+        want_declined = ['080 "C B A A A"', '052 one << one << one << one << three', '052 "a b c" << b << c << d',
+                         '052 "a b c" << c << d << e', '052 "a b c" << e << f << g', '052 a << "b c d" << e',
+                         '052 "a b c d" << "d e f"', '052 "a b c d" << "e f g"', '052 (ccc | "ddd eee") << (ddd | ggg)',
+                         '052 ^one << "one one" << two << three$', '052 "zzz aaa"/1 << bbb', '052 "zzz aaa"/1 << ddd']
+        assert sorted(declined) == sorted(want_declined) and n_ok == len(GOLDEN["cases"]) - len(want_declined), (declined, n_ok)
     else:
         assert n_ok >= 1
 
@@ -1040,5 +1045,71 @@ def test_term_position_modifiers(orc, dev, block, fmt):
             n_found += g.total_found
             n_run += 1
         assert n_run >= 150 and n_found > 20000
+    finally:
+        seg.close()
+
+
+# ------------------------------------------------------------------ BEFORE operator (ExtOrder_c)
+def BEFORE(m, *k):
+    return m.XQNode(m.SPH_QUERY_BEFORE, list(k))
+
+
+@pytest.mark.parametrize("block,fmt", [(128, 1), (32, 0)])
+def test_before_operator(orc, dev, block, fmt):
+    """'a << b << c' over 2..4 plain keywords (repeated ones included, position modifiers too): at the root and below
+    AND / OR / MAYBE / ANDNOT, every ranker.  The doc is the first operand's doc (its tfidf and fields alone); the hits of
+    every complete in-order run reach the ranker.  Reference vectors: test_052 in the golden fixture."""
+    m, ctx, batch = dev
+    if ctx_path(ctx) != 0:
+        pytest.skip("BEFORE runs on the packed path")
+    rng = np.random.default_rng(5252 + block)
+    n_docs = 30000
+    probs = [0.5, 0.35, 0.2, 0.1, 0.04, 0.01, 0.002]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=12, end_markers=True)
+    nt = len(probs) + 1
+    hi = m.index_from_hits(W, R, H, n_terms=nt, total_docs=n_docs, skiplist_block_size=block, hit_format=fmt, n_fields=3)
+    rankers = [m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_WORDCOUNT, m.SPH_RANK_SPH04,
+               m.SPH_RANK_PROXIMITY, m.SPH_RANK_MATCHANY, m.SPH_RANK_FIELDMASK]
+    qs = []
+    for i in range(200):
+        k = int(rng.integers(2, 5))
+        ts = [int(t) for t in rng.choice(nt, size=k, replace=bool(i % 3 == 0))]
+        mask = lambda: int(rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0b011, 0b110]))
+        n_ord = k if i % 2 == 0 else int(rng.integers(2, k + 1))
+        leaves = []
+        for j, t in enumerate(ts):
+            tp = int(rng.integers(0, 12))
+            leaves.append(m.XQNode.keyword(t, j + 1, mask(), field_start=tp == 1, field_end=tp == 2, field_max_pos=6 if tp == 3 else 0))
+        node = BEFORE(m, *leaves[:n_ord])
+        rest = leaves[n_ord:]
+        shape = int(rng.integers(0, 4))
+        if not rest:
+            root = node
+        elif shape == 0:
+            root = m.XQNode.AND(node, *rest)
+        elif shape == 1:
+            root = OR(m, node, *rest)
+        elif shape == 2:
+            root = ANDNOT(m, node, rest[0])
+        else:
+            root = m.XQNode(m.SPH_QUERY_MAYBE, [rest[0], node])
+        fw = [int(x) for x in rng.integers(-2, 9, 3)] if rng.random() < 0.3 else None
+        qs.append(m.Query(root, ranker=int(rng.choice(rankers)), max_matches=int(rng.choice([20, 1000])), field_weights=fw))
+    seg = m.Segment(ctx, hi)
+    oi = orc_index_of(orc, hi)
+    n_found = n_run = 0
+    try:
+        got = []
+        for i in range(0, len(qs), batch.max_queries):
+            got += batch.search(seg, qs[i:i + batch.max_queries])
+        for q, g in zip(qs, got):
+            if g.status == -2:
+                continue
+            want = to_orc(orc, q).run(oi)
+            assert g.status == 0 and g.total_found == want.total_found
+            assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+            n_found += g.total_found
+            n_run += 1
+        assert n_run >= 180 and n_found > 20000, (n_run, n_found)
     finally:
         seg.close()
