@@ -121,6 +121,23 @@ typedef struct {
    both = STARTEND, a field position limit = LIMIT (and wins over the anchors) */
 enum { MRK_TERMPOS_NONE = 0, MRK_TERMPOS_START = 1, MRK_TERMPOS_END = 2, MRK_TERMPOS_STARTEND = 3, MRK_TERMPOS_LIMIT = 4 };
 
+/* One attribute filter (CSphFilterSettings, sphinx.h:2461-2496) over an integer attribute of the row-wise .spa storage,
+   already resolved to the attribute's locator.  All filters of a query must pass (Filter_And); rejected rows never reach
+   the ranker or the sorter and are not counted (ExtRanker_c::GetMatches -> CSphIndex_VLN::EarlyReject,
+   sphinxsearch.cpp:1055-1064, sphinx.cpp:11903-11917). */
+enum { MRK_FILTER_VALUES = 0, MRK_FILTER_RANGE = 1 }; /* SPH_FILTER_VALUES, SPH_FILTER_RANGE */
+#define MRK_MAX_FILTERS 2
+#define MRK_MAX_FILTER_VALUES 8
+typedef struct {
+  int32_t kind;                 /* MRK_FILTER_* */
+  int32_t bit_offset, bit_count; /* CSphAttrLocator::m_iBitOffset / m_iBitCount (1..32 inside one dword, or 64 dword-aligned) */
+  int32_t exclude;              /* m_bExclude: the row passes iff the test fails */
+  int32_t has_equal_min, has_equal_max, open_left, open_right; /* RANGE: m_bHasEqualMin/Max, m_bOpenLeft/Right */
+  int64_t min_value, max_value; /* RANGE (SphAttr_t is signed 64-bit) */
+  const int64_t* values;        /* VALUES: ascending (IFilter_Values::SetValues), <= MRK_MAX_FILTER_VALUES on the device */
+  int32_t n_values;
+} mrk_filter;
+
 /* CSphQuery fields that reach the ranker + the query tree */
 typedef struct {
   const mrk_node* nodes;
@@ -137,6 +154,8 @@ typedef struct {
   int64_t total_docs_override;  /* CSphQueryContext::m_iTotalDocs (local_df), <= 0: segment's */
   const int64_t* local_docs;    /* per node: m_pLocalDocs override of term docs, < 0 none; or NULL */
   int32_t cutoff;               /* CSphQuery::m_iCutoff; only 0 supported on device */
+  const mrk_filter* filters;    /* CSphQuery::m_dFilters resolved against the schema; needs mrk_segment_set_attrs */
+  int32_t n_filters;            /* <= MRK_MAX_FILTERS on the device */
 } mrk_query;
 
 typedef struct {
@@ -182,6 +201,9 @@ void mrk_segment_destroy(mrk_segment* seg);
    (CSphIndex_VLN::MatchExtended, sphinx.cpp:12213-12217).  bitmap = NULL clears the map.  The call waits
    for the context's running batches, so a search sees either the old or the new map. */
 int mrk_segment_set_dead_rows(mrk_segment* seg, const uint32_t* bitmap, uint64_t n_rows);
+/* Row-wise attribute storage (.spa: CSphRowitem rows[n_rows][stride], sphinx.cpp GetDocinfoByRowID) copied to HBM for the
+   filters of mrk_query; rows = NULL drops it.  Waits for the context's running batches like mrk_segment_set_dead_rows. */
+int mrk_segment_set_attrs(mrk_segment* seg, const uint32_t* rows, uint32_t stride_dwords, uint64_t n_rows);
 /* device bytes held, and the reference-format doclist bytes of one term */
 uint64_t mrk_segment_device_bytes(const mrk_segment* seg);
 

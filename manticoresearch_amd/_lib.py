@@ -42,12 +42,20 @@ class Node(C.Structure):
                 ("not_weighted", C.c_int32), ("term_pos", C.c_int32), ("field_max_pos", C.c_int32)]
 
 
+class Filter(C.Structure):
+    """mrk_filter (include/mrk.h)"""
+    _fields_ = [("kind", C.c_int32), ("bit_offset", C.c_int32), ("bit_count", C.c_int32), ("exclude", C.c_int32),
+                ("has_equal_min", C.c_int32), ("has_equal_max", C.c_int32), ("open_left", C.c_int32), ("open_right", C.c_int32),
+                ("min_value", C.c_int64), ("max_value", C.c_int64), ("values", C.POINTER(C.c_int64)), ("n_values", C.c_int32)]
+
+
 class Query(C.Structure):
     _fields_ = [("nodes", C.POINTER(Node)), ("n_nodes", C.c_int32), ("children", C.POINTER(C.c_int32)),
                 ("root", C.c_int32), ("ranker", C.c_int32), ("max_matches", C.c_int32),
                 ("field_weights", C.POINTER(C.c_int32)), ("n_weights", C.c_int32), ("index_weight", C.c_int32),
                 ("plain_idf", C.c_int32), ("normalized_tfidf", C.c_int32), ("total_docs_override", C.c_int64),
-                ("local_docs", C.POINTER(C.c_int64)), ("cutoff", C.c_int32)]
+                ("local_docs", C.POINTER(C.c_int64)), ("cutoff", C.c_int32), ("filters", C.POINTER(Filter)),
+                ("n_filters", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -94,6 +102,7 @@ SYMBOLS = [
     ("mrk_batch_record_event", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mrk_topk_merge_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("mrk_segment_set_dead_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    ("mrk_segment_set_attrs", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     ("mrk_batch_create", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("mrk_batch_destroy", None, [C.c_void_p]),
     ("mrk_batch_submit", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Query), C.c_uint32]),

@@ -189,6 +189,29 @@ class XQNode:
 
 
 @dataclass
+class Filter:
+    """CSphFilterSettings over an integer attribute of the row-wise storage (sphinx.h:2461-2496), resolved to the
+    attribute's locator.  values (ascending) => SPH_FILTER_VALUES, else SPH_FILTER_RANGE over [min, max]."""
+    bit_offset: int
+    bit_count: int
+    values: Optional[Sequence[int]] = None
+    min: int = 0
+    max: int = 0
+    exclude: bool = False
+    has_equal_min: bool = True
+    has_equal_max: bool = True
+    open_left: bool = False
+    open_right: bool = False
+
+    def as_dict(self) -> dict:  # the oracle's spelling
+        d = dict(bit_offset=self.bit_offset, bit_count=self.bit_count, exclude=self.exclude, has_equal_min=self.has_equal_min,
+                 has_equal_max=self.has_equal_max, open_left=self.open_left, open_right=self.open_right, min=self.min, max=self.max)
+        if self.values is not None:
+            d["values"] = list(self.values)
+        return d
+
+
+@dataclass
 class Query:
     """CSphQuery fields that reach the ranker, plus the parsed tree."""
     root: XQNode
@@ -201,6 +224,7 @@ class Query:
     total_docs: int = 0                       # local_df: m_iTotalDocs override
     local_docs: Optional[Dict[int, int]] = None  # local_df: term id -> global docs
     cutoff: int = 0
+    filters: Optional[Sequence["Filter"]] = None  # CSphQuery::m_dFilters, resolved to attribute locators
 
 
 class _CQueries:
@@ -249,6 +273,20 @@ class _CQueries:
                 c.local_docs = ld
                 self.keep.append(ld)
             c.cutoff = q.cutoff
+            if q.filters:
+                fl = (_lib.Filter * len(q.filters))()
+                for i, f in enumerate(q.filters):
+                    fl[i].kind = 0 if f.values is not None else 1
+                    fl[i].bit_offset, fl[i].bit_count, fl[i].exclude = f.bit_offset, f.bit_count, int(f.exclude)
+                    fl[i].has_equal_min, fl[i].has_equal_max = int(f.has_equal_min), int(f.has_equal_max)
+                    fl[i].open_left, fl[i].open_right = int(f.open_left), int(f.open_right)
+                    fl[i].min_value, fl[i].max_value = int(f.min), int(f.max)
+                    if f.values is not None:
+                        vals = (C.c_int64 * len(f.values))(*sorted(int(v) for v in f.values))
+                        self.keep.append(vals)
+                        fl[i].values, fl[i].n_values = vals, len(f.values)
+                self.keep.append(fl)
+                c.filters, c.n_filters = fl, len(q.filters)
             self.keep += [cn, ch]
 
 
@@ -303,6 +341,15 @@ class Segment:
     @property
     def device_bytes(self) -> int:
         return int(lib().mrk_segment_device_bytes(self._h))
+
+    def set_attrs(self, rows: Optional[np.ndarray]) -> None:
+        """Upload the row-wise attribute storage (.spa rows: uint32 [n_rows, stride]) for Query.filters; None drops it."""
+        if rows is None:
+            check(lib().mrk_segment_set_attrs(self._h, None, 0, 0))
+            return
+        a = np.ascontiguousarray(rows, dtype=np.uint32)
+        assert a.ndim == 2
+        check(lib().mrk_segment_set_attrs(self._h, a.ctypes.data, a.shape[1], a.shape[0]))
 
     def set_dead_rows(self, bitmap: Optional[np.ndarray]) -> None:
         """Install the segment's dead-row map (uint32 words, DeadRowMap_c layout); None clears it."""
@@ -401,5 +448,5 @@ def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool =
 __all__ = ["SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
            "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE",
-           "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Matches", "Context",
+           "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Filter", "Matches", "Context",
            "Segment", "Batch", "prepare", "idf", "MrkError"]

@@ -45,7 +45,46 @@ struct DevSegment {
   const uint32_t* bm;
   const uint32_t* bm_dir;
   uint32_t n_windows;       // windows per bitmap = ceil(total_docs / 2048)
+  const uint32_t* attrs;    // row-wise attributes (.spa rows, attr_stride dwords each) or NULL
+  uint32_t attr_stride;
 };
+
+struct DevFilter { // mrk_filter with the values inline
+  uint32_t kind;                  // MRK_FILTER_* | exclude << 8 | has_equal_min << 9 | has_equal_max << 10 | open_left << 11 | open_right << 12
+  uint32_t item, shift, bits;     // dword of the row, bit offset inside it, width (64 = two dwords)
+  uint32_t n_values, pad;
+  int64_t lo, hi;                 // RANGE
+  int64_t values[MRK_MAX_FILTER_VALUES];
+};
+
+// ISphFilter::Eval over the row's attributes: Filter_Values (binary search in the reference, <= 8 values here),
+// Filter_Range (EvalRange, sphinxfilter.h:130-143), FilterNot for m_bExclude; Filter_And over the query's filters
+__device__ __forceinline__ bool row_passes_filters(const DevSegment& seg, const DevFilter* __restrict__ fl, uint32_t n, uint32_t rowid) {
+  const uint32_t* __restrict__ row = seg.attrs + (uint64_t)rowid * seg.attr_stride;
+  bool ok = true;
+  for (uint32_t i = 0; i < n; ++i) {
+    const DevFilter& F = fl[i];
+    int64_t v; // sphGetRowAttr (sphinx.h:993-1014)
+    if (F.bits == 64)
+      v = (int64_t)((uint64_t)row[F.item] | ((uint64_t)row[F.item + 1] << 32));
+    else if (F.bits == 32)
+      v = (int64_t)row[F.item];
+    else
+      v = (int64_t)((row[F.item] >> F.shift) & ((1u << F.bits) - 1u));
+    bool pass;
+    if ((F.kind & 0xffu) == MRK_FILTER_VALUES) {
+      pass = false;
+      for (uint32_t k = 0; k < F.n_values; ++k) pass = pass || v == F.values[k];
+    } else {
+      const bool eq_min = (F.kind >> 9) & 1u, eq_max = (F.kind >> 10) & 1u, open_l = (F.kind >> 11) & 1u, open_r = (F.kind >> 12) & 1u;
+      const bool min_ok = eq_min ? v >= F.lo : v > F.lo, max_ok = eq_max ? v <= F.hi : v < F.hi;
+      pass = open_l ? max_ok : open_r ? min_ok : (min_ok && max_ok);
+    }
+    if ((F.kind >> 8) & 1u) pass = !pass;
+    ok = ok && pass;
+  }
+  return ok;
+}
 
 __device__ __forceinline__ bool row_is_dead(const DevSegment& seg, uint32_t rowid) {
   return (seg.dead[rowid >> 5] >> (rowid & 31u)) & 1u; // DeadRowMap_c::IsSet, killlist.h:39-46
@@ -88,6 +127,7 @@ struct DevTerm {
   uint32_t tp_max;    // MRK_TERMPOS_LIMIT: largest acceptable position within the field
 };
 
+
 struct DevQuery {
   uint32_t n_terms; // terms sorted ascending by docs (ExtMultiAnd_T node order); [0] drives
   uint32_t ranker;
@@ -110,6 +150,8 @@ struct DevQuery {
   uint32_t tree_flags; // TF_*
   uint32_t prog[16];  // op | left node << 8 | right node << 16 | keyword << 24
   uint32_t ph_atoms[MAX_PROX_TERMS_]; // PHRASE: query positions of its words, in phrase order
+  uint32_t n_filters;                 // attribute filters: all must pass (EarlyReject)
+  DevFilter filters[MRK_MAX_FILTERS];
   uint32_t ph_mask;                   // TF_PHRASE_LEAF: keyword slots of the phrase's words
   // ExtQuorum_c: keyword slots, threshold, and the order of its children (4 bits per slot, 0xF = end) as a
   // function of the rowid: qr_ord[0] up to qr_row[0], qr_ord[i + 1] for rowids beyond qr_row[i] (the keyword whose

@@ -257,6 +257,7 @@ extern "C" void mrk_segment_destroy(mrk_segment* s) {
   if (s->d_pk_hbase) (void)hipFree(s->d_pk_hbase);
   if (s->d_pk_attr1) (void)hipFree(s->d_pk_attr1);
   if (s->d_dead) (void)hipFree(s->d_dead);
+  if (s->d_attrs) (void)hipFree(s->d_attrs);
   if (s->d_bm) (void)hipFree(s->d_bm);
   if (s->d_bm_dir) (void)hipFree(s->d_bm_dir);
   delete s;
@@ -282,6 +283,28 @@ extern "C" int mrk_segment_set_dead_rows(mrk_segment* s, const uint32_t* bitmap,
   if (s->d_dead) (void)hipFree(s->d_dead);
   s->d_dead = fresh;
   s->dev.dead = (const uint32_t*)fresh;
+  return MRK_OK;
+}
+
+extern "C" int mrk_segment_set_attrs(mrk_segment* s, const uint32_t* rows, uint32_t stride, uint64_t n_rows) {
+  if (!s || !s->ctx) return mrk_fail(MRK_E_INVAL, "mrk_segment_set_attrs: NULL segment");
+  if (rows && (stride == 0 || stride > 4096)) return mrk_fail(MRK_E_INVAL, "mrk_segment_set_attrs: row stride %u dwords", stride);
+  if (rows && n_rows < s->total_docs)
+    return mrk_fail(MRK_E_INVAL, "mrk_segment_set_attrs: %llu rows, segment has %llu", (unsigned long long)n_rows, (unsigned long long)s->total_docs);
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  HIP_TRY(hipDeviceSynchronize()); // batches of this context run on their own streams
+  void* fresh = nullptr;
+  if (rows) {
+    const size_t bytes = (size_t)n_rows * stride * 4;
+    HIP_TRY(hipMalloc(&fresh, bytes + 8)); // + a spare dword pair: a 64-bit attribute read never runs off the end
+    HIP_TRY(hipMemset((char*)fresh + bytes, 0, 8));
+    HIP_TRY(hipMemcpy(fresh, rows, bytes, hipMemcpyHostToDevice));
+  }
+  if (s->d_attrs) (void)hipFree(s->d_attrs);
+  s->d_attrs = fresh;
+  s->attr_rows = rows ? n_rows : 0;
+  s->dev.attrs = (const uint32_t*)fresh;
+  s->dev.attr_stride = rows ? stride : 0;
   return MRK_OK;
 }
 

@@ -60,6 +60,8 @@ struct mrk_segment {
   void* d_pk_hbase = nullptr;
   void* d_pk_attr1 = nullptr;
   void* d_dead = nullptr;
+  void* d_attrs = nullptr; // .spa rows (mrk_segment_set_attrs)
+  uint64_t attr_rows = 0;
   void* d_bm = nullptr;
   void* d_bm_dir = nullptr;
 };

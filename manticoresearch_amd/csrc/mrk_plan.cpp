@@ -447,6 +447,38 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     default: return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker %d not on the device path", qi, q.ranker);
   }
 
+  // attribute filters (EarlyReject): resolved locators over the segment's .spa rows
+  dq.n_filters = 0;
+  if (q.n_filters < 0 || (q.n_filters > 0 && !q.filters)) return mrk_fail(MRK_E_INVAL, "query %u: bad filter list", qi);
+  if (q.n_filters > 0) {
+    if (!seg->dev.attrs) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: filters need the segment's attribute rows (mrk_segment_set_attrs)", qi);
+    if (!use_packed) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: filters run on the packed path only", qi);
+    if (q.n_filters > MRK_MAX_FILTERS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d filters (device path: <= %d)", qi, q.n_filters, MRK_MAX_FILTERS);
+    for (int i = 0; i < q.n_filters; ++i) {
+      const mrk_filter& f = q.filters[i];
+      DevFilter& d = dq.filters[i];
+      memset(&d, 0, sizeof d);
+      if (f.kind != MRK_FILTER_VALUES && f.kind != MRK_FILTER_RANGE) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: filter kind %d not on the device path", qi, f.kind);
+      const bool wide = f.bit_count == 64;
+      if (f.bit_offset < 0 || f.bit_count < 1 || (!wide && (f.bit_count > 32 || (f.bit_offset & 31) + f.bit_count > 32)) || (wide && (f.bit_offset & 31)) ||
+          (uint64_t)(f.bit_offset + f.bit_count) > (uint64_t)seg->dev.attr_stride * 32)
+        return mrk_fail(MRK_E_INVAL, "query %u: filter locator %d/%d outside the %u-dword row", qi, f.bit_offset, f.bit_count, seg->dev.attr_stride);
+      d.kind = (uint32_t)f.kind | (f.exclude ? 1u << 8 : 0) | (f.has_equal_min ? 1u << 9 : 0) | (f.has_equal_max ? 1u << 10 : 0) |
+               (f.open_left ? 1u << 11 : 0) | (f.open_right ? 1u << 12 : 0);
+      d.item = (uint32_t)f.bit_offset >> 5;
+      d.shift = (uint32_t)f.bit_offset & 31u;
+      d.bits = (uint32_t)f.bit_count;
+      d.lo = f.min_value, d.hi = f.max_value;
+      if (f.kind == MRK_FILTER_VALUES) {
+        if (f.n_values < 1 || !f.values) return mrk_fail(MRK_E_INVAL, "query %u: values filter without values", qi);
+        if (f.n_values > MRK_MAX_FILTER_VALUES) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d filter values (device path: <= %d)", qi, f.n_values, MRK_MAX_FILTER_VALUES);
+        d.n_values = (uint32_t)f.n_values;
+        for (int k = 0; k < f.n_values; ++k) d.values[k] = f.values[k];
+      }
+    }
+    dq.n_filters = (uint32_t)q.n_filters;
+  }
+
   // IDFs: distinct words in GetQwords traversal order (searchnode.cpp:2029-2055, 3276-3286)
   IntVec words;
   for (int i = 0; i < n; ++i) {
@@ -593,7 +625,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   tree_out = tree_out || !pure_and;
 
   // two dense keywords: the bitmap kernel (mrk_scan_bm.hip) walks 2048-rowid windows instead of blocks
-  if (use_packed && pure_and && !T.phrase && n == 2 && (ranker == MRK_RANK_NONE || ranker == MRK_RANK_BM25) && seg->dev.bm &&
+  if (use_packed && pure_and && !T.phrase && n == 2 && q.n_filters == 0 && (ranker == MRK_RANK_NONE || ranker == MRK_RANK_BM25) && seg->dev.bm &&
       seg->ctx->bitmap_inv > 0 && seg->terms[T.kws[0].term_id].bm_off != ~0ull && seg->terms[T.kws[1].term_id].bm_off != ~0ull) {
     dq.n_terms = 2;
     for (int i = 0; i < 2; ++i) fill_term(seg, T.kws[i], dq.t[i]);

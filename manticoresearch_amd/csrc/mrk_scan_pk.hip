@@ -1367,6 +1367,11 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       }
 
       if (gt_new > tau_bin) tau_bin = gt_new;
+      if (Q->n_filters) { // EarlyReject: filtered rows never reach the ranker (sphinxsearch.cpp:1055-1064)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          if (live[r] && !row_passes_filters(a.seg, Q->filters, Q->n_filters, row[r])) live[r] = false;
+      }
       if (a.seg.dead) { // MatchExtended drops dead rows before they reach the sorter (sphinx.cpp:12213-12217)
 #pragma unroll
         for (int r = 0; r < 2; ++r)

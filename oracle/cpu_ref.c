@@ -2109,6 +2109,46 @@ static inline int matchany_finalize(matchany_state* s, int n_fields, const int32
 /* ------------------------------------------------------------------------ */
 /* search = sphCreateRanker + MatchExtended + sorter                         */
 /* ------------------------------------------------------------------------ */
+/* ISphFilter::Eval: sphGetRowAttr (sphinx.h:993-1014), IFilter_Values::EvalValues (sphinxfilter.cpp:69-91), EvalRange
+   (sphinxfilter.h:130-143), FilterNot for m_bExclude, Filter_And over the list */
+static int filters_pass(const orc_index* idx, const orc_query* q, uint32_t rowid) {
+  const uint32_t* row = idx->attrs + (size_t)rowid * (size_t)idx->attr_stride;
+  for (int i = 0; i < q->n_filters; i++) {
+    const orc_filter* f = &q->filters[i];
+    const int item = f->bit_offset >> 5;
+    int64_t v;
+    if (f->bit_count == 32)
+      v = (int64_t)row[item];
+    else if (f->bit_count == 64)
+      v = (int64_t)((uint64_t)row[item] | ((uint64_t)row[item + 1] << 32));
+    else
+      v = (int64_t)((row[item] >> (f->bit_offset & 31)) & ((1ul << f->bit_count) - 1));
+    int pass;
+    if (f->kind == ORC_FILTER_VALUES) {
+      pass = 0;
+      int lo = 0, hi = f->n_values - 1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) / 2;
+        if (f->values[mid] == v) {
+          pass = 1;
+          break;
+        }
+        if (f->values[mid] < v)
+          lo = mid + 1;
+        else
+          hi = mid - 1;
+      }
+    } else {
+      const int min_ok = f->has_equal_min ? v >= f->min_value : v > f->min_value;
+      const int max_ok = f->has_equal_max ? v <= f->max_value : v < f->max_value;
+      pass = f->open_left ? max_ok : f->open_right ? min_ok : (min_ok && max_ok);
+    }
+    if (f->exclude) pass = !pass;
+    if (!pass) return 0;
+  }
+  return 1;
+}
+
 int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
   g_err[0] = 0;
   res->n = 0;
@@ -2240,6 +2280,9 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
           if (mask & (1u << i)) rank += (uint32_t)weights[i];
       weight = use_bm25 ? (int)((uint32_t)bm25 + rank * SPH_BM25_SCALE) : (int)rank;
     }
+    /* EarlyReject (ExtRanker_c::GetMatches, sphinxsearch.cpp:1055-1064; CSphIndex_VLN::EarlyReject, sphinx.cpp:11903-11917):
+       the reference drops filtered rows before it ranks them; dropping them here gives the same matches */
+    if (q->n_filters > 0 && !filters_pass(idx, q, root->rowid)) continue;
     /* MatchExtended (sphinx.cpp:12211-12263): dead rows never reach the sorter (:12213-12217) */
     if (idx->dead_rows && (idx->dead_rows[root->rowid >> 5] >> (root->rowid & 31u)) & 1u) continue;
     weight = (int)((uint32_t)weight * (uint32_t)index_weight);

@@ -102,7 +102,21 @@ typedef struct {
   int inline_hits; /* hit_format=inline (1) or plain (0) */
   int n_fields;
   const uint32_t* dead_rows; /* DeadRowMap_c bitmap (killlist.h:22-46) or NULL */
+  const uint32_t* attrs;     /* row-wise attribute storage (.spa): CSphRowitem rows[total_docs][attr_stride], or NULL */
+  int attr_stride;
 } orc_index;
+
+/* CSphFilterSettings over an integer attribute (sphinx.h:2461-2496), resolved to the attribute's locator */
+enum { ORC_FILTER_VALUES = 0, ORC_FILTER_RANGE = 1 };
+typedef struct {
+  int kind;
+  int bit_offset, bit_count; /* CSphAttrLocator */
+  int exclude;
+  int has_equal_min, has_equal_max, open_left, open_right;
+  int64_t min_value, max_value;
+  const int64_t* values; /* ascending */
+  int n_values;
+} orc_filter;
 
 /* ---- query tree ---- */
 typedef struct {
@@ -138,6 +152,8 @@ typedef struct {
   int64_t total_docs_override; /* local_df: m_iTotalDocs (<=0: use index) */
   const int64_t* local_docs;   /* local_df per NODE index (docs override, <0 none) or NULL */
   int cutoff;          /* 0 = none */
+  const orc_filter* filters; /* all must pass (Filter_And) */
+  int n_filters;
 } orc_query;
 
 typedef struct {

@@ -44,7 +44,7 @@ class _Index(C.Structure):
     _fields_ = [("spd", C.c_void_p), ("spd_len", C.c_size_t), ("spp", C.c_void_p), ("spp_len", C.c_size_t),
                 ("spe", C.c_void_p), ("spe_len", C.c_size_t), ("dict", C.c_void_p), ("n_terms", C.c_uint32),
                 ("total_docs", C.c_int64), ("skiplist_block_size", C.c_int), ("inline_hits", C.c_int),
-                ("n_fields", C.c_int), ("dead_rows", C.c_void_p)]
+                ("n_fields", C.c_int), ("dead_rows", C.c_void_p), ("attrs", C.c_void_p), ("attr_stride", C.c_int)]
 
 
 class _Node(C.Structure):
@@ -53,12 +53,18 @@ class _Node(C.Structure):
                 ("not_weighted", C.c_int), ("term_pos", C.c_int), ("field_max_pos", C.c_int)]
 
 
+class _Filter(C.Structure):
+    _fields_ = [("kind", C.c_int), ("bit_offset", C.c_int), ("bit_count", C.c_int), ("exclude", C.c_int),
+                ("has_equal_min", C.c_int), ("has_equal_max", C.c_int), ("open_left", C.c_int), ("open_right", C.c_int),
+                ("min_value", C.c_int64), ("max_value", C.c_int64), ("values", C.POINTER(C.c_int64)), ("n_values", C.c_int)]
+
+
 class _Query(C.Structure):
     _fields_ = [("nodes", C.POINTER(_Node)), ("n_nodes", C.c_int), ("children", C.POINTER(C.c_int)),
                 ("root", C.c_int), ("ranker", C.c_int), ("max_matches", C.c_int),
                 ("field_weights", C.POINTER(C.c_int32)), ("n_weights", C.c_int), ("index_weight", C.c_int),
                 ("plain_idf", C.c_int), ("normalized_tfidf", C.c_int), ("total_docs_override", C.c_int64),
-                ("local_docs", C.POINTER(C.c_int64)), ("cutoff", C.c_int)]
+                ("local_docs", C.POINTER(C.c_int64)), ("cutoff", C.c_int), ("filters", C.POINTER(_Filter)), ("n_filters", C.c_int)]
 
 
 class _Result(C.Structure):
@@ -126,6 +132,7 @@ class Index:
     inline_hits: int = 1
     n_fields: int = 2
     dead_rows: Optional[np.ndarray] = None  # uint32 bitmap, DeadRowMap_c layout
+    attrs: Optional[np.ndarray] = None      # uint32 [total_docs, stride]: the .spa rows
 
     def c_struct(self) -> _Index:
         s = _Index()
@@ -138,6 +145,8 @@ class Index:
         s.inline_hits = self.inline_hits
         s.n_fields = self.n_fields
         s.dead_rows = self.dead_rows.ctypes.data if self.dead_rows is not None else None
+        s.attrs = self.attrs.ctypes.data if self.attrs is not None else None
+        s.attr_stride = int(self.attrs.shape[1]) if self.attrs is not None else 0
         return s
 
     def decode_doclist(self, term_id: int):
@@ -221,6 +230,7 @@ class QNode:
     field_max_pos: int = 0
 
 
+FILTER_VALUES, FILTER_RANGE = 0, 1
 TERMPOS_NONE, TERMPOS_START, TERMPOS_END, TERMPOS_STARTEND, TERMPOS_LIMIT = 0, 1, 2, 3, 4
 
 
@@ -249,7 +259,7 @@ class FlatQuery:
     def __init__(self, root: QNode, ranker: int = RANK_BM25, max_matches: int = 1000,
                  field_weights: Optional[Sequence[int]] = None, index_weight: int = 1,
                  plain_idf: bool = False, normalized_tfidf: bool = True, total_docs_override: int = 0,
-                 local_docs: Optional[dict] = None, cutoff: int = 0):
+                 local_docs: Optional[dict] = None, cutoff: int = 0, filters: Optional[Sequence[dict]] = None):
         nodes: List[QNode] = []
 
         def walk(n: QNode) -> int:
@@ -287,6 +297,21 @@ class FlatQuery:
             self.ld = (C.c_int64 * len(nodes))(*arr)
             q.local_docs = self.ld
         q.cutoff = cutoff
+        if filters:  # dicts with the fields of orc_filter; "values" = ascending ints
+            self.fl = (_Filter * len(filters))()
+            self.fv = []
+            for i, f in enumerate(filters):
+                c = self.fl[i]
+                c.kind = FILTER_VALUES if "values" in f else FILTER_RANGE
+                c.bit_offset, c.bit_count, c.exclude = f["bit_offset"], f["bit_count"], int(f.get("exclude", False))
+                c.has_equal_min, c.has_equal_max = int(f.get("has_equal_min", True)), int(f.get("has_equal_max", True))
+                c.open_left, c.open_right = int(f.get("open_left", False)), int(f.get("open_right", False))
+                c.min_value, c.max_value = int(f.get("min", 0)), int(f.get("max", 0))
+                if "values" in f:
+                    vals = (C.c_int64 * len(f["values"]))(*sorted(int(v) for v in f["values"]))
+                    self.fv.append(vals)
+                    c.values, c.n_values = vals, len(f["values"])
+            q.filters, q.n_filters = self.fl, len(filters)
         self.q = q
         self.K = max_matches
 

@@ -39,7 +39,8 @@ def to_orc(orc, q):
 
     return orc.FlatQuery(conv(q.root), ranker=q.ranker, max_matches=q.max_matches, field_weights=q.field_weights,
                          index_weight=q.index_weight, plain_idf=q.plain_idf, normalized_tfidf=q.normalized_tfidf,
-                         total_docs_override=q.total_docs, local_docs=q.local_docs)
+                         total_docs_override=q.total_docs, local_docs=q.local_docs,
+                         filters=[f.as_dict() for f in q.filters] if q.filters else None)
 
 
 def check_batch(orc, dev, hi, queries, rowid_base=0):
@@ -1111,5 +1112,81 @@ def test_before_operator(orc, dev, block, fmt):
             n_found += g.total_found
             n_run += 1
         assert n_run >= 180 and n_found > 20000, (n_run, n_found)
+    finally:
+        seg.close()
+
+
+# ------------------------------------------------------------------ attribute filters (EarlyReject)
+def test_attribute_filters(orc, dev):
+    """SPH_FILTER_VALUES / SPH_FILTER_RANGE over integer attributes of the row-wise storage (32-bit, 64-bit, bit fields),
+    include / exclude, open ranges, strict bounds, two filters at once; with trees, phrases, every ranker and dead rows.
+    Rejected rows are neither ranked nor counted (sphinxsearch.cpp:1055-1064, sphinx.cpp:11903-11917)."""
+    m, ctx, batch = dev
+    if ctx_path(ctx) != 0:
+        pytest.skip("filters run on the packed path")
+    rng = np.random.default_rng(31337)
+    n_docs = 40000
+    probs = [0.45, 0.3, 0.1, 0.03, 0.006, 0.001]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=20, end_markers=True)
+    nt = len(probs)
+    hi = m.index_from_hits(W, R, H, n_terms=nt, total_docs=n_docs, n_fields=3)
+    # rows: [id lo, id hi (64-bit id), gid (32-bit), flags: 3-bit field at bit 4 and 1-bit at bit 9 of dword 3, price (64-bit, signed use)]
+    rows = np.zeros((n_docs, 6), np.uint32)
+    ids = np.arange(n_docs, dtype=np.uint64) * np.uint64(7) + np.uint64(1 << 33)
+    rows[:, 0], rows[:, 1] = (ids & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ids >> np.uint64(32)).astype(np.uint32)
+    rows[:, 2] = rng.integers(0, 50, n_docs)
+    rows[:, 3] = (rng.integers(0, 8, n_docs) << 4) | (rng.integers(0, 2, n_docs) << 9) | (rng.integers(0, 16, n_docs)) | (rng.integers(0, 1 << 20, n_docs) << 10 << 1)
+    price = rng.integers(-1000, 100000, n_docs).astype(np.int64)
+    rows[:, 4], rows[:, 5] = (price.view(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32), (price.view(np.uint64) >> np.uint64(32)).astype(np.uint32)
+    F = m.Filter
+
+    def rand_filter():
+        k = int(rng.integers(0, 5))
+        excl = bool(rng.random() < 0.25)
+        if k == 0:
+            return F(64, 32, values=sorted(set(int(v) for v in rng.integers(0, 50, int(rng.integers(1, 9))))), exclude=excl)
+        if k == 1:
+            lo = int(rng.integers(0, 40))
+            return F(64, 32, min=lo, max=lo + int(rng.integers(0, 20)), exclude=excl, has_equal_min=bool(rng.random() < 0.7), has_equal_max=bool(rng.random() < 0.7))
+        if k == 2:
+            return F(96 + 4, 3, values=sorted(set(int(v) for v in rng.integers(0, 8, 3))), exclude=excl) if rng.random() < 0.5 else F(96 + 9, 1, values=[1], exclude=excl)
+        if k == 3:
+            lo = int(rng.integers(-1000, 90000))
+            return F(128, 64, min=lo, max=lo + int(rng.integers(0, 30000)), exclude=excl, open_left=bool(rng.random() < 0.2), open_right=bool(rng.random() < 0.2))
+        base = (1 << 33) + 7 * int(rng.integers(0, n_docs))
+        return F(0, 64, min=base, max=base + 7 * 5000, exclude=excl)
+
+    qs = []
+    rankers = [m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_SPH04, m.SPH_RANK_WORDCOUNT]
+    for i in range(150):
+        a, b, c = (int(t) for t in rng.choice(nt, 3, replace=False))
+        shape = i % 6
+        root = [kw(m, a, 1), m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), OR(m, kw(m, a, 1), kw(m, b, 2)), m.XQNode.AND(OR(m, kw(m, a, 1), kw(m, b, 2)), kw(m, c, 3)),
+                PHRASE(m, kw(m, a, 1), kw(m, b, 2)), ANDNOT(m, kw(m, a, 1), kw(m, b, 2))][shape]
+        fl = [rand_filter() for _ in range(int(rng.integers(1, 3)))]
+        qs.append(m.Query(root, ranker=int(rng.choice(rankers)), max_matches=int(rng.choice([30, 1000])), filters=fl))
+    seg = m.Segment(ctx, hi)
+    oi = orc_index_of(orc, hi)
+    oi.attrs = rows
+    dead = np.zeros((n_docs + 31) // 32, np.uint32)
+    for r in rng.choice(n_docs, 900, replace=False):
+        dead[r >> 5] |= np.uint32(1 << (int(r) & 31))
+    r0 = batch.search(seg, qs[:1])[0]
+    assert r0.status == -2  # no attribute rows yet: declined, not answered
+    seg.set_attrs(rows)
+    seg.set_dead_rows(dead)
+    oi.dead_rows = dead
+    n_found = 0
+    try:
+        got = batch.search(seg, qs)
+        for q, g in zip(qs, got):
+            want = to_orc(orc, q).run(oi)
+            assert g.status == 0 and g.total_found == want.total_found
+            assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+            n_found += g.total_found
+        assert n_found > 50000, n_found
+        # more filters / values than the device path holds: declined
+        assert batch.search(seg, [m.Query(kw(m, 0, 1), filters=[F(64, 32, values=list(range(9)))])])[0].status == -2
+        assert batch.search(seg, [m.Query(kw(m, 0, 1), filters=[F(64, 32, min=1, max=2)] * 3)])[0].status == -2
     finally:
         seg.close()
