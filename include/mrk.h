@@ -327,6 +327,17 @@ int32_t mrk_host_index_find_word(const mrk_host_index* h, const char* word, int3
 const char* mrk_host_index_word(const mrk_host_index* h, uint32_t term_id, uint32_t* len);
 /* dict=crc: term id of a word id, -1 = absent */
 int32_t mrk_host_index_find_wordid(const mrk_host_index* h, uint64_t wordid);
+/* Schema attributes as the header lists them (CSphColumnInfo: name, ESphAttr type, locator) and the row-wise storage of
+   the .spa file: the first n_rows (= m_iDocinfo) rows of stride dwords -- what mrk_segment_set_attrs takes; the min-max
+   index that follows them in the file is not used.  NULL / 0 when the index has no .spa (no attributes but the id). */
+typedef struct {
+  const char* name;
+  uint32_t type;       /* ESphAttr (sphinx.h): 1 = uint, 2 = timestamp, 4 = bool, 5 = float, 6 = bigint, ... */
+  int32_t bit_offset;  /* CSphAttrLocator::m_iBitOffset; < 0 for blob-stored attributes */
+  int32_t bit_count;
+} mrk_attr_info;
+int mrk_host_index_attr(const mrk_host_index* h, uint32_t i, mrk_attr_info* out); /* i < mrk_index_info.n_attrs */
+const uint32_t* mrk_host_index_attr_rows(const mrk_host_index* h, uint32_t* stride_dwords, uint64_t* n_rows);
 /* .spm bitmap (bit rowid & 31 of word rowid >> 5), as mrk_segment_set_dead_rows takes it; NULL = no map */
 const uint32_t* mrk_host_index_dead_rows(const mrk_host_index* h, uint64_t* n_rows);
 

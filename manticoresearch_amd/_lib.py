@@ -78,6 +78,10 @@ class IndexInfo(C.Structure):
                 ("total_docs", C.c_uint64), ("total_bytes", C.c_uint64), ("n_dead", C.c_uint64)]
 
 
+class AttrInfo(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_uint32), ("bit_offset", C.c_int32), ("bit_count", C.c_int32)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_docs", C.c_uint64), ("shard", C.c_uint32), ("term_prob", C.POINTER(C.c_double)),
                 ("n_terms", C.c_uint32), ("n_fields", C.c_uint32), ("title_frac", C.c_double), ("max_pos", C.c_uint32),
@@ -127,6 +131,8 @@ SYMBOLS = [
     ("mrk_host_index_word", C.c_void_p, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("mrk_host_index_find_wordid", C.c_int32, [C.c_void_p, C.c_uint64]),
     ("mrk_host_index_dead_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("mrk_host_index_attr", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(AttrInfo)]),
+    ("mrk_host_index_attr_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
 ]
 
 

@@ -109,6 +109,16 @@ def open_index(path_prefix: str) -> HostIndex:
         for t in range(len(hi.dict)):
             p = L.mrk_host_index_word(h, t, C.byref(n))
             hi.words.append(C.string_at(p, n.value).decode("utf-8", "surrogateescape"))
+    hi.attrs = {}  # name -> (ESphAttr type, bit_offset, bit_count): Filter(bit_offset, bit_count, ...)
+    ai = _lib.AttrInfo()
+    for i in range(info.n_attrs):
+        check(L.mrk_host_index_attr(h, i, C.byref(ai)))
+        hi.attrs[ai.name.decode()] = (int(ai.type), int(ai.bit_offset), int(ai.bit_count))
+    stride, arows = C.c_uint32(), C.c_uint64()
+    p = L.mrk_host_index_attr_rows(h, C.byref(stride), C.byref(arows))
+    hi.attr_rows = None  # the .spa rows for Segment.set_attrs()
+    if p:
+        hi.attr_rows = np.frombuffer((C.c_uint32 * (arows.value * stride.value)).from_address(p), dtype=np.uint32).reshape(arows.value, stride.value).copy()
     nrows = C.c_uint64()
     p = L.mrk_host_index_dead_rows(h, C.byref(nrows))
     hi.dead_bitmap = hi.dead_rows = None

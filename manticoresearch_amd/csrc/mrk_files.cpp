@@ -15,6 +15,7 @@
 //         binary search over that table.
 //   .spd / .spp / .spe   taken as they are.
 //   .spm  dead-row map: one bit per row, DWORD words (DeadRowMap_c::IsSet, killlist.h:39-46).
+#include <ctype.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -127,11 +128,17 @@ struct Reader {
   }
 };
 
-void schema_column(Reader& r, uint32_t version) { // ReadSchemaColumn
-  r.str();
-  r.dword(), r.dword(), r.dword(), r.dword(); // type, rowitem, bit offset, bit count
-  r.byte();                                   // payload
-  if (version >= 61) r.dword();               // attr flags
+void schema_column(Reader& r, uint32_t version, mrk_host_index::Attr* out = nullptr) { // ReadSchemaColumn
+  std::string name = r.str();
+  const uint32_t type = r.dword();
+  r.dword(); // rowitem (ignored by the reference too)
+  const int32_t bit_offset = (int32_t)r.dword(), bit_count = (int32_t)r.dword();
+  r.byte();                     // payload
+  if (version >= 61) r.dword(); // attr flags
+  if (out) {
+    for (char& c : name) c = (char)tolower((unsigned char)c);
+    *out = mrk_host_index::Attr{name.empty() ? "@emptyname" : name, type, bit_offset, bit_count};
+  }
 }
 
 int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_index* h, uint64_t& cp_offset) {
@@ -159,7 +166,11 @@ int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_ind
   }
   I.n_attrs = r.dword();
   if (I.n_attrs > 65536) return mrk_fail(MRK_E_FORMAT, "%s: %u attributes", name, I.n_attrs);
-  for (uint32_t i = 0; i < I.n_attrs && !r.bad; ++i) schema_column(r, I.version);
+  for (uint32_t i = 0; i < I.n_attrs && !r.bad; ++i) {
+    mrk_host_index::Attr a;
+    schema_column(r, I.version, &a);
+    h->attrs.push_back(a);
+  }
   // dictionary header
   cp_offset = r.offset();
   I.n_checkpoints = r.dword();
@@ -229,7 +240,9 @@ int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_ind
   I.word_dict = r.byte() != 0;
   r.byte(); // stopwords unstemmed
   r.str();  // morphology fingerprint
-  r.offset(), r.offset(), r.offset(); // docinfo, docinfo index, min-max index
+  h->docinfo_rows = r.offset(); // m_iDocinfo: rows in .spa
+  r.offset();                   // m_iDocinfoIndex
+  r.offset();                   // m_iMinMaxIndex: where the min-max index starts in .spa, in dwords
   const uint32_t n_re = r.dword();
   for (uint32_t i = 0; i < n_re && !r.bad; ++i) r.str();
   if (I.index_field_lens)
@@ -352,6 +365,23 @@ extern "C" int mrk_index_open(const char* path_prefix, mrk_host_index** out) {
     for (uint64_t r = 0; r < rows && (r >> 5) < h->dead.size(); ++r) h->info.n_dead += (h->dead[r >> 5] >> (r & 31u)) & 1u;
     if (h->dead.size() * 32ull < rows) rc = mrk_fail(MRK_E_FORMAT, "%s.spm: %zu bytes for %llu rows", path_prefix, spm.size(), (unsigned long long)rows);
   }
+  if (rc == MRK_OK) {
+    // row-wise attributes: row size = the widest locator, in dwords (CSphSchema::GetRowSize); rows lead the .spa file
+    uint32_t bits = 0;
+    for (const mrk_host_index::Attr& a : h->attrs)
+      if (a.bit_offset >= 0 && a.bit_count > 0) bits = std::max<uint32_t>(bits, (uint32_t)(a.bit_offset + a.bit_count));
+    h->attr_stride = (bits + 31) / 32;
+    std::vector<uint8_t> spa;
+    if (h->attr_stride && h->docinfo_rows && read_file(base + ".spa", spa, true)) {
+      const uint64_t need = h->docinfo_rows * h->attr_stride * 4ull;
+      if (spa.size() < need)
+        rc = mrk_fail(MRK_E_FORMAT, "%s.spa: %zu bytes for %llu rows of %u dwords", path_prefix, spa.size(), (unsigned long long)h->docinfo_rows, h->attr_stride);
+      else {
+        h->attr_rows.resize((size_t)(need / 4));
+        memcpy(h->attr_rows.data(), spa.data(), (size_t)need);
+      }
+    }
+  }
   if (rc != MRK_OK) {
     delete h;
     return rc;
@@ -408,6 +438,20 @@ extern "C" int32_t mrk_host_index_find_wordid(const mrk_host_index* h, uint64_t 
       hi = mid;
   }
   return -1;
+}
+
+extern "C" int mrk_host_index_attr(const mrk_host_index* h, uint32_t i, mrk_attr_info* out) {
+  if (!h || !out || i >= h->attrs.size()) return mrk_fail(MRK_E_INVAL, "mrk_host_index_attr: no attribute %u", i);
+  const mrk_host_index::Attr& a = h->attrs[i];
+  *out = mrk_attr_info{a.name.c_str(), a.type, a.bit_offset, a.bit_count};
+  return MRK_OK;
+}
+
+extern "C" const uint32_t* mrk_host_index_attr_rows(const mrk_host_index* h, uint32_t* stride_dwords, uint64_t* n_rows) {
+  if (!h || h->attr_rows.empty()) return nullptr;
+  if (stride_dwords) *stride_dwords = h->attr_stride;
+  if (n_rows) *n_rows = h->docinfo_rows;
+  return h->attr_rows.data();
 }
 
 extern "C" const uint32_t* mrk_host_index_dead_rows(const mrk_host_index* h, uint64_t* n_rows) {

@@ -20,6 +20,15 @@ struct mrk_host_index {
   std::vector<char> words;          // dict=keywords: the keywords back to back, NUL terminated
   std::vector<uint32_t> word_off;   // per term: offset into words
   std::vector<uint32_t> dead;       // .spm: one bit per row
+  struct Attr {
+    std::string name;
+    uint32_t type;
+    int32_t bit_offset, bit_count;
+  };
+  std::vector<Attr> attrs;          // schema attributes, header order
+  std::vector<uint32_t> attr_rows;  // .spa: docinfo_rows x attr_stride dwords
+  uint32_t attr_stride = 0;
+  uint64_t docinfo_rows = 0;
   ~mrk_host_index() {
     free(spd);
     free(spp);

@@ -950,6 +950,19 @@ def test_index_files_on_device(orc, dev, tmp_path):
                         elif ctx_path(ctx) == 0:
                             qs.append(m.Query(OR(m, kw(m, a, 1), kw(m, b, 2)), ranker=rk))
         check_batch(orc, dev, hi, qs)
+        if name == "t250_plain2" and ctx_path(ctx) == 0:  # filters by attribute name over the ingested .spa rows
+            seg = m.Segment(ctx, hi)
+            seg.set_attrs(hi.attr_rows)
+            _, off, cnt = hi.attrs["id"]
+            third, fourth = hi.find_word("third"), hi.find_word("fourth")
+            root = OR(m, kw(m, third, 1), kw(m, fourth, 2))
+            res = batch.search(seg, [m.Query(root, ranker=m.SPH_RANK_BM25, filters=[m.Filter(off, cnt, values=[4])]),
+                                     m.Query(root, ranker=m.SPH_RANK_BM25, filters=[m.Filter(off, cnt, min=3, max=3)]),
+                                     m.Query(root, ranker=m.SPH_RANK_BM25, filters=[m.Filter(hi.attrs["mode"][1], hi.attrs["mode"][2], values=[2])]),
+                                     m.Query(root, ranker=m.SPH_RANK_BM25, filters=[m.Filter(hi.attrs["mode"][1], hi.attrs["mode"][2], values=[2], exclude=True)])])
+            assert [r.status for r in res] == [0, 0, 0, 0]
+            assert [r.rowid.tolist() for r in res] == [[1], [0], [0, 1], []] and [r.total_found for r in res] == [1, 1, 2, 0]
+            seg.close()
     # 2. a written index: dictionary lookups by keyword, dead rows from the .spm file
     src = synth(m, n_terms=60, n_docs=20000, block=32)
     words = sorted("kw%04d" % (t * 37 % 1009) for t in range(len(src.dict)))

@@ -26,6 +26,14 @@ EXPECT = {
 }
 
 
+ATTRS = {  # name -> (ESphAttr, bit offset, bit count); rows of the .spa file
+    "t250_plain2": ({"id": (6, 0, 64), "mode": (1, 64, 32)}, [[3, 0, 2], [4, 0, 2]]),
+    "t233_test": ({"id": (6, 0, 64), "$_blob_locator": (6, 64, 64), "gid": (1, 128, 32), "title": (7, 0, 0)}, [[3, 0, 8, 0, 123]]),
+    "t233_reload": ({"id": (6, 0, 64), "$_blob_locator": (6, 64, 64), "gid": (1, 128, 32), "title": (7, 0, 0)}, [[2, 0, 8, 0, 123]]),
+    "t406_index0": ({"id": (6, 0, 64)}, [[1, 0]]),
+}
+
+
 def orc_index(orc, hi):
     return orc.Index(hi.spd, hi.spp, hi.spe, hi.dict.view(orc.DICT_DTYPE), hi.total_docs, hi.skiplist_block_size,
                      hi.hit_format, hi.n_fields)
@@ -43,6 +51,9 @@ def test_reference_index_files(orc, name):
     assert hi.total_docs == total_docs and hi.info["total_bytes"] == total_bytes
     assert hi.words == [w for w, _, _ in words]  # dictionary order
     assert hi.dead_rows is None and hi.info["n_dead"] == 0
+    # schema attributes + the .spa rows: ids (and gid / mode) as that test's expected result rows list them
+    want_attrs, want_rows = ATTRS[name]
+    assert hi.attrs == want_attrs and hi.attr_rows.tolist() == want_rows
     oi = orc_index(orc, hi)
     for t, (w, pos, rowid) in enumerate(words):
         assert hi.find_word(w) == t
@@ -72,6 +83,14 @@ def test_reference_index_positions_through_the_rankers(orc):
     assert orc.search(oi, orc.op(orc.OP_PHRASE, kw("reload", 1), kw("index", 2)), ranker=orc.RANK_PROXIMITY_BM25).total_found == 1
     assert orc.search(oi, orc.op(orc.OP_PHRASE, kw("index", 1), kw("reload", 2)), ranker=orc.RANK_PROXIMITY_BM25).total_found == 0
     assert orc.search(oi, orc.op(orc.OP_PHRASE, kw("reload", 1), kw("from", 2)), ranker=orc.RANK_PROXIMITY_BM25).total_found == 0
+    # filters over the ingested .spa rows, by attribute name: gid = 123, id = 2
+    oi.attrs = hi.attr_rows
+    _, off, cnt = hi.attrs["gid"]
+    assert orc.search(oi, kw("index", 1), ranker=orc.RANK_BM25, filters=[dict(bit_offset=off, bit_count=cnt, values=[123])]).total_found == 1
+    assert orc.search(oi, kw("index", 1), ranker=orc.RANK_BM25, filters=[dict(bit_offset=off, bit_count=cnt, values=[122, 124])]).total_found == 0
+    _, off, cnt = hi.attrs["id"]
+    assert orc.search(oi, kw("index", 1), ranker=orc.RANK_BM25, filters=[dict(bit_offset=off, bit_count=cnt, min=2, max=2)]).total_found == 1
+    assert orc.search(oi, kw("index", 1), ranker=orc.RANK_BM25, filters=[dict(bit_offset=off, bit_count=cnt, min=2, max=2, exclude=True)]).total_found == 0
     # SPH04: 'reload index from' is the whole field => exact-match bonus: 4 * lcs + 2 (head) + 1 (exact)
     r = orc.search(oi, orc.op(orc.OP_AND, kw("reload", 1), kw("index", 2), kw("from", 3)), ranker=orc.RANK_SPH04)
     assert list(r.weight) == [(4 * 3 + 2 + 1) * 1000 + 500]
