@@ -236,7 +236,7 @@ struct PackRowsArgs {
 void launch_pack_rows(const PackRowsArgs& a, void* stream);
 
 void launch_scan(const ScanArgs& a, void* stream);
-void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, void* stream);
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, bool ext, void* stream);
 constexpr int MAX_PROX_TERMS = MAX_PROX_TERMS_; // keywords whose hit streams the hit kernel merges per doc
 void launch_scan_bm(const ScanArgs& a, void* stream); // a.items: (query, window range) work items
 void launch_select(const SelectArgs& a, void* stream);

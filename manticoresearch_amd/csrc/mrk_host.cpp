@@ -147,7 +147,7 @@ struct mrk_batch {
   // what a rerun of an overflowed query needs (mrk_batch_wait)
   mrk_segment* last_seg = nullptr;
   uint32_t n_pass = 0, last_max_terms = 1;
-  bool last_prox = false, last_tree = false;
+  bool last_prox = false, last_tree = false, last_ext = false;
   mrk_batch* retry = nullptr;
   hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_merge1 = nullptr;
   mrk_batch_stats stats{};
@@ -665,7 +665,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   items.reserve(n * 4);
   uint64_t algo_bytes = 0, dev_bytes = 0, cand_total = 0;
   uint32_t max_terms = 1;
-  bool any_prox = false, any_tree = false;
+  bool any_prox = false, any_tree = false, any_ext = false; // ext: position modifiers, BEFORE, attribute filters
   if (b->ctx->path == 2 && !seg->has_packed) return mrk_fail(MRK_E_UNSUPPORTED, "path=packed but the segment has no packed doclists");
   const bool use_packed = seg->has_packed && b->ctx->path != 1;
   std::vector<DevQuery> extra; // passes beyond the first of tree queries; pass index = n + position
@@ -683,6 +683,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
       b->h_queries.p[i].n_terms = 0;
     }
     max_terms = std::max(max_terms, b->h_queries.p[i].n_terms);
+    any_ext = any_ext || (b->h_queries.p[i].tree_flags & (mrk::TF_TERMPOS | mrk::TF_ORDER)) != 0 || b->h_queries.p[i].n_filters != 0;
     b->h_list_first.p[i] = b->h_queries.p[i].item_first;
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;
@@ -755,7 +756,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   lap("h2d+memset");
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
   if (use_packed) {
-    launch_scan_pk(sa, max_terms, any_prox, any_tree, st);
+    launch_scan_pk(sa, max_terms, any_prox, any_tree, any_ext, st);
     if (n_items_bm) {
       ScanArgs sb = sa;
       sb.items = b->d_items.p + n_items_pk;
@@ -810,6 +811,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   b->last_max_terms = max_terms;
   b->last_prox = any_prox;
   b->last_tree = any_tree;
+  b->last_ext = any_ext;
   if (use_packed) {
     HIP_TRY(hipMemcpyAsync(b->h_flags.p, b->d_q_flags.p, n * 4, hipMemcpyDeviceToHost, st2));
     HIP_TRY(hipMemcpyAsync(b->h_cand_n.p, b->d_q_cand_n.p, n * 4, hipMemcpyDeviceToHost, st2));
@@ -890,7 +892,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   sa.q_flags = r->d_q_flags.p;
   sa.q_tau_bin = r->d_q_tau_bin.p;
   sa.cand = r->d_cand.p;
-  launch_scan_pk(sa, b->last_max_terms, b->last_prox, b->last_tree, st);
+  launch_scan_pk(sa, b->last_max_terms, b->last_prox, b->last_tree, b->last_ext, st);
   if (n_items > n_pk) {
     ScanArgs sb = sa;
     sb.items = r->d_items.p + n_pk;

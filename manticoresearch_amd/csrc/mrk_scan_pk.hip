@@ -703,7 +703,9 @@ __device__ __forceinline__ bool termpos_any(const HitCtx& C, const DevTerm& Tt, 
   return false;
 }
 
-template <bool PROX, bool TREE>
+// EXT: the batch holds queries with position modifiers, a BEFORE node or attribute filters; batches without them run the
+// leaner instance (the extra code costs the three-keyword proximity mixes ~7 % even when it never executes)
+template <bool PROX, bool TREE, bool EXT = false>
 __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   extern __shared__ __align__(16) uint8_t smem_raw[];
   PkSmem<PROX, TREE>& s = *reinterpret_cast<PkSmem<PROX, TREE>*>(smem_raw);
@@ -883,8 +885,8 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   HC.max_qpos = (int)Q->max_qpos, HC.n_qwords = (int)Q->n_qwords;
   HC.inline_hits = inline_hits, HC.multi_and = multi_and;
   HC.quorum_hits = (Q->tree_flags & TF_QUORUM_HITS) != 0;
-  HC.termpos = PROX && TREE && (Q->tree_flags & TF_TERMPOS) != 0; // both only occur in tree programs: the plain-AND variant drops the code
-  HC.order = PROX && TREE && (Q->tree_flags & TF_ORDER) != 0;
+  HC.termpos = EXT && PROX && TREE && (Q->tree_flags & TF_TERMPOS) != 0; // both only occur in tree programs
+  HC.order = EXT && PROX && TREE && (Q->tree_flags & TF_ORDER) != 0;
   HC.apack = (uint64_t)(ap0 & 0xFFFFu) | ((uint64_t)(ap1 & 0xFFFFu) << 16) | ((uint64_t)(ap2 & 0xFFFFu) << 32) | ((uint64_t)(ap3 & 0xFFFFu) << 48);
   HC.dupes = (Q->tree_flags & TF_DUPES) != 0 && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY);
   auto drain_hits = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
@@ -1367,7 +1369,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       }
 
       if (gt_new > tau_bin) tau_bin = gt_new;
-      if (Q->n_filters) { // EarlyReject: filtered rows never reach the ranker (sphinxsearch.cpp:1055-1064)
+      if (EXT && Q->n_filters) { // EarlyReject: filtered rows never reach the ranker (sphinxsearch.cpp:1055-1064)
 #pragma unroll
         for (int r = 0; r < 2; ++r)
           if (live[r] && !row_passes_filters(a.seg, Q->filters, Q->n_filters, row[r])) live[r] = false;
@@ -1479,17 +1481,19 @@ __global__ __launch_bounds__(WG) void select_kernel(SelectArgs a) {
   if (tid == 0) a.out_cnt[q] = m;
 }
 
-template <bool PROX, bool TREE>
+template <bool PROX, bool TREE, bool EXT = false>
 static void launch_pk(const ScanArgs& a, size_t tail, hipStream_t st) {
-  hipLaunchKernelGGL((scan_pk_kernel<PROX, TREE>), dim3(a.n_items), dim3(WG), sizeof(PkSmem<PROX, TREE>) + tail, st, a);
+  hipLaunchKernelGGL((scan_pk_kernel<PROX, TREE, EXT>), dim3(a.n_items), dim3(WG), sizeof(PkSmem<PROX, TREE>) + tail, st, a);
 }
 
-void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, void* stream) {
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, bool ext, void* stream) {
   if (!a.n_items) return;
   if (max_terms < 1) max_terms = 1;
   const size_t tail = (size_t)(max_terms - 1) * 256 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (tree)
+  if (ext) // filters alone may come with a plain AND: the EXT instance is the full tree + hit-stream kernel
+    launch_pk<true, true, true>(a, tail, st);
+  else if (tree)
     prox ? launch_pk<true, true>(a, tail, st) : launch_pk<false, true>(a, tail, st);
   else
     prox ? launch_pk<true, false>(a, tail, st) : launch_pk<false, false>(a, tail, st);
