@@ -387,6 +387,10 @@ def MAYBE(m, *k):
     return m.XQNode(m.SPH_QUERY_MAYBE, list(k))
 
 
+def BEFORE(m, *k):
+    return m.XQNode(m.SPH_QUERY_BEFORE, list(k))
+
+
 def ANDNOT(m, *k):
     return m.XQNode(m.SPH_QUERY_ANDNOT, list(k))
 
@@ -796,8 +800,15 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
             ts = [int(t) for t in rng.choice(nt + 1, size=k, replace=bool(packed and rng.random() < 0.15))]
             masks = [0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)) for _ in ts]
             kws = [kw(m, t, i + 1, mk) for i, (t, mk) in enumerate(zip(ts, masks))]
-            shape = (rng.choice(["and", "or", "andnot", "maybe", "phrase", "mixed", "proximity", "quorum", "phrase_in_tree"])
+            shape = (rng.choice(["and", "or", "andnot", "maybe", "phrase", "mixed", "proximity", "quorum", "phrase_in_tree", "before",
+                                 "before_in_tree", "real_quorum"])
                      if (packed and k > 1) else "and")
+            if packed and shape not in ("phrase", "proximity", "quorum", "phrase_in_tree", "real_quorum") and rng.random() < 0.3:
+                for i in range(k):  # position modifiers: '^word', 'word$', '^word$', '@field[N] word'
+                    tp = int(rng.integers(0, 8))
+                    if tp < 4:
+                        kws[i] = m.XQNode.keyword(ts[i], i + 1, masks[i], field_start=tp in (0, 2), field_end=tp in (1, 2),
+                                                  field_max_pos=int(rng.integers(1, 4)) if tp == 3 else 0)
             if k == 1:
                 root = kws[0]
             elif shape == "and":
@@ -814,6 +825,13 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
                 root = PROXIMITY(m, int(rng.integers(1, 6)), *kws)
             elif shape == "quorum":
                 root = m.XQNode(m.SPH_QUERY_QUORUM, kws, None, 0xFFFFFFFF, 1 if rng.random() < 0.5 else k)
+            elif shape == "before":
+                root = BEFORE(m, *kws)
+            elif shape == "before_in_tree" and k > 2:
+                bf = BEFORE(m, *kws[:2])
+                root = [OR(m, bf, *kws[2:]), m.XQNode.AND(bf, *kws[2:]), ANDNOT(m, kws[2], bf), MAYBE(m, bf, kws[2])][int(rng.integers(0, 4))]
+            elif shape == "real_quorum" and k > 2 and len(set(ts)) == k:
+                root = m.XQNode(m.SPH_QUERY_QUORUM, [kw(m, t, i + 1) for i, t in enumerate(ts)], None, 0xFFFFFFFF, int(rng.integers(2, k)))
             elif shape == "phrase_in_tree" and k > 2:
                 ph = PHRASE(m, *kws[:2]) if rng.random() < 0.5 else PROXIMITY(m, 3, *kws[:2])
                 root = [OR(m, ph, *kws[2:]), m.XQNode.AND(ph, *kws[2:]), ANDNOT(m, kws[2], ph), MAYBE(m, ph, kws[2])][int(rng.integers(0, 4))]
@@ -821,11 +839,22 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
                 root = m.XQNode.AND(OR(m, *kws[:2]), *kws[2:]) if k > 2 else OR(m, *kws)
             rk = [m.SPH_RANK_BM25, m.SPH_RANK_NONE] + ([m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_PROXIMITY, m.SPH_RANK_WORDCOUNT,
                                                        m.SPH_RANK_MATCHANY, m.SPH_RANK_FIELDMASK, m.SPH_RANK_SPH04] if packed else [])
+            fl = None
+            if packed and rng.random() < 0.2:  # attribute filters over the rows set below
+                fl = [m.Filter(0, 32, values=sorted(set(int(v) for v in rng.integers(0, 6, 2))), exclude=bool(rng.random() < 0.3))
+                      if rng.random() < 0.5 else m.Filter(32, 64, min=int(rng.integers(-3, 3)), max=int(rng.integers(3, 9)))]
             qs.append(m.Query(root, ranker=int(rng.choice(rk)), max_matches=int(rng.choice([1, 3, 1000, 1024])),
-                              field_weights=[int(x) for x in rng.integers(-2, 9, 3)] if rng.random() < 0.4 else None))
+                              field_weights=[int(x) for x in rng.integers(-2, 9, 3)] if rng.random() < 0.4 else None, filters=fl))
         base = int(rng.choice([0, 7, 1 << 20]))
         seg = m.Segment(ctx, hi, rowid_base=base)
         oi = orc_index_of(orc, hi)
+        if packed:
+            arows = np.zeros((n_docs, 3), np.uint32)
+            arows[:, 0] = rng.integers(0, 6, n_docs)
+            big = rng.integers(-5, 12, n_docs).astype(np.int64).view(np.uint64)
+            arows[:, 1], arows[:, 2] = (big & np.uint64(0xFFFFFFFF)).astype(np.uint32), (big >> np.uint64(32)).astype(np.uint32)
+            seg.set_attrs(arows)
+            oi.attrs = arows
         if rng.random() < 0.5:
             dead = np.zeros((n_docs + 31) // 32, np.uint32)
             killed = rng.choice(n_docs, size=max(1, n_docs // 5), replace=False)
@@ -1064,9 +1093,6 @@ def test_term_position_modifiers(orc, dev, block, fmt):
 
 
 # ------------------------------------------------------------------ BEFORE operator (ExtOrder_c)
-def BEFORE(m, *k):
-    return m.XQNode(m.SPH_QUERY_BEFORE, list(k))
-
 
 @pytest.mark.parametrize("block,fmt", [(128, 1), (32, 0)])
 def test_before_operator(orc, dev, block, fmt):
