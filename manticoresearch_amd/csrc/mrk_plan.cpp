@@ -153,7 +153,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
       const size_t nodes0 = T.nodes.size();
       for (int i = 0; i < n.n_children; ++i) {
         for (int j = 0; j < i; ++j)
-          if (q.nodes[kids[ord[j]]].term_id == q.nodes[kids[ord[i]]].term_id)
+          if (q.nodes[kids[ord[i]]].term_id >= 0 && q.nodes[kids[ord[j]]].term_id == q.nodes[kids[ord[i]]].term_id)
             return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum with a repeated keyword (m_bHasDupes) is not on the device path", qi), -1;
         (void)leaf(kids[ord[i]]);
       }
@@ -483,7 +483,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   IntVec words;
   for (int i = 0; i < n; ++i) {
     bool seen = false;
-    for (int w : words) seen |= T.kws[w].term_id == T.kws[i].term_id;
+    for (int w : words) seen |= T.kws[i].term_id >= 0 && T.kws[w].term_id == T.kws[i].term_id; // words missing from the dictionary are distinct words
     T.kws[i].weighted_first = !seen;
     if (!seen) words.push_back(i);
   }

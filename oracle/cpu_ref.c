@@ -1503,7 +1503,8 @@ static void mnode_init(build_ctx* bc, mnode* n, const orc_node* qn, int nodepos)
   n->idf = 0.0f;
   n->atom_pos = qn->atom_pos;
   n->nodepos = nodepos;
-  n->word_key = qn->term_id;
+  /* same key = same word; words missing from the dictionary are different words (the reference keys by the word itself) */
+  n->word_key = qn->term_id >= 0 ? qn->term_id : -(1 + qn->atom_pos); /* (query positions are unique per keyword occurrence) */
   n->boost = qn->boost;
   n->rowid = ORC_INVALID_ROWID;
 }
@@ -1655,7 +1656,8 @@ static enode* build_node(build_ctx* bc, int ni) {
       if (thr != 1 && thr < k) { /* a real ExtQuorum_c: children stay in query-position order (QuorumNodeAtomPos_fn) */
         for (int i = 0; i < k; i++)
           for (int j = i + 1; j < k; j++)
-            if (q->nodes[q->children[qn->first_child + i]].term_id == q->nodes[q->children[qn->first_child + j]].term_id) {
+            if (q->nodes[q->children[qn->first_child + i]].term_id >= 0 &&
+                q->nodes[q->children[qn->first_child + i]].term_id == q->nodes[q->children[qn->first_child + j]].term_id) {
               bc->error = 1;
               fail("ExtQuorum_c with duplicate keywords (m_bHasDupes) not restated in the oracle");
               for (int t = 0; t < k; t++) en_free(terms[t]);

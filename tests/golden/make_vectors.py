@@ -64,6 +64,10 @@ G = {
         "test_052": {"source": "test/test_052/test.xml (index test: rows 1..5) + model.bin", "min_word_len": 1, "ids": [1, 2, 3, 4, 5],
                      "docs": [["aaa bbb", "ccc ddd"], ["xxx", "ccc ddd eee fff ggg"], ["yyy", "one one one two three"],
                               ["zzz", "one two three one three one two four one two three four"], ["", "a b c d e f g"]]},
+        "test_054": {"source": "test/test_054/test.xml (index test: rows 1, 2) + model.bin", "min_word_len": 1, "ids": [1, 2],
+                     "docs": [["hello world"], ["one two three four five"]]},
+        "test_157": {"source": "test/test_157/test.xml (RT inserts) + model.bin", "min_word_len": 1, "ids": [1, 2, 3],
+                     "docs": [["this is cool place"], ["cool place is like no other"], ["place is cool becouse there is no things like this"]]},
         # test_055 (position anchors): rows 10..19 are doubled six times by INSERT .. SELECT document_id+N
         "test_055": {"source": "test/test_055/test.xml + model.bin", "min_word_len": 1,
                      "ids": [1, 2, 3, 4, 9] + list(range(10, 650)) + [2000, 1000, 1001],
@@ -175,6 +179,39 @@ G["cases"] += [  # test_052: the BEFORE operator '<<' (ExtOrder_c, searchnode.cp
         ("\"zzz aaa\"/1 << bbb", OP("before", OP("quorum", T("zzz", 1), T("aaa", 2), opt=1), T("bbb", 4)), [[1, 1568]]),
         ("\"zzz aaa\"/1 << ddd", OP("before", OP("quorum", T("zzz", 1), T("aaa", 2), opt=1), T("ddd", 4)), []),
     ]
+]
+SIX = [T(w, i + 1) for i, w in enumerate(("five", "tree", "oak", "one", "two", "hive"))]
+G["cases"] += [  # test_054 (quorum): the queries without repeated or wildcard words.  Percent thresholds are resolved by the
+    # parser: '/0.4' of 6 words = floor(0.4 * 6 + 0.5) = 2; '/0.59' is stored as 58 % (float to int) = floor(3.48 + 0.5) = 3;
+    # '/0.60' = floor(3.6 + 0.5) = 4 (ExtQuorum_c::GetThreshold, searchnode.cpp:4598-4601)
+    {"name": "054 \"hello heaven\"/1", "corpus": "test_054", "query": OP("quorum", T("hello", 1), T("heaven", 2), opt=1),
+     "ranker": "proximity_bm25", "expect": [[1, 1571]], "total_found": 1},
+    {"name": "054 \"hello from above\"/2", "corpus": "test_054", "query": OP("quorum", T("hello", 1), T("from", 2), T("above", 3), opt=2),
+     "ranker": "proximity_bm25", "expect": [], "total_found": 0},
+    {"name": "054 \"one two foo bar\"/3", "corpus": "test_054",
+     "query": OP("quorum", T("one", 1), T("two", 2), T("foo", 3), T("bar", 4), opt=3), "ranker": "proximity_bm25", "expect": [], "total_found": 0},
+    {"name": "054 \"five tree oak one two hive\"/0.4", "corpus": "test_054", "query": OP("quorum", *SIX, opt=2),
+     "ranker": "proximity_bm25", "expect": [[2, 2571]], "total_found": 1},
+    # the same node under BM25, for the device (its hit rankers take <= 4 keywords): 1000 x the field weight + the 571 of
+    # the reference's 2571 -- the tfidf sum over six query words, three of them not in the dictionary
+    {"name": "054 \"five tree oak one two hive\"/0.4 (bm25)", "corpus": "test_054", "query": OP("quorum", *SIX, opt=2),
+     "ranker": "bm25", "expect": [[2, 1571]], "total_found": 1},
+    {"name": "054 \"five tree oak one two hive\"/0.59", "corpus": "test_054", "query": OP("quorum", *SIX, opt=3),
+     "ranker": "proximity_bm25", "expect": [[2, 2571]], "total_found": 1},
+    {"name": "054 \"five tree oak one two hive\"/0.60", "corpus": "test_054", "query": OP("quorum", *SIX, opt=4),
+     "ranker": "proximity_bm25", "expect": [], "total_found": 0},
+]
+G["cases"] += [  # test_157: a real ExtQuorum_c (5 words, threshold 3).  model.bin lists the matching rows only ("expect_ids");
+    # the second spelling of each case asks for BM25 -- the matching set does not depend on the ranker -- so that the device,
+    # whose hit rankers take <= 4 keywords, runs the node too
+    {"name": "157 \"is cool place\"/3", "corpus": "test_157", "query": OP("quorum", T("is", 1), T("cool", 2), T("place", 3), opt=3),
+     "ranker": "proximity_bm25", "expect_ids": [1, 2, 3], "total_found": 3},
+    {"name": "157 \"there things is cool place\"/3", "corpus": "test_157",
+     "query": OP("quorum", T("there", 1), T("things", 2), T("is", 3), T("cool", 4), T("place", 5), opt=3),
+     "ranker": "proximity_bm25", "expect_ids": [1, 2, 3], "total_found": 3},
+    {"name": "157 \"there things is cool place\"/3 (bm25)", "corpus": "test_157",
+     "query": OP("quorum", T("there", 1), T("things", 2), T("is", 3), T("cool", 4), T("place", 5), opt=3),
+     "ranker": "bm25", "expect_ids": [1, 2, 3], "total_found": 3},
 ]
 G["cases"] += [  # test_055: '^' and '$' (ExtTermPos_T, searchnode.cpp:2259-2405)
     {"name": "055 ^one two", "corpus": "test_055", "query": OP("and", T("one", 1, tp="start"), T("two", 2)),

@@ -206,7 +206,10 @@ def test_reference_vectors(orc, case):
     idx, v = mini_index(orc, corpus["docs"], min_word_len=corpus["min_word_len"])
     got, r = run(orc, idx, _golden_tree(orc, v, case["query"]), getattr(orc, "RANK_" + case["ranker"].upper()), corpus["ids"],
                  **({"field_weights": case["field_weights"]} if "field_weights" in case else {}))
-    assert got[:case.get("limit", len(got))] == [tuple(x) for x in case["expect"]]
+    if "expect_ids" in case:  # the reference's test lists the matching rows only
+        assert sorted(i for i, _ in got) == sorted(case["expect_ids"])
+    else:
+        assert got[:case.get("limit", len(got))] == [tuple(x) for x in case["expect"]]
     if "total_found" in case:
         assert r.total_found == case["total_found"]
 
