@@ -298,7 +298,8 @@ static void cover_of(const PlanTree& T, int ni, IntVec& out) {
     IntVec k;
     for (int i = 0; i < T.q_n; ++i) k.push_back(T.q_kw0 + i);
     std::stable_sort(k.begin(), k.end(), [&](int a, int b) { return T.kws[a].docs < T.kws[b].docs; });
-    for (int i = 0; i < T.q_n - T.q_thr + 1; ++i) out.push_back(k[i]);
+    for (int i = 0; i < T.q_n - T.q_thr + 1; ++i)
+      if (T.kws[k[i]].docs > 0) out.push_back(k[i]); // a keyword without postings drives nothing
     return;
   }
   if (n.op == PN_TERM) {
