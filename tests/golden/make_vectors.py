@@ -66,6 +66,15 @@ G = {
                               ["zzz", "one two three one three one two four one two three four"], ["", "a b c d e f g"]]},
         "test_054": {"source": "test/test_054/test.xml (index test: rows 1, 2) + model.bin", "min_word_len": 1, "ids": [1, 2],
                      "docs": [["hello world"], ["one two three four five"]]},
+        # test_205 (idf=plain, local_df): four plain indexes over one table, searched one by one / as "l1,l2" with global statistics
+        "test_205_i1": {"source": "test/test_205/test.xml (gid=1) + model.bin", "min_word_len": 1, "ids": [1, 2, 3],
+                        "docs": [["da one"], ["da two"], ["da three"]]},
+        "test_205_i2": {"source": "test/test_205/test.xml (gid=2) + model.bin", "min_word_len": 1, "ids": [11, 12, 13, 14, 15],
+                        "docs": [["da blow"], ["da pills"], ["da yak"], ["da herb"], ["da blow"]]},
+        "test_205_l1": {"source": "test/test_205/test.xml (gid=3) + model.bin", "min_word_len": 1, "ids": [100, 101, 102, 103, 104],
+                        "docs": [["da blow"], ["da win"], ["da yak"], ["da herb"], ["da blow"]]},
+        "test_205_l2": {"source": "test/test_205/test.xml (gid=4) + model.bin", "min_word_len": 1, "ids": [200, 201, 202, 203, 204],
+                        "docs": [["da white"], ["da win"], ["da win"], ["da win"], ["da blow"]]},
         "test_157": {"source": "test/test_157/test.xml (RT inserts) + model.bin", "min_word_len": 1, "ids": [1, 2, 3],
                      "docs": [["this is cool place"], ["cool place is like no other"], ["place is cool becouse there is no things like this"]]},
         # test_055 (position anchors): rows 10..19 are doubled six times by INSERT .. SELECT document_id+N
@@ -179,6 +188,26 @@ G["cases"] += [  # test_052: the BEFORE operator '<<' (ExtOrder_c, searchnode.cp
         ("\"zzz aaa\"/1 << bbb", OP("before", OP("quorum", T("zzz", 1), T("aaa", 2), opt=1), T("bbb", 4)), [[1, 1568]]),
         ("\"zzz aaa\"/1 << ddd", OP("before", OP("quorum", T("zzz", 1), T("aaa", 2), opt=1), T("ddd", 4)), []),
     ]
+]
+DA_WIN = OP("and", T("da", 1), T("win", 2))
+LDF = {"total_docs": 10, "local_docs": {"da": 10, "win": 4, "blow": 3}}  # local_df=1 over l1 + l2 (SetupLocalDF, searchd.cpp:5869-5990)
+G["cases"] += [  # test_205: each index ranks with its own statistics unless local_df hands it the global ones; idf=plain
+    {"name": "205 i1 da", "corpus": "test_205_i1", "query": T("da", 1), "ranker": "proximity_bm25", "expect": [[1, 1319], [2, 1319], [3, 1319]]},
+    {"name": "205 i2 da", "corpus": "test_205_i2", "query": T("da", 1), "ranker": "proximity_bm25", "expect": [[i, 1295] for i in range(11, 16)]},
+    {"name": "205 i1 da idf=plain", "corpus": "test_205_i1", "query": T("da", 1), "ranker": "proximity_bm25", "plain_idf": True,
+     "expect": [[1, 1500], [2, 1500], [3, 1500]]},
+    {"name": "205 i2 da idf=plain", "corpus": "test_205_i2", "query": T("da", 1), "ranker": "proximity_bm25", "plain_idf": True,
+     "expect": [[i, 1500] for i in range(11, 16)]},
+    {"name": "205 l1 da win", "corpus": "test_205_l1", "query": DA_WIN, "ranker": "proximity_bm25", "expect": [[101, 2500]]},
+    {"name": "205 l2 da win", "corpus": "test_205_l2", "query": DA_WIN, "ranker": "proximity_bm25", "expect": [[201, 2397], [202, 2397], [203, 2397]]},
+    dict({"name": "205 l1 da win local_df", "corpus": "test_205_l1", "query": DA_WIN, "ranker": "proximity_bm25", "expect": [[101, 2417]]}, **LDF),
+    dict({"name": "205 l2 da win local_df", "corpus": "test_205_l2", "query": DA_WIN, "ranker": "proximity_bm25",
+          "expect": [[201, 2417], [202, 2417], [203, 2417]]}, **LDF),
+    {"name": "205 l1 blow", "corpus": "test_205_l1", "query": T("blow", 1), "ranker": "proximity_bm25", "expect": [[100, 1587], [104, 1587]]},
+    {"name": "205 l2 blow", "corpus": "test_205_l2", "query": T("blow", 1), "ranker": "proximity_bm25", "expect": [[204, 1704]]},
+    dict({"name": "205 l1 blow local_df", "corpus": "test_205_l1", "query": T("blow", 1), "ranker": "proximity_bm25",
+          "expect": [[100, 1592], [104, 1592]]}, **LDF),
+    dict({"name": "205 l2 blow local_df", "corpus": "test_205_l2", "query": T("blow", 1), "ranker": "proximity_bm25", "expect": [[204, 1592]]}, **LDF),
 ]
 SIX = [T(w, i + 1) for i, w in enumerate(("five", "tree", "oak", "one", "two", "hive"))]
 G["cases"] += [  # test_054 (quorum): the queries without repeated or wildcard words.  Percent thresholds are resolved by the

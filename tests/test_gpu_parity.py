@@ -751,7 +751,9 @@ def test_golden_vectors_on_device(dev):
         nf = max(len(d) for d in corpus["docs"])
         seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(corpus["docs"]), n_fields=nf))
         cases = [c for c in GOLDEN["cases"] if c["corpus"] == name]
-        qs = [m.Query(tree(v, c["query"]), ranker=rankers[c["ranker"]], field_weights=c.get("field_weights")) for c in cases]
+        qs = [m.Query(tree(v, c["query"]), ranker=rankers[c["ranker"]], field_weights=c.get("field_weights"), plain_idf=bool(c.get("plain_idf")),
+                      total_docs=c.get("total_docs", 0), local_docs={v[w]: n for w, n in c["local_docs"].items() if w in v} if "local_docs" in c else None)
+              for c in cases]
         for c, r in zip(cases, batch.search(seg, qs)):
             if r.status == -2:
                 declined.append(c["name"])

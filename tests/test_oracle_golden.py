@@ -204,8 +204,13 @@ def _golden_tree(orc, v, q):
 def test_reference_vectors(orc, case):
     corpus = GOLDEN["corpora"][case["corpus"]]
     idx, v = mini_index(orc, corpus["docs"], min_word_len=corpus["min_word_len"])
-    got, r = run(orc, idx, _golden_tree(orc, v, case["query"]), getattr(orc, "RANK_" + case["ranker"].upper()), corpus["ids"],
-                 **({"field_weights": case["field_weights"]} if "field_weights" in case else {}))
+    kw = {"field_weights": case["field_weights"]} if "field_weights" in case else {}
+    if case.get("plain_idf"):
+        kw["plain_idf"] = True
+    if "total_docs" in case:  # local_df: the statistics of all the indexes searched together
+        kw["total_docs_override"] = case["total_docs"]
+        kw["local_docs"] = {v[w]: n for w, n in case["local_docs"].items() if w in v}
+    got, r = run(orc, idx, _golden_tree(orc, v, case["query"]), getattr(orc, "RANK_" + case["ranker"].upper()), corpus["ids"], **kw)
     if "expect_ids" in case:  # the reference's test lists the matching rows only
         assert sorted(i for i, _ in got) == sorted(case["expect_ids"])
     else:
