@@ -75,6 +75,11 @@ G = {
                         "docs": [["da blow"], ["da win"], ["da yak"], ["da herb"], ["da blow"]]},
         "test_205_l2": {"source": "test/test_205/test.xml (gid=4) + model.bin", "min_word_len": 1, "ids": [200, 201, 202, 203, 204],
                         "docs": [["da white"], ["da win"], ["da win"], ["da win"], ["da blow"]]},
+        "test_019_fld": {"source": "test/test_019/test.xml (index fld: rows 1000..1010) + model.bin", "min_word_len": 1,
+                         "ids": list(range(1000, 1011)),
+                         "docs": [["spec1", "dummy1"], ["spec1 dummy1", ""], ["", "spec1 dummy1"], ["spec2 dummy2 text2", ""], ["spec2", "dummy2 text2"],
+                                  ["spec3", "dummy3 text3"], ["spec3 dummy3 text3", "spec3"], ["spec4 dummy4", "text4"], ["spec4", "dummy4 text4"],
+                                  ["spec5 of my", "dummy5"], ["spec5", "of my text5"]]},
         "test_157": {"source": "test/test_157/test.xml (RT inserts) + model.bin", "min_word_len": 1, "ids": [1, 2, 3],
                      "docs": [["this is cool place"], ["cool place is like no other"], ["place is cool becouse there is no things like this"]]},
         # test_055 (position anchors): rows 10..19 are doubled six times by INSERT .. SELECT document_id+N
@@ -188,6 +193,23 @@ G["cases"] += [  # test_052: the BEFORE operator '<<' (ExtOrder_c, searchnode.cp
         ("\"zzz aaa\"/1 << bbb", OP("before", OP("quorum", T("zzz", 1), T("aaa", 2), opt=1), T("bbb", 4)), [[1, 1568]]),
         ("\"zzz aaa\"/1 << ddd", OP("before", OP("quorum", T("zzz", 1), T("aaa", 2), opt=1), T("ddd", 4)), []),
     ]
+]
+TI, BO = 0b01, 0b10  # field masks of index fld: title, body
+G["cases"] += [  # test_019, index fld: the FIELDMASK ranker (weights = matched-fields masks) and field limits inside brackets
+    # (model.bin lists the rows only for those: "expect_ids")
+    {"name": "019 fld spec1 | dummy1 fieldmask", "corpus": "test_019_fld", "query": OP("or", T("spec1", 1), T("dummy1", 2)), "ranker": "fieldmask",
+     "expect_ids": [1000, 1001, 1002], "expect_weights": {"1000": 3, "1001": 1, "1002": 2}, "total_found": 3},
+    {"name": "019 fld @title spec1 @body dummy1", "corpus": "test_019_fld", "query": OP("and", T("spec1", 1, TI), T("dummy1", 2, BO)),
+     "ranker": "proximity_bm25", "expect_ids": [1000], "total_found": 1},
+    {"name": "019 fld @title ( ( spec2 ) (dummy2) | text2 )", "corpus": "test_019_fld",
+     "query": OP("and", T("spec2", 1, TI), OP("or", T("dummy2", 2, TI), T("text2", 3, TI))), "ranker": "proximity_bm25", "expect_ids": [1003], "total_found": 1},
+    {"name": "019 fld @title ( ( spec3 ) @body (dummy3) | text3 )", "corpus": "test_019_fld",
+     "query": OP("and", T("spec3", 1, TI), OP("or", T("dummy3", 2, BO), T("text3", 3, BO))), "ranker": "proximity_bm25", "expect_ids": [1005], "total_found": 1},
+    {"name": "019 fld @title ( ( spec4 ) (dummy4) | @body text4 )", "corpus": "test_019_fld",
+     "query": OP("and", T("spec4", 1, TI), OP("or", T("dummy4", 2, TI), T("text4", 3, BO))), "ranker": "proximity_bm25", "expect_ids": [1007, 1008],
+     "total_found": 2},
+    {"name": "019 fld @title ( ( spec4 ) (dummy4) @body text4 )", "corpus": "test_019_fld",
+     "query": OP("and", T("spec4", 1, TI), T("dummy4", 2, TI), T("text4", 3, BO)), "ranker": "proximity_bm25", "expect_ids": [1007], "total_found": 1},
 ]
 DA_WIN = OP("and", T("da", 1), T("win", 2))
 LDF = {"total_docs": 10, "local_docs": {"da": 10, "win": 4, "blow": 3}}  # local_df=1 over l1 + l2 (SetupLocalDF, searchd.cpp:5869-5990)

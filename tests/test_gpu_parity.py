@@ -733,7 +733,7 @@ def test_golden_vectors_on_device(dev):
     from test_oracle_golden import GOLDEN
     m, ctx, batch = dev
     rankers = {"proximity_bm25": m.SPH_RANK_PROXIMITY_BM25, "bm25": m.SPH_RANK_BM25, "none": m.SPH_RANK_NONE,
-               "wordcount": m.SPH_RANK_WORDCOUNT, "sph04": m.SPH_RANK_SPH04}
+               "wordcount": m.SPH_RANK_WORDCOUNT, "sph04": m.SPH_RANK_SPH04, "fieldmask": m.SPH_RANK_FIELDMASK}
     ops = {"and": m.SPH_QUERY_AND, "or": m.SPH_QUERY_OR, "andnot": m.SPH_QUERY_ANDNOT, "phrase": m.SPH_QUERY_PHRASE,
            "proximity": m.SPH_QUERY_PROXIMITY, "quorum": m.SPH_QUERY_QUORUM, "before": m.SPH_QUERY_BEFORE}
 
@@ -762,6 +762,8 @@ def test_golden_vectors_on_device(dev):
             got = [(corpus["ids"][i], int(w)) for i, w in zip(r.rowid, r.weight)]
             if "expect_ids" in c:
                 assert sorted(i for i, _ in got) == sorted(c["expect_ids"]), c["name"]
+                if "expect_weights" in c:
+                    assert {str(i): w for i, w in got} == c["expect_weights"], c["name"]
             else:
                 assert got[:c.get("limit", len(got))] == [tuple(x) for x in c["expect"]], c["name"]
             if "total_found" in c:

@@ -213,6 +213,8 @@ def test_reference_vectors(orc, case):
     got, r = run(orc, idx, _golden_tree(orc, v, case["query"]), getattr(orc, "RANK_" + case["ranker"].upper()), corpus["ids"], **kw)
     if "expect_ids" in case:  # the reference's test lists the matching rows only
         assert sorted(i for i, _ in got) == sorted(case["expect_ids"])
+        if "expect_weights" in case:  # rows listed in id order with their weights
+            assert {str(i): w for i, w in got} == case["expect_weights"]
     else:
         assert got[:case.get("limit", len(got))] == [tuple(x) for x in case["expect"]]
     if "total_found" in case:
