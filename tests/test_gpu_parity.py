@@ -813,8 +813,9 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
             shape = (rng.choice(["and", "or", "andnot", "maybe", "phrase", "mixed", "proximity", "quorum", "phrase_in_tree", "before",
                                  "before_in_tree", "real_quorum"])
                      if (packed and k > 1) else "and")
-            if packed and shape not in ("phrase", "proximity", "quorum", "phrase_in_tree", "real_quorum") and rng.random() < 0.3:
-                for i in range(k):  # position modifiers: '^word', 'word$', '^word$', '@field[N] word'
+            if packed and shape not in ("phrase", "proximity", "quorum", "real_quorum") and rng.random() < 0.3:
+                for i in range(2 if shape == "phrase_in_tree" else 0, k):  # position modifiers ('^word', 'word$', '^word$',
+                    # '@field[N] word') -- not on the words of a phrase
                     tp = int(rng.integers(0, 8))
                     if tp < 4:
                         kws[i] = m.XQNode.keyword(ts[i], i + 1, masks[i], field_start=tp in (0, 2), field_end=tp in (1, 2),
