@@ -102,7 +102,7 @@ def open_index(path_prefix: str) -> HostIndex:
     check(L.mrk_host_index_info(h, C.byref(info)))
     hi = _take_host_index(h, int(info.total_docs), int(info.skiplist_block_size), int(info.hit_format), int(info.n_fields))
     hi.info = {k: int(getattr(info, k)) for k, _ in _lib.IndexInfo._fields_}
-    hi.fields = [L.mrk_host_index_field_name(h, i).decode() for i in range(info.n_fields)]
+    hi.fields = [L.mrk_host_index_field_name(h, i).decode("utf-8", "surrogateescape") for i in range(info.n_fields)]
     hi.words = []
     if info.word_dict:
         n = C.c_uint32()
@@ -113,7 +113,7 @@ def open_index(path_prefix: str) -> HostIndex:
     ai = _lib.AttrInfo()
     for i in range(info.n_attrs):
         check(L.mrk_host_index_attr(h, i, C.byref(ai)))
-        hi.attrs[ai.name.decode()] = (int(ai.type), int(ai.bit_offset), int(ai.bit_count))
+        hi.attrs[ai.name.decode("utf-8", "surrogateescape")] = (int(ai.type), int(ai.bit_offset), int(ai.bit_count))
     stride, arows = C.c_uint32(), C.c_uint64()
     p = L.mrk_host_index_attr_rows(h, C.byref(stride), C.byref(arows))
     hi.attr_rows = None  # the .spa rows for Segment.set_attrs()

@@ -1,0 +1,60 @@
+#!/bin/bash
+# tools/fuzz_index_open.sh [SEED] [ITERATIONS] -- CPU only: builds csrc/mrk_files.cpp alone with ASan + UBSan and feeds
+# mrk_index_open mutated copies of the index fixtures under tests/golden/indexes/ (bytes flipped, files cut, junk inserted).
+# Every open must end in MRK_OK or an error code; the sanitizers abort on anything else.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+W=${TMPDIR:-/tmp}/mrk_fuzz_open
+mkdir -p $W
+cat > $W/stub.cpp <<'CPP'
+#include <stdarg.h>
+#include <stdio.h>
+#include "mrk_hostindex.h"
+static char g_err[1024];
+int mrk_fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); return code; }
+extern "C" void fuzz_free(mrk_host_index* h) { delete h; }
+CPP
+g++ -std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -shared -fPIC -I$ROOT/manticoresearch_amd/csrc \
+    $ROOT/manticoresearch_amd/csrc/mrk_files.cpp $W/stub.cpp -o $W/libfiles_asan.so
+LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
+    python3 - "$ROOT" "$W" "${1:-1}" "${2:-4000}" <<'PY'
+import ctypes as C, os, random, sys
+root, w, seed, n_iter = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+L = C.CDLL(w + "/libfiles_asan.so")
+L.mrk_index_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+L.mrk_host_index_find_word.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+L.mrk_host_index_word.restype = C.c_void_p
+L.mrk_host_index_word.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+L.fuzz_free.argtypes = [C.c_void_p]
+random.seed(seed)
+src = root + "/tests/golden/indexes/"
+names = ["t233_reload", "t250_plain2", "t406_index0", "t233_test"]
+ok = err = 0
+for _ in range(n_iter):
+    name = random.choice(names)
+    for e in ("sph", "spi", "spd", "spp", "spe", "spm", "spa"):
+        data = bytearray(open(src + name + "." + e, "rb").read())
+        if random.random() < 0.6:
+            for _ in range(random.randint(1, 5)):
+                if not data:
+                    break
+                k, r = random.randrange(len(data)), random.random()
+                if r < 0.5:
+                    data[k] = random.choice([0, 1, 0x7F, 0x80, 0xFF, random.randrange(256)])
+                elif r < 0.75:
+                    del data[k:]
+                else:
+                    data[k:k] = bytes(random.randrange(256) for _ in range(random.randint(1, 8)))
+        open(w + "/x." + e, "wb").write(bytes(data))
+    h = C.c_void_p()
+    if L.mrk_index_open((w + "/x").encode(), C.byref(h)) == 0:
+        ok += 1
+        L.mrk_host_index_find_word(h, b"index", 5)
+        n = C.c_uint32()
+        for t in range(8):
+            L.mrk_host_index_word(h, t, C.byref(n))
+        L.fuzz_free(h)
+    else:
+        err += 1
+print("opened", ok, "rejected", err, "-- no sanitizer report")
+PY
