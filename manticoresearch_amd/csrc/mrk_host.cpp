@@ -419,7 +419,7 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
         // dense terms also get a bitmap of their doc set (the two-bitmap AND kernel, mrk_scan_bm.hip)
         const bool dense = ctx->bitmap_inv > 0 && d->total_docs > 0 && d->total_docs < (1ull << 32) &&
                            (uint64_t)d->dict[t].docs * (uint64_t)ctx->bitmap_inv >= d->total_docs;
-        if (!pack_term(d->spd, d->spd_len, d->dict[t], inl, dense ? d->total_docs : 0, pt[t], errs[t])) bad = true;
+        if (!pack_term(d->spd, d->spd_len, d->dict[t], inl, dense ? d->total_docs : 0, pt[t], errs[t], d->total_docs, d->spp ? d->spp_len : 0)) bad = true;
       }
     };
     std::vector<std::thread> th;
@@ -427,6 +427,12 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
     work();
     for (auto& x : th) x.join();
     if (bad) {
+      for (uint32_t t = 0; t < d->n_terms; ++t)
+        if (errs[t].compare(0, 8, "corrupt:") == 0) { // malformed bytes: nothing of this segment may reach a kernel
+          const int rc = mrk_fail(MRK_E_FORMAT, "mrk_segment_create: term %u: %s", t, errs[t].c_str() + 9);
+          mrk_segment_destroy(s);
+          return rc;
+        }
       // e.g. field masks wider than 8 bits: this segment is served by the VLB path only
       packed = false;
       for (uint32_t t = 0; t < d->n_terms; ++t)

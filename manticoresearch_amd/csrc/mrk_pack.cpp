@@ -40,11 +40,11 @@ struct Rd {
 } // namespace
 
 bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, uint64_t bitmap_rows,
-               PackedTerm& out, std::string& err) {
+               PackedTerm& out, std::string& err, uint64_t total_rows, uint64_t spp_len) {
   out = PackedTerm();
   if (!e.docs) return true;
   if (e.doclist_off == 0 || e.doclist_off + e.doclist_len > spd_len) {
-    err = "doclist outside .spd";
+    err = "corrupt: doclist outside .spd";
     return false;
   }
   Rd rd{spd + e.doclist_off, spd + e.doclist_off + e.doclist_len};
@@ -80,13 +80,17 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
     for (uint32_t i = 0; i < n; ++i) {
       const uint32_t delta = (uint32_t)rd.vlb();
       if (!rd.ok || delta == 0) {
-        err = "doclist shorter than the dictionary's doc count";
+        err = "corrupt: doclist shorter than the dictionary's doc count";
         return false;
       }
       const uint32_t prev = rowid;
       rowid += delta;
       if (prev != 0xFFFFFFFFu && rowid <= prev) {
-        err = "rowids do not ascend";
+        err = "corrupt: rowids do not ascend";
+        return false;
+      }
+      if (total_rows && rowid >= total_rows) { // the dead-row map, the attribute rows and the bitmaps are sized by the row count
+        err = "corrupt: rowid beyond the segment's row count";
         return false;
       }
       uint32_t hits, fields;
@@ -107,6 +111,10 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
             return false;
           }
           hitref[i] = (uint32_t)(hit_position - hb);
+          if (spp_len && hit_position >= spp_len) {
+            err = "corrupt: hitlist offset past .spp";
+            return false;
+          }
         }
       } else {
         hit_position += rd.vlb();
@@ -116,11 +124,15 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
           return false;
         }
         hitref[i] = (uint32_t)(hit_position - hb);
+        if (spp_len && hit_position >= spp_len) {
+          err = "corrupt: hitlist offset past .spp";
+          return false;
+        }
         fields = (uint32_t)rd.vlb();
         hits = (uint32_t)rd.vlb();
       }
       if (!rd.ok) {
-        err = "truncated doclist entry";
+        err = "corrupt: truncated doclist entry";
         return false;
       }
       if (fields > 0xFFu) {
@@ -174,7 +186,7 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
     }
   }
   if (rd.vlb() != 0 || !rd.ok) {
-    err = "doclist longer than the dictionary's doc count";
+    err = "corrupt: doclist longer than the dictionary's doc count";
     return false;
   }
   out.packed_bytes = out.delta.size() * 4 + out.attr.size() * 4 + (uint64_t)nblk * 9;

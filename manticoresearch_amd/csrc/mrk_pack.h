@@ -35,9 +35,11 @@ struct PackedTerm {
 constexpr uint32_t BM_WINDOW = 2048; // rowids per bitmap window (64 lanes x 32 bits)
 constexpr uint32_t BM_GROUP = 256;   // rowids per rank-directory entry
 
-// returns false and sets err on malformed input
+// returns false and sets err on input it cannot pack; err starts with "corrupt:" when the bytes are malformed (truncated
+// entries, descending rowids, rowids >= total_rows, hitlist offsets >= spp_len; the last two only when the limit is
+// given) -- as opposed to well-formed input beyond the packed format (field masks wider than 8 bits)
 // bitmap_rows: 0 = no bitmap; else the segment's row count (every rowid of the term must be below it)
 bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, uint64_t bitmap_rows,
-               PackedTerm& out, std::string& err);
+               PackedTerm& out, std::string& err, uint64_t total_rows = 0, uint64_t spp_len = 0);
 
 } // namespace mrk

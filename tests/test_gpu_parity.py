@@ -1240,3 +1240,32 @@ def test_attribute_filters(orc, dev):
         assert batch.search(seg, [m.Query(kw(m, 0, 1), filters=[F(64, 32, min=1, max=2)] * 3)])[0].status == -2
     finally:
         seg.close()
+
+
+# ------------------------------------------------------------------ malformed postings never reach a kernel
+def test_corrupt_postings_are_rejected_at_load(dev):
+    """Segment creation walks every doclist once (the load-time transcode): rowids beyond the row count, hitlist offsets
+    past .spp, truncated or descending entries fail mrk_segment_create instead of becoming out-of-bounds device reads."""
+    m, ctx, batch = dev
+    if ctx_path(ctx) != 0:
+        pytest.skip("the walk happens in the packed-format transcode")
+    hi = m.synth_index(5000, [0.4, 0.1], seed=3, n_fields=2, max_pos=20)
+    good = m.Segment(ctx, hi)
+    good.close()
+
+    def broken(total_docs=None, spd=None, spp_cut=None):
+        h = m.HostIndex(hi.spd if spd is None else spd, hi.spp if spp_cut is None else hi.spp[:spp_cut], hi.spe, hi.dict.copy(),
+                        hi.total_docs if total_docs is None else total_docs, hi.skiplist_block_size, hi.hit_format, hi.n_fields)
+        with pytest.raises(m.MrkError):
+            m.Segment(ctx, h)
+
+    broken(total_docs=100)  # rowids >= the row count
+    broken(spp_cut=16)      # hitlist offsets past the (cut) .spp
+    spd = hi.spd.copy()
+    off = int(hi.dict[0]["doclist_off"])
+    spd[off + 40: off + 44] = 0x80  # a run of continuation bytes: deltas explode / entries no longer parse
+    broken(spd=spd)
+    d = hi.dict.copy()
+    d[0]["docs"] += 5  # the dictionary promises more docs than the doclist holds
+    with pytest.raises(m.MrkError):
+        m.Segment(ctx, m.HostIndex(hi.spd, hi.spp, hi.spe, d, hi.total_docs, hi.skiplist_block_size, hi.hit_format, hi.n_fields))
