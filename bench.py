@@ -8,9 +8,13 @@ selective x selective thirds.  A "step" = one pass over the whole query set: one
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--docs D] [--queries Q]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the corpus is split into N
-rowid-range shards (strong scaling: total docs fixed), every rank scans its shard, partial
-top-K lists are all-gathered over RCCL and merged on device, total_found is all-reduced.
+N > 1, one rank per GPU: the corpus is split into N rowid-range shards (strong scaling: total docs
+fixed; `--scaling weak` keeps --docs per GPU instead), every rank scans its shard, partial top-K
+lists are all-gathered over RCCL and merged on device, totals are added up.  Launched either by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in the
+environment) or plainly as `python bench.py --gpus N`: with no launcher environment the parent
+process starts the N ranks itself -- as child processes, before anything touches the GPU -- and
+prints rank 0's JSON line; it exits non-zero if any rank fails or fewer than N ranks joined.
 """
 from __future__ import annotations
 
@@ -90,12 +94,18 @@ def main() -> None:
     ap.add_argument("--path", type=int, default=0, help="0 = packed doclists (default), 1 = VLB-direct")
     ap.add_argument("--attr-nibbles", action="store_true", help="build the one-byte tf/field plane (ctx key attr_nibbles)")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra 3-term AND/OR mix leg (BASELINE config 3)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = --docs in total, split N ways (default); weak = --docs per GPU (BASELINE config 4: 8 x 100 M)")
     args = ap.parse_args()
 
+    # (MRK_FORCE_DIST=1 with --gpus 1 rehearses the same parent -> ranks -> JSON relay with ONE rank: the only multi-rank
+    # path a one-GPU box can run)
+    if (args.gpus > 1 or os.environ.get("MRK_FORCE_DIST")) and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(max(1, args.gpus)))  # no torch, no HIP in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and world > 1:
+    if world != max(1, args.gpus):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     # MRK_FORCE_DIST=1 runs the sharded code path (RCCL exchange + device merge) even with one rank
@@ -105,8 +115,12 @@ def main() -> None:
         import torch
         import torch.distributed as dist
 
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: local GPU {local_rank} of {torch.cuda.device_count()} visible")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", timeout=__import__("datetime").timedelta(seconds=900))
+        if dist.get_world_size() != world:
+            raise SystemExit(f"rank {rank}: {dist.get_world_size()} ranks joined, {world} expected")
 
     import manticoresearch_amd as m
     from manticoresearch_amd import dist as mdist
@@ -115,8 +129,11 @@ def main() -> None:
     c = zipf_c()
     ranks, strata = make_queries(c, args.queries)
     probs = [min(0.5, c / r) for r in ranks]
-    shard_docs = args.docs // world
-    hi = m.synth_index(shard_docs, probs, seed=CORPUS_SEED, shard=rank, skiplist_block_size=args.skiplist_block)
+    # rowid-range shards of ONE corpus (postings are keyed on the global rowid): rank r holds rows [row0, row0 + shard_docs)
+    corpus_docs = args.docs * world if args.scaling == "weak" else args.docs
+    row0 = rank * corpus_docs // world
+    shard_docs = (rank + 1) * corpus_docs // world - row0
+    hi = m.synth_index(shard_docs, probs, seed=CORPUS_SEED, rowid_base=row0, skiplist_block_size=args.skiplist_block)
     t_gen = time.time() - t_setup
 
     ctx = m.Context(local_rank)
@@ -125,7 +142,7 @@ def main() -> None:
     ctx.set("path", args.path)
     if args.attr_nibbles:
         ctx.set("attr_nibbles", 1)
-    seg = m.Segment(ctx, hi, rowid_base=rank * shard_docs)
+    seg = m.Segment(ctx, hi, rowid_base=row0)
     batch = m.Batch(ctx, args.queries)
     sharded = world > 1 or force_dist
     state = {"i": 0, "pending": [], "rec": [False] * 8}
@@ -199,7 +216,7 @@ def main() -> None:
             # sharded: submit -> (event) -> all-gather -> merge -> host copy is ONE stream-ordered chain queued right
             # here; the host only waits when a set comes round again, n_sets steps later
             t_w = time.perf_counter()
-            merger.wait(idx)
+            merger.finish(idx)  # merged rows in host memory; reruns / re-exchanges if a shard flagged a row
             if used[idx]:
                 sets[idx]["all"].wait()
                 if state["rec"][idx]:
@@ -228,7 +245,7 @@ def main() -> None:
             collect(*state["pending"].pop(0))
         if merger is not None:
             for i in range(n_sets):
-                merger.wait(i)
+                merger.finish(i)
                 if used[i]:
                     sets[i]["all"].wait()
                     if state["rec"][i]:
@@ -331,15 +348,15 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u8 postings -> u32 rowids, f32 BM25, i32 weights",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.docs // 1_000_000}M docs (Zipf s=1, V=2^20, {AVG_TERMS_PER_DOC:.0f} terms/doc), 2-term AND, "
+            "workload": f"{corpus_docs // 1_000_000}M docs (Zipf s=1, V=2^20, {AVG_TERMS_PER_DOC:.0f} terms/doc), 2-term AND, "
                         f"SPH_RANK_BM25, top-{K}, {3 * nq} queries/step in 3 strata (cc/sc/ss), "
                         f"skiplist_block_size={args.skiplist_block}, inline hits",
-            "docs": args.docs,
+            "docs": corpus_docs,
             "shards": world,
             "queries_per_step": 3 * nq,
             "k": K,
@@ -424,6 +441,54 @@ def main() -> None:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as CHILD processes (env rendezvous
+    on 127.0.0.1), relay rank 0's JSON line, return non-zero if a rank failed or the line does not report N ranks.
+    Runs before torch or HIP are imported; nothing is exec'ed over a process that touched the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.2)
+    if failed is None:
+        failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:  # one rank down: the others would sit in the rendezvous / a collective until it times out
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        sys.stderr.write(f"bench.py: rank {failed} exited with {procs[failed].returncode}; {n}-rank run aborted\n")
+        return 1
+    reader.join(timeout=10)
+    line = next((ln for ln in reversed(out0) if ln.lstrip().startswith("{")), None)
+    if line is None:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    if json.loads(line).get("n_gpus") != n:
+        sys.stderr.write(f"bench.py: the run reports {json.loads(line).get('n_gpus')} ranks, {n} expected\n")
+        return 1
+    sys.stdout.write(line if line.endswith("\n") else line + "\n")
+    sys.stdout.flush()
+    return 0
 
 
 def cpu_baseline(hi, strata, total_docs, K, budget_s: float) -> dict:

@@ -195,6 +195,12 @@ void mrk_ctx_destroy(mrk_ctx* ctx);
 int mrk_ctx_set(mrk_ctx* ctx, const char* key, int64_t value);
 
 int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* desc, mrk_segment** out);
+/* The host-only half of mrk_segment_create, no device needed: the descriptor's limits, every skiplist, and a walk of
+   every doclist (entries decode, rowids ascend and stay below total_docs, hitlist offsets stay inside .spp, the
+   terminator sits where the dictionary's doc count says).  MRK_OK, or the error mrk_segment_create would return --
+   it runs the same checks on whatever the load-time transcode did not already walk, so that untrusted bytes never
+   become an out-of-bounds device read. */
+int mrk_segment_validate(const mrk_segment_desc* desc);
 void mrk_segment_destroy(mrk_segment* seg);
 /* Dead-row map of the segment (DeadRowMap_c, killlist.h:22-46: bit rowid&31 of DWORD rowid>>5), copied
    to the device; dead rows are dropped right after ranking, before the sorter, and do not count as found
@@ -231,13 +237,19 @@ int mrk_batch_export_device(mrk_batch* b, uint64_t* keys_dst, uint32_t* counts_d
    (device) into out_rows[n_queries][MRK_ROW_WORDS]: best k keys per query, totals added up
    (CSphMatchQueue::MoveTo, sphinxsort.cpp:681-710). */
 #define MRK_ROW_WORDS (MRK_MAX_K + 2)
+/* flag bits in a row's total_found word; mrk_topk_merge_rows ORs them through (the counts in the low 62 bits add up):
+   MRK_ROW_RERUN    a shard's candidate list overflowed and the row left before mrk_batch_wait reran the query: call
+                    mrk_batch_wait + mrk_batch_export_rows on that shard's batch and exchange / merge again;
+   MRK_ROW_DECLINED a shard declined the query (MRK_E_UNSUPPORTED there): the merged row is not an answer. */
+#define MRK_ROW_RERUN (1ull << 63)
+#define MRK_ROW_DECLINED (1ull << 62)
 int mrk_batch_export_rows(mrk_batch* b, uint64_t* rows_dst);
 /* standing order: every later submit also writes its rows to rows_dst (device, [max_queries][MRK_ROW_WORDS]) on the
    batch's own stream right behind the selection kernel -- valid after mrk_batch_wait, no device work at collection
    time.  NULL cancels it. */
 int mrk_batch_set_rows_dst(mrk_batch* b, uint64_t* rows_dst);
 /* (A query whose candidate list overflowed is rerun by mrk_batch_wait; a row that left through the standing export
-   before that carries no keys and bit 63 of total_found, which survives the merge's sum: ask that shard again.) */
+   before that carries no keys and MRK_ROW_RERUN: ask that shard again, see above.) */
 /* record a caller-owned hipEvent_t on the batch's stream, i.e. behind everything the last submit queued there
    (selection, standing rows export, result copies): lets another stream (RCCL's) wait for the rows without the host */
 int mrk_batch_record_event(mrk_batch* b, void* hip_event);
@@ -277,7 +289,8 @@ int mrk_index_from_hits(const uint64_t* wordid, const uint32_t* rowid, const uin
 typedef struct {
   uint64_t seed;
   uint64_t n_docs;          /* docs in this segment (rowids 0..n_docs-1) */
-  uint32_t shard;           /* mixed into the seed so shards are independent */
+  uint64_t rowid_base;      /* global rowid of the segment's rowid 0: postings are a function of (seed, term, global rowid),
+                               so shards [base, base + n_docs) are slices of the one corpus */
   const double* term_prob;  /* document probability of each generated term */
   uint32_t n_terms;
   uint32_t n_fields;        /* hits fall into field 0 with prob title_frac, else uniformly in 1..n_fields-1 */

@@ -83,7 +83,7 @@ class AttrInfo(C.Structure):
 
 
 class SynthParams(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("n_docs", C.c_uint64), ("shard", C.c_uint32), ("term_prob", C.POINTER(C.c_double)),
+    _fields_ = [("seed", C.c_uint64), ("n_docs", C.c_uint64), ("rowid_base", C.c_uint64), ("term_prob", C.POINTER(C.c_double)),
                 ("n_terms", C.c_uint32), ("n_fields", C.c_uint32), ("title_frac", C.c_double), ("max_pos", C.c_uint32),
                 ("skiplist_block_size", C.c_uint32), ("hit_format", C.c_uint32), ("end_markers", C.c_uint32),
                 ("n_threads", C.c_uint32)]
@@ -96,6 +96,7 @@ SYMBOLS = [
     ("mrk_ctx_destroy", None, [C.c_void_p]),
     ("mrk_ctx_set", C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("mrk_segment_create", C.c_int, [C.c_void_p, C.POINTER(SegmentDesc), C.POINTER(C.c_void_p)]),
+    ("mrk_segment_validate", C.c_int, [C.POINTER(SegmentDesc)]),
     ("mrk_segment_destroy", None, [C.c_void_p]),
     ("mrk_segment_device_bytes", C.c_uint64, [C.c_void_p]),
     ("mrk_batch_export_rows", C.c_int, [C.c_void_p, C.c_void_p]),

@@ -150,10 +150,17 @@ def index_from_hits(wordid: np.ndarray, rowid: np.ndarray, hitpos: np.ndarray, n
 
 def synth_index(n_docs: int, term_prob: Sequence[float], seed: int = 0x5EED0001, shard: int = 0, n_fields: int = 2,
                 title_frac: float = 0.1, max_pos: int = 1024, skiplist_block_size: int = 128,
-                hit_format: int = SPH_HIT_FORMAT_INLINE, end_markers: bool = False, n_threads: int = 0) -> HostIndex:
-    """Deterministic synthetic postings for the given per-term document probabilities."""
+                hit_format: int = SPH_HIT_FORMAT_INLINE, end_markers: bool = False, n_threads: int = 0,
+                rowid_base: Optional[int] = None) -> HostIndex:
+    """Deterministic synthetic postings for the given per-term document probabilities.
+
+    Postings are a function of (seed, term, GLOBAL rowid): the segment holds the rows [rowid_base, rowid_base + n_docs)
+    of the one corpus the seed defines (`shard` is shorthand for rowid_base = shard * n_docs), so equal-sized shards
+    laid end to end ARE the unsharded corpus."""
     probs = (C.c_double * len(term_prob))(*[float(x) for x in term_prob])
-    p = _lib.SynthParams(seed, n_docs, shard, probs, len(term_prob), n_fields, title_frac, max_pos,
+    if rowid_base is None:
+        rowid_base = shard * n_docs
+    p = _lib.SynthParams(seed, n_docs, rowid_base, probs, len(term_prob), n_fields, title_frac, max_pos,
                          skiplist_block_size, hit_format, int(end_markers), n_threads)
     h = C.c_void_p()
     check(lib().mrk_synth_generate(C.byref(p), C.byref(h)))
@@ -331,20 +338,31 @@ class Context:
             pass
 
 
+def _segment_desc(hi: HostIndex, rowid_base: int = 0) -> "_lib.SegmentDesc":
+    d = _lib.SegmentDesc()
+    d.spd, d.spd_len = hi.spd.ctypes.data, hi.spd.size
+    d.spp, d.spp_len = hi.spp.ctypes.data, hi.spp.size
+    d.spe, d.spe_len = hi.spe.ctypes.data, hi.spe.size
+    d.dict, d.n_terms = hi.dict.ctypes.data, len(hi.dict)
+    d.total_docs = hi.total_docs
+    d.skiplist_block_size, d.hit_format, d.n_fields = hi.skiplist_block_size, hi.hit_format, hi.n_fields
+    d.rowid_base = rowid_base
+    return d
+
+
+def validate_index(hi: HostIndex) -> None:
+    """The host-only half of Segment(): limits, skiplists and a walk of every doclist (mrk_segment_validate); raises
+    MrkError on bytes that must not reach a kernel.  Needs no GPU."""
+    check(lib().mrk_segment_validate(C.byref(_segment_desc(hi))))
+
+
 class Segment:
     """A HostIndex made resident in HBM (+ the device block index built from its skiplists)."""
 
     def __init__(self, ctx: Context, hi: HostIndex, rowid_base: int = 0):
         self.ctx = ctx
         self.host = hi
-        d = _lib.SegmentDesc()
-        d.spd, d.spd_len = hi.spd.ctypes.data, hi.spd.size
-        d.spp, d.spp_len = hi.spp.ctypes.data, hi.spp.size
-        d.spe, d.spe_len = hi.spe.ctypes.data, hi.spe.size
-        d.dict, d.n_terms = hi.dict.ctypes.data, len(hi.dict)
-        d.total_docs = hi.total_docs
-        d.skiplist_block_size, d.hit_format, d.n_fields = hi.skiplist_block_size, hi.hit_format, hi.n_fields
-        d.rowid_base = rowid_base
+        d = _segment_desc(hi, rowid_base)
         self._h = C.c_void_p()
         check(lib().mrk_segment_create(ctx._h, C.byref(d), C.byref(self._h)))
 
@@ -459,4 +477,4 @@ __all__ = ["SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RAN
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
            "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE",
            "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Filter", "Matches", "Context",
-           "Segment", "Batch", "prepare", "idf", "MrkError"]
+           "Segment", "Batch", "prepare", "idf", "MrkError", "validate_index"]

@@ -224,6 +224,7 @@ struct MergeArgs {
   uint64_t* out_rows;
 };
 constexpr int ROW_WORDS = MRK_ROW_WORDS;
+constexpr uint64_t ROW_RERUN = MRK_ROW_RERUN, ROW_DECLINED = MRK_ROW_DECLINED, ROW_FLAG_MASK = MRK_ROW_RERUN | MRK_ROW_DECLINED;
 
 struct PackRowsArgs {
   const uint64_t* keys;   // [n][KCAP]
@@ -231,6 +232,7 @@ struct PackRowsArgs {
   const uint64_t* total;  // [n]
   uint64_t* rows;         // [n][ROW_WORDS]
   const uint32_t* flags;  // [n] QF_* of the scan (NULL = none): a flagged query's row is poisoned, not trusted
+  const uint32_t* declined; // [n] != 0: the planner declined the query on this segment (NULL = none declined)
   uint32_t n;
 };
 void launch_pack_rows(const PackRowsArgs& a, void* stream);

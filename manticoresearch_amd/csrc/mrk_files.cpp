@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -128,17 +129,18 @@ struct Reader {
   }
 };
 
-void schema_column(Reader& r, uint32_t version, mrk_host_index::Attr* out = nullptr) { // ReadSchemaColumn
+bool schema_column(Reader& r, uint32_t version, mrk_host_index::Attr* out = nullptr) { // ReadSchemaColumn; -> payload flag
   std::string name = r.str();
   const uint32_t type = r.dword();
   r.dword(); // rowitem (ignored by the reference too)
   const int32_t bit_offset = (int32_t)r.dword(), bit_count = (int32_t)r.dword();
-  r.byte();                     // payload
+  const bool payload = r.byte() != 0;
   if (version >= 61) r.dword(); // attr flags
   if (out) {
     for (char& c : name) c = (char)tolower((unsigned char)c);
     *out = mrk_host_index::Attr{name.empty() ? "@emptyname" : name, type, bit_offset, bit_count};
   }
+  return payload;
 }
 
 int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_index* h, uint64_t& cp_offset) {
@@ -155,12 +157,12 @@ int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_ind
     if (I.version >= 57) { // ReadSchemaField
       h->fields.push_back(r.str());
       r.dword(); // field flags
-      r.byte();  // payload
+      if (r.byte()) h->payload_fields |= i < 64 ? 1ull << i : 1ull << 63; // payload
     } else {
       const size_t at = r.at;
       std::string nm = r.str();
       r.at = at;
-      schema_column(r, I.version);
+      if (schema_column(r, I.version)) h->payload_fields |= i < 64 ? 1ull << i : 1ull << 63;
       h->fields.push_back(nm);
     }
   }
@@ -258,6 +260,11 @@ int parse_dict(const std::vector<uint8_t>& spi, const char* name, uint64_t cp_of
   const mrk_index_info& I = h->info;
   if (I.n_checkpoints == 0) return MRK_OK; // empty index
   if (cp_offset == 0 || cp_offset >= spi.size()) return mrk_fail(MRK_E_FORMAT, "%s: checkpoints offset past the file", name);
+  // a checkpoint takes >= 13 bytes (dword length + >= 1 keyword byte + qword offset) / exactly 16 (dict=crc): bound the
+  // header's count by the bytes that are there BEFORE allocating from it
+  if ((uint64_t)I.n_checkpoints > (spi.size() - cp_offset) / (I.word_dict ? 13u : 16u))
+    return mrk_fail(MRK_E_FORMAT, "%s: %u checkpoints cannot fit the %zu bytes behind offset %llu", name, I.n_checkpoints,
+                    spi.size() - (size_t)cp_offset, (unsigned long long)cp_offset);
   Reader cp(spi.data(), spi.size());
   cp.at = (size_t)cp_offset;
   std::vector<uint64_t> blocks(I.n_checkpoints);
@@ -323,12 +330,31 @@ int parse_dict(const std::vector<uint8_t>& spi, const char* name, uint64_t cp_of
 
 } // namespace
 
+static int index_open(const char* path_prefix, mrk_host_index* h);
+
 extern "C" int mrk_index_open(const char* path_prefix, mrk_host_index** out) {
   if (!path_prefix || !out) return mrk_fail(MRK_E_INVAL, "mrk_index_open: null argument");
   *out = nullptr;
-  const std::string base(path_prefix);
   mrk_host_index* h = new (std::nothrow) mrk_host_index();
   if (!h) return mrk_fail(MRK_E_NOMEM, "out of memory");
+  int rc;
+  try { // the C-ABI never throws: sizes come from untrusted files
+    rc = index_open(path_prefix, h);
+  } catch (const std::bad_alloc&) {
+    rc = mrk_fail(MRK_E_NOMEM, "%s: out of memory reading the index", path_prefix);
+  } catch (const std::exception& e) {
+    rc = mrk_fail(MRK_E_FORMAT, "%s: %s", path_prefix, e.what());
+  }
+  if (rc != MRK_OK) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return MRK_OK;
+}
+
+static int index_open(const char* path_prefix, mrk_host_index* h) {
+  const std::string base(path_prefix);
   h->from_files = true;
   std::vector<uint8_t> sph, spi, spm;
   std::vector<uint64_t> wordids;
@@ -337,6 +363,9 @@ extern "C" int mrk_index_open(const char* path_prefix, mrk_host_index** out) {
   if (!read_file(base + ".sph", sph) || !read_file(base + ".spi", spi)) rc = MRK_E_FORMAT;
   if (rc == MRK_OK) rc = parse_header(sph, (base + ".sph").c_str(), h, cp_offset);
   if (rc == MRK_OK && h->info.hitless != 0) rc = mrk_fail(MRK_E_UNSUPPORTED, "%s: hitless index (hitless_words) is not on the device path", path_prefix);
+  // a payload field switches SPH_RANK_PROXIMITY_BM25 to RankerState_ProximityPayload_fn (sphinxsearch.cpp:4175-4199), which
+  // the device path does not restate: such an index is declined rather than ranked differently
+  if (rc == MRK_OK && h->payload_fields) rc = mrk_fail(MRK_E_UNSUPPORTED, "%s: payload fields are not on the device path", path_prefix);
   if (rc == MRK_OK) rc = parse_dict(spi, (base + ".spi").c_str(), cp_offset, h, wordids);
   if (rc == MRK_OK && (!read_postings(base + ".spd", h->spd, h->spd_len) || !read_postings(base + ".spp", h->spp, h->spp_len) ||
                        !read_postings(base + ".spe", h->spe, h->spe_len)))
@@ -373,21 +402,20 @@ extern "C" int mrk_index_open(const char* path_prefix, mrk_host_index** out) {
     h->attr_stride = (bits + 31) / 32;
     std::vector<uint8_t> spa;
     if (h->attr_stride && h->docinfo_rows && read_file(base + ".spa", spa, true)) {
-      const uint64_t need = h->docinfo_rows * h->attr_stride * 4ull;
-      if (spa.size() < need)
+      // by division: docinfo_rows is a raw header qword, the product may wrap
+      if (h->docinfo_rows > spa.size() / ((uint64_t)h->attr_stride * 4ull))
         rc = mrk_fail(MRK_E_FORMAT, "%s.spa: %zu bytes for %llu rows of %u dwords", path_prefix, spa.size(), (unsigned long long)h->docinfo_rows, h->attr_stride);
+      else if (h->docinfo_rows < h->info.total_docs)
+        rc = mrk_fail(MRK_E_FORMAT, "%s.sph: %llu attribute rows for %llu documents", path_prefix, (unsigned long long)h->docinfo_rows,
+                      (unsigned long long)h->info.total_docs);
       else {
+        const uint64_t need = h->docinfo_rows * h->attr_stride * 4ull;
         h->attr_rows.resize((size_t)(need / 4));
         memcpy(h->attr_rows.data(), spa.data(), (size_t)need);
       }
     }
   }
-  if (rc != MRK_OK) {
-    delete h;
-    return rc;
-  }
-  *out = h;
-  return MRK_OK;
+  return rc;
 }
 
 extern "C" int mrk_host_index_info(const mrk_host_index* h, mrk_index_info* out) {

@@ -138,6 +138,11 @@ struct mrk_batch {
   PinBuf<uint32_t> h_cand_n;
   DevBuf<uint64_t> d_cand;
   PinBuf<uint32_t> h_flags;
+  // per query: != 0 when the planner declined it on the last submit's segment; travels in the exchange rows
+  PinBuf<uint32_t> h_decl;
+  DevBuf<uint32_t> d_decl;
+  bool decl_dirty = false; // d_decl holds non-zero words of an earlier submit
+  bool any_declined = false;
   // decoded results
   std::vector<uint32_t> rowid;
   std::vector<int32_t> weight;
@@ -315,8 +320,8 @@ static int upload(void** dptr, const void* src, size_t bytes, size_t pad, hipStr
   return MRK_OK;
 }
 
-extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_segment** out) {
-  if (!ctx || !d || !out) return mrk_fail(MRK_E_INVAL, "mrk_segment_create: NULL argument");
+// argument checks of a segment descriptor that need no device
+static int check_desc(const mrk_segment_desc* d) {
   if (!d->spd || !d->spd_len) return mrk_fail(MRK_E_INVAL, "mrk_segment_create: empty .spd");
   const uint32_t sb = d->skiplist_block_size;
   if (sb == 0 || (sb & (sb - 1)) || sb > (uint32_t)DEVBLK)
@@ -324,36 +329,30 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
   if (d->n_fields > 32) return mrk_fail(MRK_E_UNSUPPORTED, "%u fields: device path covers <= 32", d->n_fields);
   if (d->hit_format != MRK_HITFMT_INLINE && d->hit_format != MRK_HITFMT_PLAIN)
     return mrk_fail(MRK_E_INVAL, "bad hit_format %u", d->hit_format);
-  HIP_TRY(hipSetDevice(ctx->device));
+  if (d->n_terms && !d->dict) return mrk_fail(MRK_E_INVAL, "mrk_segment_create: %u terms but no dictionary table", d->n_terms);
+  return MRK_OK;
+}
 
-  mrk_segment* s = new (std::nothrow) mrk_segment();
-  if (!s) return mrk_fail(MRK_E_NOMEM, "out of memory");
-  s->ctx = ctx;
-  s->total_docs = d->total_docs;
-  s->n_fields = d->n_fields;
-  s->terms.resize(d->n_terms);
-
-  // device block index: every (DEVBLK / skiplist_block_size)-th SkiplistEntry_t, rebuilt the way
-  // DiskIndexQwordSetup_c::Setup does per query (sphinx.cpp:13056-13073) -- once, at load time.
-  // The writer emits ceil(docs/block) snapshots (sphinx.cpp:8447-8453), all of which are used.
+// device block index: every (DEVBLK / skiplist_block_size)-th SkiplistEntry_t, rebuilt the way
+// DiskIndexQwordSetup_c::Setup does per query (sphinx.cpp:13056-13073) -- once, at load time.
+// The writer emits ceil(docs/block) snapshots (sphinx.cpp:8447-8453), all of which are used.
+static int build_block_index(const mrk_segment_desc* d, std::vector<HostTerm>& terms, std::vector<uint32_t>& blk_base,
+                             std::vector<uint64_t>& blk_off, std::vector<uint64_t>& blk_hit) {
+  const uint32_t sb = d->skiplist_block_size;
   const uint32_t step = (uint32_t)DEVBLK / sb;
-  std::vector<uint32_t> blk_base;
-  std::vector<uint64_t> blk_off, blk_hit;
+  terms.resize(d->n_terms);
   for (uint32_t t = 0; t < d->n_terms; ++t) {
     const mrk_dict_entry& e = d->dict[t];
-    HostTerm& h = s->terms[t];
+    HostTerm& h = terms[t];
     h.docs = e.docs;
     h.hits = e.hits;
     h.doclist_off = e.doclist_off;
     h.doclist_len = e.doclist_len;
     h.blk_first = (uint32_t)blk_base.size();
     if (!e.docs) continue;
-    if (e.doclist_off == 0 || e.doclist_off + e.doclist_len > d->spd_len) {
-      delete s;
+    if (e.doclist_off == 0 || e.doclist_off > d->spd_len || e.doclist_len > d->spd_len - e.doclist_off)
       return mrk_fail(MRK_E_FORMAT, "term %u: doclist [%llu,+%llu) outside .spd (%llu bytes)", t,
-                      (unsigned long long)e.doclist_off, (unsigned long long)e.doclist_len,
-                      (unsigned long long)d->spd_len);
-    }
+                      (unsigned long long)e.doclist_off, (unsigned long long)e.doclist_len, (unsigned long long)d->spd_len);
     h.nblocks = (e.docs + DEVBLK - 1) / DEVBLK;
     uint32_t base = 0;
     uint64_t off = e.doclist_off, hit = 0;
@@ -362,10 +361,8 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
     blk_hit.push_back(hit);
     if (e.docs > sb) {
       const uint32_t n_snap = (e.docs + sb - 1) / sb; // entry 0 is implicit
-      if (!d->spe || e.skiplist_off == 0 || e.skiplist_off >= d->spe_len) {
-        delete s;
+      if (!d->spe || e.skiplist_off == 0 || e.skiplist_off >= d->spe_len)
         return mrk_fail(MRK_E_FORMAT, "term %u: skiplist offset %llu outside .spe", t, (unsigned long long)e.skiplist_off);
-      }
       const uint8_t* p = d->spe + e.skiplist_off;
       const uint8_t* end = d->spe + d->spe_len;
       bool ok = true;
@@ -373,25 +370,89 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
         base += sb + (uint32_t)unzip64(p, end, ok);
         off += 4ull * sb + unzip64(p, end, ok);
         hit += unzip64(p, end, ok);
-        if (!ok) {
-          delete s;
-          return mrk_fail(MRK_E_FORMAT, "term %u: truncated skiplist", t);
-        }
+        if (!ok) return mrk_fail(MRK_E_FORMAT, "term %u: truncated skiplist", t);
         if (i % step == 0) {
-          if (off >= e.doclist_off + e.doclist_len) {
-            delete s;
-            return mrk_fail(MRK_E_FORMAT, "term %u: skiplist entry %u points outside the doclist", t, i);
-          }
+          if (off >= e.doclist_off + e.doclist_len) return mrk_fail(MRK_E_FORMAT, "term %u: skiplist entry %u points outside the doclist", t, i);
           blk_base.push_back(base);
           blk_off.push_back(off);
           blk_hit.push_back(hit);
         }
       }
     }
-    if (blk_base.size() - h.blk_first != h.nblocks) {
+    if (blk_base.size() - h.blk_first != h.nblocks)
+      return mrk_fail(MRK_E_FORMAT, "term %u: %u docs need %u blocks, skiplist gave %zu", t, e.docs, h.nblocks, blk_base.size() - h.blk_first);
+  }
+  return MRK_OK;
+}
+
+// validate-only walk (mrk_pack.cpp) of the doclists in `which` (empty = all), in parallel; MRK_E_FORMAT on the first bad one
+static int validate_doclists(const mrk_segment_desc* d, const std::vector<uint32_t>& which) {
+  const size_t n = which.empty() ? d->n_terms : which.size();
+  if (!n) return MRK_OK;
+  std::atomic<size_t> next{0};
+  std::atomic<int64_t> bad_term{-1};
+  std::vector<std::string> errs(n);
+  unsigned nth = (unsigned)std::min<size_t>(std::max(1u, std::min(64u, std::thread::hardware_concurrency())), n);
+  auto work = [&] {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n || bad_term.load() >= 0) break;
+      const uint32_t t = which.empty() ? (uint32_t)i : which[i];
+      if (!validate_term(d->spd, d->spd_len, d->dict[t], d->hit_format == MRK_HITFMT_INLINE, d->total_docs, d->spp ? d->spp_len : 0, errs[i])) {
+        int64_t none = -1;
+        bad_term.compare_exchange_strong(none, (int64_t)i);
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned i = 1; i < nth; ++i) th.emplace_back(work);
+  work();
+  for (auto& x : th) x.join();
+  const int64_t bi = bad_term.load();
+  if (bi >= 0) {
+    const std::string& e = errs[(size_t)bi];
+    return mrk_fail(MRK_E_FORMAT, "mrk_segment_create: term %u: %s", which.empty() ? (uint32_t)bi : which[(size_t)bi],
+                    e.compare(0, 9, "corrupt: ") == 0 ? e.c_str() + 9 : e.c_str());
+  }
+  return MRK_OK;
+}
+
+extern "C" int mrk_segment_validate(const mrk_segment_desc* d) {
+  if (!d) return mrk_fail(MRK_E_INVAL, "mrk_segment_validate: NULL argument");
+  int rc = check_desc(d);
+  if (rc != MRK_OK) return rc;
+  try {
+    std::vector<HostTerm> terms;
+    std::vector<uint32_t> blk_base;
+    std::vector<uint64_t> blk_off, blk_hit;
+    if ((rc = build_block_index(d, terms, blk_base, blk_off, blk_hit)) != MRK_OK) return rc;
+    return validate_doclists(d, {});
+  } catch (const std::bad_alloc&) {
+    return mrk_fail(MRK_E_NOMEM, "mrk_segment_validate: out of memory");
+  }
+}
+
+extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_segment** out) {
+  if (!ctx || !d || !out) return mrk_fail(MRK_E_INVAL, "mrk_segment_create: NULL argument");
+  {
+    const int rc0 = check_desc(d);
+    if (rc0 != MRK_OK) return rc0;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+
+  mrk_segment* s = new (std::nothrow) mrk_segment();
+  if (!s) return mrk_fail(MRK_E_NOMEM, "out of memory");
+  s->ctx = ctx;
+  s->total_docs = d->total_docs;
+  s->n_fields = d->n_fields;
+
+  std::vector<uint32_t> blk_base;
+  std::vector<uint64_t> blk_off, blk_hit;
+  {
+    const int rc0 = build_block_index(d, s->terms, blk_base, blk_off, blk_hit);
+    if (rc0 != MRK_OK) {
       delete s;
-      return mrk_fail(MRK_E_FORMAT, "term %u: %u docs need %u blocks, skiplist gave %zu", t, e.docs, h.nblocks,
-                      blk_base.size() - h.blk_first);
+      return rc0;
     }
   }
 
@@ -404,6 +465,13 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
   std::vector<uint8_t> pk_attr1;
   bool attr1_ok = ctx->attr_nibbles && d->n_fields <= 4;
   bool packed = ctx->pack && d->n_fields <= 8;
+  if (!packed) { // no transcode, no walk by pack_term: validate every doclist before any of it reaches the VLB kernel
+    const int rcv = validate_doclists(d, {});
+    if (rcv != MRK_OK) {
+      mrk_segment_destroy(s);
+      return rcv;
+    }
+  }
   if (packed) {
     std::vector<PackedTerm> pt(d->n_terms);
     std::vector<std::string> errs(d->n_terms);
@@ -433,8 +501,18 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
           mrk_segment_destroy(s);
           return rc;
         }
-      // e.g. field masks wider than 8 bits: this segment is served by the VLB path only
+      // e.g. field masks wider than 8 bits: this segment is served by the VLB path only.  pack_term stopped at the
+      // decline: the rest of such a doclist is still unchecked -- walk it (a bad rowid behind a wide mask must not
+      // reach scan_kernel's dead-row / attribute reads)
       packed = false;
+      std::vector<uint32_t> rest;
+      for (uint32_t t = 0; t < d->n_terms; ++t)
+        if (!errs[t].empty()) rest.push_back(t);
+      const int rcv = validate_doclists(d, rest);
+      if (rcv != MRK_OK) {
+        mrk_segment_destroy(s);
+        return rcv;
+      }
       for (uint32_t t = 0; t < d->n_terms; ++t)
         if (!errs[t].empty()) {
           fprintf(stderr, "mrk: segment stays on the VLB path: term %u: %s\n", t, errs[t].c_str());
@@ -600,6 +678,8 @@ extern "C" void mrk_batch_destroy(mrk_batch* b) {
   b->h_cand_n.release();
   b->d_cand.release();
   b->h_flags.release();
+  b->h_decl.release();
+  b->d_decl.release();
   if (b->retry) mrk_batch_destroy(b->retry);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
@@ -622,7 +702,7 @@ extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** 
       (rc = b->h_total.reserve(nq)) || (rc = b->d_queries.reserve(nq)) ||
       (rc = b->d_state.reserve(nq * (8 + 8 + 4 + 4 + 4 + (size_t)NBINS * 4))) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
       (rc = b->d_kq.reserve(nq)) || (rc = b->d_out_keys.reserve(nq * KCAP)) || (rc = b->d_out_cnt.reserve(nq)) ||
-      (rc = b->h_flags.reserve(nq)) || (rc = b->h_cand_n.reserve(nq))) {
+      (rc = b->h_flags.reserve(nq)) || (rc = b->h_cand_n.reserve(nq)) || (rc = b->h_decl.reserve(nq)) || (rc = b->d_decl.reserve(nq))) {
     mrk_batch_destroy(b);
     return rc;
   }
@@ -800,6 +880,16 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   } else
     launch_merge(ma, st2);
   HIP_TRY(hipEventRecord(b->ev_merge1, st2));
+  {
+    bool any = false;
+    for (uint32_t i = 0; i < n; ++i) any = any || b->status[i] != MRK_OK;
+    b->any_declined = any;
+    if (any || b->decl_dirty) {
+      for (uint32_t i = 0; i < n; ++i) b->h_decl.p[i] = b->status[i] != MRK_OK ? 1u : 0u;
+      HIP_TRY(hipMemcpyAsync(b->d_decl.p, b->h_decl.p, n * 4, hipMemcpyHostToDevice, st2));
+    }
+    b->decl_dirty = any;
+  }
   if (b->rows_dst) { // standing export for the shard exchange
     PackRowsArgs pa{};
     pa.keys = b->d_out_keys.p;
@@ -807,6 +897,7 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
     pa.total = b->d_q_total.p;
     pa.rows = b->rows_dst;
     pa.flags = use_packed ? b->d_q_flags.p : nullptr;
+    pa.declined = b->any_declined ? b->d_decl.p : nullptr;
     pa.n = n;
     launch_pack_rows(pa, st2);
   }
@@ -1043,6 +1134,7 @@ extern "C" int mrk_batch_export_rows(mrk_batch* b, uint64_t* rows_dst) {
   pa.total = b->d_q_total.p;
   pa.rows = rows_dst;
   pa.flags = b->packed_run ? b->d_q_flags.p : nullptr;
+  pa.declined = b->any_declined ? b->d_decl.p : nullptr;
   pa.n = b->n_queries;
   launch_pack_rows(pa, b->stream); // behind the batch's selection kernel
   HIP_TRY(hipGetLastError());

@@ -566,10 +566,16 @@ __global__ __launch_bounds__(WG) void merge_kernel(MergeArgs a) {
     uint64_t* __restrict__ row = a.out_rows + (uint64_t)q * ROW_WORDS;
     for (uint32_t i = tid; i < (uint32_t)KCAP; i += WG) row[i] = i < n ? s.cand[i] : 0ull;
     if (tid == 0) {
-      uint64_t total = 0; // CSphMatchQueue::MoveTo adds the totals up (sphinxsort.cpp:681-710)
-      for (uint32_t l = 0; l < nl; ++l) total += a.in_rows[((uint64_t)l * a.n_queries + q) * ROW_WORDS + KCAP + 1];
+      // CSphMatchQueue::MoveTo adds the totals up (sphinxsort.cpp:681-710); the two flag bits of a shard's row
+      // (ROW_RERUN / ROW_DECLINED) are OR-ed through so that the receiver sees them whatever the other shards sent
+      uint64_t total = 0, flags = 0;
+      for (uint32_t l = 0; l < nl; ++l) {
+        const uint64_t t = a.in_rows[((uint64_t)l * a.n_queries + q) * ROW_WORDS + KCAP + 1];
+        total += t & ~ROW_FLAG_MASK;
+        flags |= t & ROW_FLAG_MASK;
+      }
       row[KCAP] = n;
-      row[KCAP + 1] = total;
+      row[KCAP + 1] = (total & ~ROW_FLAG_MASK) | flags;
     }
     return;
   }
@@ -583,13 +589,15 @@ __global__ __launch_bounds__(WG) void pack_rows_kernel(PackRowsArgs a) {
   if (q >= a.n) return;
   uint64_t* __restrict__ row = a.rows + (uint64_t)q * ROW_WORDS;
   // a query whose candidate list overflowed has no trustworthy list on the device until the host reran it: its row goes
-  // out empty with bit 63 of total_found set, which survives the merge's sum and tells the receiver to ask again
-  const bool bad = a.flags && (a.flags[q] & (QF_OVERFLOW | QF_FSM)) != 0;
+  // out empty with ROW_RERUN set in the total_found word; a query this shard declined (MRK_E_UNSUPPORTED) goes out empty
+  // with ROW_DECLINED.  The merge ORs both bits through: the receiver reruns / fails the query, never a partial answer.
+  const bool declined = a.declined && a.declined[q] != 0;
+  const bool bad = declined || (a.flags && (a.flags[q] & (QF_OVERFLOW | QF_FSM)) != 0);
   const uint32_t n = bad ? 0u : a.cnt[q] < (uint32_t)KCAP ? a.cnt[q] : (uint32_t)KCAP;
   for (uint32_t i = threadIdx.x; i < (uint32_t)KCAP; i += WG) row[i] = i < n ? a.keys[(uint64_t)q * KCAP + i] : 0ull;
   if (threadIdx.x == 0) {
     row[KCAP] = n;
-    row[KCAP + 1] = bad ? (1ull << 63) : a.total[q];
+    row[KCAP + 1] = declined ? ROW_DECLINED : bad ? ROW_RERUN : (a.total[q] & ~ROW_FLAG_MASK);
   }
 }
 

@@ -39,11 +39,68 @@ struct Rd {
 };
 } // namespace
 
+// The walk DiskIndexQword_c::GetNextDoc would do over the whole doclist (sphinx.cpp:511-549), checking what a kernel
+// later relies on; independent of whether the doclist can be packed.
+bool validate_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, uint64_t total_rows,
+                   uint64_t spp_len, std::string& err) {
+  if (!e.docs) return true;
+  if (e.doclist_off == 0 || e.doclist_off > spd_len || e.doclist_len > spd_len - e.doclist_off) {
+    err = "corrupt: doclist outside .spd";
+    return false;
+  }
+  Rd rd{spd + e.doclist_off, spd + e.doclist_off + e.doclist_len};
+  uint32_t rowid = 0xFFFFFFFFu;
+  uint64_t hit_position = 0;
+  for (uint32_t i = 0; i < e.docs; ++i) {
+    const uint32_t delta = (uint32_t)rd.vlb();
+    if (!rd.ok || delta == 0) {
+      err = "corrupt: doclist shorter than the dictionary's doc count";
+      return false;
+    }
+    const uint32_t prev = rowid;
+    rowid += delta;
+    if (prev != 0xFFFFFFFFu && rowid <= prev) {
+      err = "corrupt: rowids do not ascend";
+      return false;
+    }
+    if (total_rows && rowid >= total_rows) {
+      err = "corrupt: rowid beyond the segment's row count";
+      return false;
+    }
+    bool has_list = true;
+    if (inline_hits) {
+      const uint32_t hits = (uint32_t)rd.vlb();
+      rd.vlb();
+      if (hits == 1) {
+        rd.vlb();
+        has_list = false;
+      } else
+        hit_position += rd.vlb();
+    } else {
+      hit_position += rd.vlb();
+      rd.vlb(), rd.vlb();
+    }
+    if (!rd.ok) {
+      err = "corrupt: truncated doclist entry";
+      return false;
+    }
+    if (has_list && spp_len && hit_position >= spp_len) {
+      err = "corrupt: hitlist offset past .spp";
+      return false;
+    }
+  }
+  if (rd.vlb() != 0 || !rd.ok) {
+    err = "corrupt: doclist longer than the dictionary's doc count";
+    return false;
+  }
+  return true;
+}
+
 bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, uint64_t bitmap_rows,
                PackedTerm& out, std::string& err, uint64_t total_rows, uint64_t spp_len) {
   out = PackedTerm();
   if (!e.docs) return true;
-  if (e.doclist_off == 0 || e.doclist_off + e.doclist_len > spd_len) {
+  if (e.doclist_off == 0 || e.doclist_off > spd_len || e.doclist_len > spd_len - e.doclist_off) {
     err = "corrupt: doclist outside .spd";
     return false;
   }

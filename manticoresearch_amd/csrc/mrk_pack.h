@@ -42,4 +42,11 @@ constexpr uint32_t BM_GROUP = 256;   // rowids per rank-directory entry
 bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, uint64_t bitmap_rows,
                PackedTerm& out, std::string& err, uint64_t total_rows = 0, uint64_t spp_len = 0);
 
+// Validate-only walk of one term's doclist: every entry decodes, rowids ascend and stay below total_rows, hitlist
+// offsets stay below spp_len, the terminator sits where the dictionary's doc count says.  false + err ("corrupt: ...")
+// otherwise.  mrk_segment_create runs it on every doclist pack_term did not walk to the end (segments with > 8 fields,
+// pack = 0, a packing decline half way): nothing unvalidated reaches a kernel.
+bool validate_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bool inline_hits, uint64_t total_rows,
+                   uint64_t spp_len, std::string& err);
+
 } // namespace mrk

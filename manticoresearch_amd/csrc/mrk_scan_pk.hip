@@ -378,10 +378,10 @@ struct RankState {
         fmask = hp;
         if (f < 8 && (uint32_t)((lcs >> (8 * f)) & 0xffu) < hw) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)(hw & 0xffu) << (8 * f));
       }
-      exact |= 1u << (hq & 31u);
+      exact |= (uint32_t)(1ull << (hq & 63u)); // 1UL << qpos stored into a DWORD: positions 32..63 add no bit
       const int dd = (int)(fmask - min_exp_pos);
       if (dd && dd < 32 && ((exact >> (dd & 31)) & head)) {
-        head = 1u << (hq & 31u);
+        head = (uint32_t)(1ull << (hq & 63u));
         min_exp_pos = fmask;
         cur_lcs = (cur_lcs + hw) & 0xffu;
         exact = 0;

@@ -312,14 +312,21 @@ extern "C" int mrk_index_from_hits(const uint64_t* wordid, const uint32_t* rowid
   return build(words, skiplist_block_size, hit_format, 1, out);
 }
 
-// Synthetic postings, deterministic in (seed, shard, term index): term t occurs in a doc with
-// probability term_prob[t] (gaps are geometric), tf = 1 + min(254, Geometric(1/2)), every hit
-// falls into field 0 with probability title_frac (else one of the other fields) at a uniform
-// position in [1, max_pos]; duplicate positions collapse like the reference writer collapses them.
+// Synthetic postings, deterministic in (seed, term index, GLOBAL rowid): the global rowid space is cut into chunks of
+// SYNTH_CHUNK rowids and every (term, chunk) draws from its own splitmix64 stream (keyed on seed, term
+// and rowid), so a shard [rowid_base, rowid_base + n_docs) holds exactly the postings the unsharded corpus holds for
+// those rows -- "sharded result == unsharded result" is testable.  Inside a chunk term t occurs in a doc with
+// probability term_prob[t] (geometric gaps; restarting them at a chunk border leaves the per-doc Bernoulli law
+// untouched), tf = 1 + min(254, Geometric(1/2)), every hit falls into field 0 with probability title_frac (else one
+// of the other fields) at a uniform position in [1, max_pos]; duplicate positions collapse like the reference writer
+// collapses them.  A chunk the shard covers only partly is drawn whole and the rows outside the shard are dropped.
+constexpr uint64_t SYNTH_CHUNK = 65536;
+
 extern "C" int mrk_synth_generate(const mrk_synth_params* p, mrk_host_index** out) {
   if (!p || !out) return mrk_fail(MRK_E_INVAL, "mrk_synth_generate: NULL argument");
   if (!p->n_terms || !p->term_prob) return mrk_fail(MRK_E_INVAL, "mrk_synth_generate: no terms");
   if (p->n_docs == 0 || p->n_docs > 0xFFFFFFFEull) return mrk_fail(MRK_E_INVAL, "n_docs %llu outside 1..2^32-2", (unsigned long long)p->n_docs);
+  if (p->rowid_base > (1ull << 40)) return mrk_fail(MRK_E_INVAL, "rowid_base %llu too large", (unsigned long long)p->rowid_base);
   if (p->n_fields == 0 || p->n_fields > 32 || p->max_pos == 0 || p->max_pos >= (1u << 23))
     return mrk_fail(MRK_E_INVAL, "mrk_synth_generate: bad n_fields/max_pos");
   for (uint32_t t = 0; t < p->n_terms; ++t)
@@ -327,49 +334,55 @@ extern "C" int mrk_synth_generate(const mrk_synth_params* p, mrk_host_index** ou
   const double tg0 = now_s();
   std::vector<WordPostings> words(p->n_terms);
   const uint64_t title_thr = (uint64_t)(p->title_frac * 18446744073709551615.0);
+  const uint64_t g0 = p->rowid_base, g1 = p->rowid_base + p->n_docs; // the shard's global rowid range
   parallel_for(p->n_terms, p->n_threads, [&](size_t t) {
     WordPostings& w = words[t];
-    uint64_t s = p->seed ^ (0xD1B54A32D192ED03ull * (t + 1)) ^ ((uint64_t)p->shard << 40);
-    splitmix64(s);
     const double pr = p->term_prob[t];
     const double inv_log1mp = pr < 1.0 ? 1.0 / log1p(-pr) : 0.0;
     w.rowid.reserve((size_t)(pr * (double)p->n_docs * 1.05) + 16);
     w.hit_begin.reserve(w.rowid.capacity() + 1);
-    uint64_t row = 0; // next candidate rowid
     uint32_t tmp[256];
-    for (;;) {
-      uint64_t gap = 0;
-      if (pr < 1.0) {
-        const double u = ((splitmix64(s) >> 11) + 1) * (1.0 / 9007199254740992.0); // (0,1]
-        const double g = floor(log(u) * inv_log1mp);
-        gap = g > 4.0e18 ? (uint64_t)4e18 : (uint64_t)g;
+    for (uint64_t chunk = g0 / SYNTH_CHUNK; chunk * SYNTH_CHUNK < g1; ++chunk) {
+      uint64_t s = p->seed ^ (0xD1B54A32D192ED03ull * (t + 1)) ^ (0x9FB21C651E98DF25ull * (chunk + 1));
+      splitmix64(s);
+      const uint64_t cbase = chunk * SYNTH_CHUNK;
+      uint64_t row = 0; // next candidate rowid inside the chunk
+      for (;;) {
+        uint64_t gap = 0;
+        if (pr < 1.0) {
+          const double u = ((splitmix64(s) >> 11) + 1) * (1.0 / 9007199254740992.0); // (0,1]
+          const double g = floor(log(u) * inv_log1mp);
+          gap = g > 4.0e18 ? (uint64_t)4e18 : (uint64_t)g;
+        }
+        row += gap;
+        if (row >= SYNTH_CHUNK || cbase + row >= g1) break;
+        uint64_t r = splitmix64(s);
+        uint32_t tf = 1 + (uint32_t)std::min(254, r ? __builtin_ctzll(r) : 64);
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < tf; ++i) {
+          const uint64_t a = splitmix64(s);
+          uint32_t f = 0;
+          if (p->n_fields > 1 && a >= title_thr) f = 1 + (uint32_t)((a >> 20) % (p->n_fields - 1));
+          const uint32_t pos = 1 + (uint32_t)((a & 0xFFFFF) * (uint64_t)p->max_pos >> 20);
+          tmp[n++] = (f << 24) | pos;
+        }
+        const uint64_t grow = cbase + row;
+        ++row;
+        if (grow < g0) continue; // a row of the chunk's part that belongs to the previous shard
+        if (n > 1) {
+          if (n == 2) {
+            if (tmp[0] > tmp[1]) std::swap(tmp[0], tmp[1]);
+          } else
+            std::sort(tmp, tmp + n);
+          n = (uint32_t)(std::unique(tmp, tmp + n) - tmp);
+        }
+        if (p->end_markers) // mark each field's last hit of this word in this doc
+          for (uint32_t i = 0; i < n; ++i)
+            if (i + 1 == n || (tmp[i + 1] >> 24) != (tmp[i] >> 24)) tmp[i] |= 1u << 23;
+        w.rowid.push_back((uint32_t)(grow - g0));
+        w.hit_begin.push_back((uint32_t)w.hits.size());
+        w.hits.insert(w.hits.end(), tmp, tmp + n);
       }
-      row += gap;
-      if (row >= p->n_docs) break;
-      uint64_t r = splitmix64(s);
-      uint32_t tf = 1 + (uint32_t)std::min(254, r ? __builtin_ctzll(r) : 64);
-      uint32_t n = 0;
-      for (uint32_t i = 0; i < tf; ++i) {
-        const uint64_t a = splitmix64(s);
-        uint32_t f = 0;
-        if (p->n_fields > 1 && a >= title_thr) f = 1 + (uint32_t)((a >> 20) % (p->n_fields - 1));
-        const uint32_t pos = 1 + (uint32_t)((a & 0xFFFFF) * (uint64_t)p->max_pos >> 20);
-        tmp[n++] = (f << 24) | pos;
-      }
-      if (n > 1) {
-        if (n == 2) {
-          if (tmp[0] > tmp[1]) std::swap(tmp[0], tmp[1]);
-        } else
-          std::sort(tmp, tmp + n);
-        n = (uint32_t)(std::unique(tmp, tmp + n) - tmp);
-      }
-      if (p->end_markers) // mark each field's last hit of this word in this doc
-        for (uint32_t i = 0; i < n; ++i)
-          if (i + 1 == n || (tmp[i + 1] >> 24) != (tmp[i] >> 24)) tmp[i] |= 1u << 23;
-      w.rowid.push_back((uint32_t)row);
-      w.hit_begin.push_back((uint32_t)w.hits.size());
-      w.hits.insert(w.hits.end(), tmp, tmp + n);
-      ++row;
     }
     w.hit_begin.push_back((uint32_t)w.hits.size());
   });

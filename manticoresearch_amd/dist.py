@@ -45,6 +45,7 @@ def exchange_partial_topk(keys, counts, totals):
 
 
 ROW_WORDS = MRK_MAX_K + 2  # MRK_ROW_WORDS: keys | count | total_found
+ROW_RERUN, ROW_DECLINED = 1 << 63, 1 << 62  # MRK_ROW_RERUN / MRK_ROW_DECLINED: flag bits of the total_found word
 
 
 def exchange_rows(rows):
@@ -141,13 +142,43 @@ class ShardMerger:
     def wait(self, set_index: int = 0):
         check(lib().mrk_merge_wait(self.ctx._h, set_index))
 
-    def results(self, set_index: int = 0, nq=None):
-        """Decoded (global docid, weight) lists per query + total_found."""
+    def _merged(self, set_index: int):
+        return (self.host_rows[set_index] if self.on_host[set_index] else self.out_rows[set_index].cpu()).numpy().view(np.uint64)
+
+    def finish(self, set_index: int = 0):
+        """wait() + never a silently partial answer: a merged row whose total_found word carries MRK_ROW_RERUN (some
+        shard's candidate list overflowed and its row left before the rerun) makes EVERY rank -- all of them see the
+        same merged rows -- run mrk_batch_wait on its attached batches (the rerun), export the repaired rows, and redo
+        the exchange and the merge; a row with MRK_ROW_DECLINED (a shard declined the query) is left flagged for
+        results() to report.  Returns the merged rows [nq, ROW_WORDS] as uint64."""
         self.wait(set_index)
-        rows = (self.host_rows[set_index] if self.on_host[set_index] else self.out_rows[set_index].cpu()).numpy().view(np.uint64)
+        rows = self._merged(set_index)
+        if not self.attached[set_index] or not (rows[:, MRK_MAX_K + 1] & np.uint64(ROW_RERUN)).any():
+            return rows
+        n = self.per_batch
+        for i, b in enumerate(self.attached[set_index]):
+            check(lib().mrk_batch_wait(b._h))  # reruns this shard's overflowed queries, repairs the device-side lists
+            check(lib().mrk_batch_export_rows(b._h, self.rows[set_index][i * n:].data_ptr()))
+        self.merge_attached(len(self.attached[set_index]), set_index, to_host=self.on_host[set_index])
+        self.wait(set_index)
+        rows = self._merged(set_index)
+        bad = np.flatnonzero(rows[:, MRK_MAX_K + 1] & np.uint64(ROW_RERUN))
+        if bad.size:
+            raise _lib.MrkError(_lib.MRK_E_UNSUPPORTED, f"queries {bad.tolist()[:8]}: a shard's candidate list overflowed again on the rerun")
+        return rows
+
+    def results(self, set_index: int = 0, nq=None, allow_declined: bool = False):
+        """Decoded (global docid, weight) lists per query + total_found.  A query some shard declined raises MrkError
+        (allow_declined=True: its entry is None instead)."""
+        rows = self.finish(set_index)
         out = []
         for q in range(nq if nq is not None else self.nq):
             cnt, tot = int(rows[q, MRK_MAX_K]), int(rows[q, MRK_MAX_K + 1])
+            if tot & ROW_DECLINED:
+                if not allow_declined:
+                    raise _lib.MrkError(_lib.MRK_E_UNSUPPORTED, f"query {q}: declined on a shard (MRK_E_UNSUPPORTED there); no merged answer")
+                out.append(None)
+                continue
             k = rows[q, :cnt]
             weight = ((k >> np.uint64(32)).astype(np.uint32) ^ np.uint32(0x80000000)).view(np.int32)
             docid = ~k.astype(np.uint32)

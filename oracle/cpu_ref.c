@@ -1983,12 +1983,13 @@ static inline void prox_update_dupes(prox_state* s, const hit_t* h) {
     s->cur_pos = pos;
     if (s->lcs[field] < h->weight) s->lcs[field] = (uint8_t)h->weight;
   }
-  s->cur_qpos_mask |= 1u << (h->qpos & 31);
+  /* the reference shifts 1UL (64 bits on LP64) and stores into a DWORD: query positions 32..63 add no bit */
+  s->cur_qpos_mask |= (uint32_t)(1ull << (h->qpos & 63));
   int delta = (int)(s->cur_pos - s->lcs_tail_pos);
   /* (a negative delta -- positions running backwards -- is a negative shift count in the reference, undefined in C++;
      x86 masks the count to 5 bits, and so do we) */
   if (delta && delta < 32 && ((s->cur_qpos_mask >> (delta & 31)) & s->lcs_tail_qpos_mask)) {
-    s->lcs_tail_qpos_mask = 1u << (h->qpos & 31);
+    s->lcs_tail_qpos_mask = (uint32_t)(1ull << (h->qpos & 63));
     s->lcs_tail_pos = s->cur_pos;
     s->cur_lcs = (uint8_t)(s->cur_lcs + h->weight);
     s->cur_qpos_mask = 0;

@@ -76,6 +76,39 @@ def main():
         for bb in batches + [b]:
             bb.close()
         seg.close()
+        # never a silently partial answer (ShardMerger.finish): 1.3 M docs that all match with one weight overflow the
+        # candidate list, the row leaves flagged through the standing export and must come back repaired; a query the
+        # shard declines (max_matches beyond the device top-K) must be reported, not merged as "no matches"
+        n2 = 1_300_000
+        rows = np.arange(n2, dtype=np.uint32)
+        W = np.concatenate([np.full(n2, 1, np.uint64), np.full(n2, 2, np.uint64)])
+        H = np.concatenate([np.full(n2, (1 << 24) | 1, np.uint32), np.full(n2, (1 << 24) | 2, np.uint32)])
+        hi2 = m.index_from_hits(W, np.concatenate([rows, rows]), H, n_terms=2, total_docs=n2, n_fields=2)
+        ctx.set("bitmap_inv", 0)
+        seg2 = m.Segment(ctx, hi2, rowid_base=500)
+        q2 = [m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_BM25, max_matches=1000),
+              m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25, max_matches=20),
+              m.Query(kw(m, 1, 1), ranker=m.SPH_RANK_BM25, max_matches=5000)]
+        b2 = m.Batch(ctx, len(q2))
+        sm2 = mdist.ShardMerger(ctx, b2, len(q2), K, 1, 0)
+        sm2.attach([b2])
+        b2.submit_prepared(seg2, m.prepare(q2), len(q2))
+        sm2.merge_attached(1, set_index=0, to_host=True, after_submit=True)
+        sm2.wait(0)
+        raw = sm2._merged(0)[:, 1025]
+        assert int(raw[0]) >> 63 == 1 and int(raw[1]) >> 63 == 1 and (int(raw[2]) >> 62) & 1 == 1, [hex(int(x)) for x in raw]
+        try:
+            sm2.results(0)
+            raise AssertionError("a declined query must raise")
+        except m.MrkError:
+            pass
+        got2 = sm2.results(0, allow_declined=True)
+        assert got2[2] is None
+        for q in range(2):
+            docid, weight, tot = got2[q]
+            assert tot == n2 and list(docid) == [500 + i for i in range(q2[q].max_matches)] and len(set(weight.tolist())) == 1
+        b2.close()
+        seg2.close()
         ctx.close()
     finally:
         dist.destroy_process_group()

@@ -99,3 +99,11 @@ def test_sharded_exchange_and_merge(orc):
         got = [(-(int(k >> np.uint64(32)) ^ 0x80000000 if (int(k >> np.uint64(32)) ^ 0x80000000) < 2**31 else (int(k >> np.uint64(32)) ^ 0x80000000) - 2**32),
                 (~int(k)) & 0xFFFFFFFF) for k in merged]
         assert got == want[:K]
+        # ... and the merge of the shards' answers IS the answer of the unsharded corpus: the shards are slices of the one
+        # corpus (generator keyed on the global rowid), ranked with its document frequencies
+        if qi == 0:
+            whole = m.synth_index(2 * N_DOCS, PROBS, seed=99, n_threads=1)
+            ow = orc.Index(whole.spd, whole.spp, whole.spe, whole.dict.view(orc.DICT_DTYPE), 2 * N_DOCS, whole.skiplist_block_size, 1, 2)
+            assert [int(x) for x in gdocs] == [int(whole.dict[t]["docs"]) for t in range(3)]
+        r = orc.search(ow, orc.op(orc.OP_AND, orc.term(a, 1), orc.term(b, 2)), ranker=orc.RANK_BM25, max_matches=K)
+        assert r.total_found == tot and [(-int(w), int(rid)) for rid, w in zip(r.rowid, r.weight)] == got

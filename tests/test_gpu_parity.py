@@ -324,8 +324,9 @@ def test_random_corpus_proximity(orc, dev, block, fmt):
         k = int(rng.integers(2, 5))
         ts = rng.choice(len(probs), size=k, replace=bool(rng.random() < 0.25))  # repeated keywords: the HANDLE_DUPES update
         masks = [0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)) for _ in ts]
-        # atom positions as the parser numbers them, sometimes with a gap (stop word)
-        pos, ap = [], 0
+        # atom positions as the parser numbers them, sometimes with a gap (stop word); some queries sit at positions
+        # around 32: the HANDLE_DUPES masks are DWORDs fed by 1UL << qpos (sphinxsearch.cpp:1396, 1403)
+        pos, ap = [], int(rng.choice([0, 0, 0, 0, 29, 31, 45]))
         for _ in ts:
             ap += 1 if rng.random() < 0.85 else 2
             pos.append(ap)
@@ -722,6 +723,68 @@ def test_row_export_and_merge(orc, dev):
         assert [(-int(w), int(d)) for w, d in zip(weight, docid)] == exp
         assert int(host[qi, 1025]) == want[0][qi].total_found + want[1][qi].total_found
         assert not host[qi, cnt:1024].any()
+    for p in (rows_all, out_rows):
+        hip.hipFree(p)
+
+
+def test_sharded_equals_unsharded(orc, dev):
+    """Rowid-range shards are slices of the one corpus (the generator is keyed on the global rowid), document
+    frequencies and N are the corpus-wide ones (local_df), and the cross-shard order is (weight desc, global docid asc)
+    = the unsharded sorter's (weight desc, rowid asc): three uneven shards, exchanged as rows and merged on the device,
+    must equal the unsharded device result bit for bit -- ties at rank K included -- for AND pairs under BM25 / NONE,
+    an OR / ANDNOT tree and a proximity-ranked 3-keyword AND; the unsharded result itself is checked against the oracle
+    (sphinxrt.cpp:6018-6108: chunks searched apart, sphinxrt.cpp:5945-5950: sorters merged)."""
+    import ctypes as C
+    _tree_only(dev)
+    m, ctx, batch = dev
+    from manticoresearch_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+
+    def dmalloc(n):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(n)) == 0
+        return p
+
+    probs = [0.35, 0.2, 0.04, 0.006]
+    n_docs, K, RW = 700_001, 1000, 1026
+    cuts = [0, 131_072, 400_003, n_docs]
+    whole = m.synth_index(n_docs, probs, seed=2026, max_pos=64)
+    shards = [m.synth_index(cuts[i + 1] - cuts[i], probs, seed=2026, max_pos=64, rowid_base=cuts[i]) for i in range(3)]
+    gdocs = {t: int(whole.dict[t]["docs"]) for t in range(4)}
+    assert all(gdocs[t] == sum(int(sh.dict[t]["docs"]) for sh in shards) for t in range(4))
+
+    def mk(root, ranker, k=K):
+        return m.Query(root, ranker=ranker, max_matches=k, total_docs=n_docs, local_docs=dict(gdocs))
+
+    qs = [mk(m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), rk) for a in range(4) for b in range(4) if a < b for rk in (m.SPH_RANK_BM25, m.SPH_RANK_NONE)]
+    qs.append(mk(m.XQNode.AND(OR(m, kw(m, 2, 1), kw(m, 3, 2)), kw(m, 0, 3)), m.SPH_RANK_BM25))
+    qs.append(mk(m.XQNode(m.SPH_QUERY_ANDNOT, [kw(m, 1, 1), kw(m, 0, 2)]), m.SPH_RANK_BM25, 37))
+    qs.append(mk(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2), kw(m, 2, 3)), m.SPH_RANK_PROXIMITY_BM25))
+    nq = len(qs)
+    seg = m.Segment(ctx, whole)
+    want = batch.search(seg, qs)
+    seg.close()
+    oi = orc_index_of(orc, whole)
+    for q, w in zip(qs, want):
+        o = to_orc(orc, q).run(oi)
+        assert w.status == 0 and w.total_found == o.total_found
+        assert np.array_equal(w.rowid, o.rowid) and np.array_equal(w.weight, o.weight)
+    rows_all, out_rows = dmalloc(3 * nq * RW * 8), dmalloc(nq * RW * 8)
+    for s in range(3):
+        seg = m.Segment(ctx, shards[s], rowid_base=cuts[s])
+        batch.submit(seg, qs)
+        batch.wait()
+        _lib.check(_lib.lib().mrk_batch_export_rows(batch._h, C.c_void_p(rows_all.value + s * nq * RW * 8)))
+        seg.close()
+    _lib.check(_lib.lib().mrk_topk_merge_rows(ctx._h, rows_all, 3, nq, 1024, out_rows))
+    host = np.zeros((nq, RW), np.uint64)
+    assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), out_rows, C.c_size_t(host.nbytes), 2) == 0
+    for qi, (q, w) in enumerate(zip(qs, want)):
+        k = host[qi, : min(int(host[qi, 1024]), q.max_matches)]  # the merged list, cut to the query's own K
+        weight = ((k >> np.uint64(32)).astype(np.uint32) ^ np.uint32(0x80000000)).view(np.int32)
+        docid = ~k.astype(np.uint32)
+        assert int(host[qi, 1025]) == w.total_found, qi
+        assert np.array_equal(docid, w.rowid) and np.array_equal(weight, w.weight), qi
     for p in (rows_all, out_rows):
         hip.hipFree(p)
 
@@ -1269,3 +1332,24 @@ def test_corrupt_postings_are_rejected_at_load(dev):
     d[0]["docs"] += 5  # the dictionary promises more docs than the doclist holds
     with pytest.raises(m.MrkError):
         m.Segment(ctx, m.HostIndex(hi.spd, hi.spp, hi.spe, d, hi.total_docs, hi.skiplist_block_size, hi.hit_format, hi.n_fields))
+
+
+def test_bad_postings_behind_a_packing_decline_are_rejected(dev):
+    """The doclists the load-time transcode does not walk to the end (a field mask wider than 8 bits stops it; segments
+    with more than 8 fields or ctx pack = 0 never start it) are walked by the validate-only pass: a rowid beyond the row
+    count or a hitlist offset past .spp behind such an entry fails mrk_segment_create on every path -- nothing of it
+    reaches scan_kernel's dead-row / attribute reads.  Same descriptors as tests/test_validate_cpu.py."""
+    from test_validate_cpu import crafted
+    m, ctx, batch = dev
+    cases = crafted()
+    for pack in (1, 0):
+        ctx.set("pack", pack)
+        try:
+            for name, hi in cases.items():
+                if name.startswith("good"):
+                    m.Segment(ctx, hi).close()
+                else:
+                    with pytest.raises(m.MrkError):
+                        m.Segment(ctx, hi)
+        finally:
+            ctx.set("pack", 1)

@@ -262,3 +262,38 @@ def test_open_errors(tmp_path):
         m.open_index(variant("cutspi", spi=lambda d: d[:30]))
     hi = m.open_index(variant("nospm", spm=lambda d: None))  # the dead-row map is optional
     assert hi.dead_rows is None and hi.words == ["from", "index", "reload"]
+
+
+def test_header_counts_are_bounded_before_they_are_trusted(tmp_path):
+    """Every dword / qword of a real header overwritten with an extreme count (n_checkpoints = 0x40000000, m_iDocinfo =
+    2^62 + 1, ...): the open ends in MRK_OK or an error code -- never an abort (std::bad_alloc out of an extern "C"
+    function), never a multi-gigabyte allocation, never more attribute rows than the .spa file holds."""
+    import resource
+    import time
+
+    import manticoresearch_amd as m
+
+    for name in ("t233_test", "t406_index0"):
+        src = os.path.join(IDX, name)
+        files = {ext: open(src + "." + ext, "rb").read() for ext in ("sph", "spi", "spd", "spp", "spe", "spm", "spa") if os.path.exists(src + "." + ext)}
+        p = str(tmp_path / name)
+        for ext, data in files.items():
+            open(p + "." + ext, "wb").write(data)
+        sph = files["sph"]
+        t0 = time.time()
+        rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        opened = 0
+        for k in range(8, len(sph) - 3):
+            for v in (struct.pack("<I", 0x40000000), struct.pack("<I", 0x08000000), struct.pack("<I", 0xFFFFFFFF), struct.pack("<Q", (1 << 62) + 1)):
+                open(p + ".sph", "wb").write(sph[:k] + v + sph[k + len(v):])
+                try:
+                    hi = m.open_index(p)
+                except m.MrkError as e:
+                    assert e.code in (-2, -4, -5), (k, e)
+                    continue
+                opened += 1
+                if hi.attr_rows is not None:
+                    assert hi.attr_rows.nbytes <= len(files.get("spa", b"")) and hi.attr_rows.shape[0] >= hi.total_docs
+        assert time.time() - t0 < 60
+        assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - rss0 < 600_000  # KiB: no count was allocated from unchecked
+        assert opened > 0

@@ -1,6 +1,8 @@
 #!/bin/bash
 # tools/fuzz_index_open.sh [SEED] [ITERATIONS] -- CPU only: builds csrc/mrk_files.cpp alone with ASan + UBSan and feeds
-# mrk_index_open mutated copies of the index fixtures under tests/golden/indexes/ (bytes flipped, files cut, junk inserted).
+# mrk_index_open mutated copies of the index fixtures under tests/golden/indexes/ (bytes flipped, files cut, junk inserted,
+# and -- for the header's count fields: n_fields, n_attrs, n_checkpoints, m_iDocinfo, embedded-list counts -- dwords / qwords
+# at random header offsets overwritten with extreme values such as 0x40000000 or 2^62 + 1).
 # Every open must end in MRK_OK or an error code; the sanitizers abort on anything else.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -45,6 +47,16 @@ for _ in range(n_iter):
                     del data[k:]
                 else:
                     data[k:k] = bytes(random.randrange(256) for _ in range(random.randint(1, 8)))
+        if e == "sph" and data and random.random() < 0.5:  # extreme counts: every dword / qword of the header gets its turn
+            import struct
+            for _ in range(random.randint(1, 2)):
+                k = random.randrange(len(data))
+                if random.random() < 0.6:
+                    v = random.choice([0xFFFFFFFF, 0x40000000, 0x08000000, 0x7FFFFFFF, 0x80000000, 0x10000, 65537, 257])
+                    data[k:k + 4] = struct.pack("<I", v)
+                else:
+                    v = random.choice([(1 << 62) + 1, (1 << 63), (1 << 64) - 1, 1 << 32, (1 << 40) + 7])
+                    data[k:k + 8] = struct.pack("<Q", v)
         open(w + "/x." + e, "wb").write(bytes(data))
     h = C.c_void_p()
     if L.mrk_index_open((w + "/x").encode(), C.byref(h)) == 0:
