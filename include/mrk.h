@@ -310,6 +310,17 @@ const uint8_t* mrk_host_index_spp(const mrk_host_index* h, uint64_t* len);
 const uint8_t* mrk_host_index_spe(const mrk_host_index* h, uint64_t* len);
 const mrk_dict_entry* mrk_host_index_dict(const mrk_host_index* h, uint32_t* n_terms);
 
+/* Accounting aid for the roofline figures; not on the query path.  For each keyword pair
+   (pairs[2i], pairs[2i+1]): common docs, each keyword's doc count, and the distinct 128-byte lines of each keyword's packed
+   tf / field words (64 words per 128-doc block, in doclist order) that the common docs touch -- what the two-bitmap AND
+   kernel's gathers have to fetch, instead of "every tf / field word of both doclists" -- and the distinct 128-doc
+   blocks touched (= 128-byte lines of the one-byte-per-doc "attr_nibbles" plane). */
+typedef struct {
+  uint64_t matches, docs_a, docs_b, lines128_a, lines128_b, blocks_a, blocks_b;
+} mrk_pair_stats;
+int mrk_host_index_pair_stats(const mrk_host_index* h, uint32_t hit_format, const uint32_t* pairs, uint32_t n_pairs,
+                              uint32_t n_threads, mrk_pair_stats* out);
+
 /* ------------------------------------------------------------------------------------
  * Real index ingestion: the files a Manticore 3.x indexer / RT disk chunk wrote,
  * format versions 54..62, read from disk into the same host-side object.  Replaces CSphIndex_VLN::LoadHeader

@@ -82,6 +82,11 @@ class AttrInfo(C.Structure):
     _fields_ = [("name", C.c_char_p), ("type", C.c_uint32), ("bit_offset", C.c_int32), ("bit_count", C.c_int32)]
 
 
+class PairStats(C.Structure):
+    _fields_ = [("matches", C.c_uint64), ("docs_a", C.c_uint64), ("docs_b", C.c_uint64), ("lines128_a", C.c_uint64), ("lines128_b", C.c_uint64),
+                ("blocks_a", C.c_uint64), ("blocks_b", C.c_uint64)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_docs", C.c_uint64), ("rowid_base", C.c_uint64), ("term_prob", C.POINTER(C.c_double)),
                 ("n_terms", C.c_uint32), ("n_fields", C.c_uint32), ("title_frac", C.c_double), ("max_pos", C.c_uint32),
@@ -125,6 +130,7 @@ SYMBOLS = [
     ("mrk_host_index_spp", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("mrk_host_index_spe", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("mrk_host_index_dict", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("mrk_host_index_pair_stats", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(PairStats)]),
     ("mrk_index_open", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("mrk_host_index_info", C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),
     ("mrk_host_index_field_name", C.c_char_p, [C.c_void_p, C.c_uint32]),
@@ -139,7 +145,7 @@ SYMBOLS = [
 
 def build(force: bool = False) -> str:
     """Compile libmrk.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mrk_kernels.hip", "mrk_scan_pk.hip", "mrk_kcommon.h", "mrk_host.cpp", "mrk_pack.cpp", "mrk_pack.h", "mrk_writer.cpp", "mrk_dev.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mrk_kernels.hip", "mrk_scan_pk.hip", "mrk_kcommon.h", "mrk_host.cpp", "mrk_pack.cpp", "mrk_pack.h", "mrk_writer.cpp", "mrk_dev.h", "mrk_scan_bm.hip", "mrk_plan.cpp", "mrk_files.cpp", "mrk_diag.cpp", "mrk_kprune.h", "mrk_host_int.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mrk.h"))
     stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:

@@ -136,6 +136,16 @@ def open_index(path_prefix: str) -> HostIndex:
     return hi
 
 
+def pair_stats(hi: HostIndex, pairs: Sequence[Sequence[int]], n_threads: int = 0):
+    """[(matches, docs_a, docs_b, lines128_a, lines128_b, blocks_a, blocks_b)] per keyword pair: common docs, the distinct
+    128-byte lines of each keyword's packed tf / field words they touch, and the distinct 128-doc blocks
+    (mrk_host_index_pair_stats; roofline accounting only)."""
+    arr = np.ascontiguousarray(np.asarray(pairs, dtype=np.uint32).reshape(-1, 2))
+    out = (_lib.PairStats * len(arr))()
+    check(lib().mrk_host_index_pair_stats(hi._owner.h, hi.hit_format, arr.ctypes.data, len(arr), n_threads, out))
+    return [(int(o.matches), int(o.docs_a), int(o.docs_b), int(o.lines128_a), int(o.lines128_b), int(o.blocks_a), int(o.blocks_b)) for o in out]
+
+
 def index_from_hits(wordid: np.ndarray, rowid: np.ndarray, hitpos: np.ndarray, n_terms: int, total_docs: int,
                     skiplist_block_size: int = 128, hit_format: int = SPH_HIT_FORMAT_INLINE, n_fields: int = 2) -> HostIndex:
     """Encode explicit hits (sorted by wordid, rowid, hitpos; wordid = term id + 1)."""
@@ -477,4 +487,4 @@ __all__ = ["SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RAN
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
            "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE",
            "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Filter", "Matches", "Context",
-           "Segment", "Batch", "prepare", "idf", "MrkError", "validate_index"]
+           "Segment", "Batch", "prepare", "idf", "MrkError", "validate_index", "pair_stats"]

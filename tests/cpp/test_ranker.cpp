@@ -13,7 +13,7 @@
 static mrk_segment* make_segment(mrk_ctx* ctx, uint64_t n_docs, const double* probs, uint32_t n_terms, uint64_t seed,
                                  uint32_t shard, mrk_host_index** keep) {
   mrk_synth_params p{};
-  p.seed = seed, p.n_docs = n_docs, p.shard = shard, p.term_prob = probs, p.n_terms = n_terms, p.n_fields = 2;
+  p.seed = seed, p.n_docs = n_docs, p.rowid_base = (uint64_t)shard * n_docs, p.term_prob = probs, p.n_terms = n_terms, p.n_fields = 2;
   p.title_frac = 0.1, p.max_pos = 1024, p.skiplist_block_size = 32, p.hit_format = MRK_HITFMT_INLINE, p.n_threads = 2;
   if (mrk_synth_generate(&p, keep) != MRK_OK) return nullptr;
   mrk_segment_desc d{};
