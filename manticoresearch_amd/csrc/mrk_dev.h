@@ -179,6 +179,18 @@ __host__ __device__ inline uint64_t make_key(int32_t weight, uint32_t rowid) {
 __host__ __device__ inline int32_t key_weight(uint64_t k) { return (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); }
 __host__ __device__ inline uint32_t key_rowid(uint64_t k) { return ~(uint32_t)k; }
 
+// Matched docs of hit-ranked queries travel from the scan kernels to rank_kernel through an HBM queue of 64-entry chunks
+// (structure of arrays: per chunk MQ_PLANES rows of 64 dwords -- rowid, tfidf sum, fields | contributing keywords << 8,
+// one packed-array reference per keyword -- each written and read as one coalesced 256-B row)
+constexpr int MQ_PLANES = 3 + MAX_PROX_TERMS_;
+constexpr int MQ_SHARDS = 8; // chunk allocators per queue (workgroup b uses shard b % 8): one hot atomic address would serialize the producers
+struct MatchQueue {
+  uint32_t* data;  // [MQ_SHARDS * cap][MQ_PLANES][64]
+  uint32_t* hdr;   // [MQ_SHARDS * cap] pass index | valid entries << 24
+  uint32_t* count; // [MQ_SHARDS] chunks handed out per shard (past cap: dropped, the query flagged QF_OVERFLOW)
+  uint32_t cap;    // chunks per shard; shard s owns chunks [s * cap, (s + 1) * cap)
+};
+
 struct ScanArgs {
   DevSegment seg;
   const DevQuery* queries;
@@ -194,6 +206,7 @@ struct ScanArgs {
   uint32_t* q_flags;   // [n_queries]
   uint32_t* q_tau_bin; // [n_queries] running pruning threshold (bin index), atomicMax
   uint64_t* cand;      // candidate arena
+  MatchQueue mq[2];    // [0] plain boolean trees, [1] queries with PHRASE / PROXIMITY / BEFORE nodes or position modifiers
 };
 
 struct SelectArgs {
@@ -241,6 +254,8 @@ void launch_scan(const ScanArgs& a, void* stream);
 void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, bool ext, void* stream);
 constexpr int MAX_PROX_TERMS = MAX_PROX_TERMS_; // keywords whose hit streams the hit kernel merges per doc
 void launch_scan_bm(const ScanArgs& a, void* stream); // a.items: (query, window range) work items
+// final ranking of the queued matches (mrk_rank.hip): a persistent grid drains queue `which` of a.mq
+void launch_rank(const ScanArgs& a, int which, void* stream);
 void launch_select(const SelectArgs& a, void* stream);
 void launch_merge(const MergeArgs& a, void* stream);
 

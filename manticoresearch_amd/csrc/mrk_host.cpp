@@ -143,6 +143,10 @@ struct mrk_batch {
   DevBuf<uint32_t> d_decl;
   bool decl_dirty = false; // d_decl holds non-zero words of an earlier submit
   bool any_declined = false;
+  // HBM match queues of the hit-ranked queries (scan kernels -> rank_kernel): [0] plain trees, [1] PHRASE & co
+  DevBuf<uint32_t> d_mq_data[2], d_mq_hdr[2];
+  DevBuf<uint32_t> d_mq_count; // [2][MQ_SHARDS]
+  bool last_fat = false;
   // decoded results
   std::vector<uint32_t> rowid;
   std::vector<int32_t> weight;
@@ -216,6 +220,11 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "bm_target_items")) {
     if (value < 1 || value > (1 << 20)) return mrk_fail(MRK_E_INVAL, "bm_target_items must be 1 .. 2^20");
     c->bm_target_items = (int)value;
+    return MRK_OK;
+  }
+  if (!strcmp(key, "mq_max_chunks")) {
+    if (value < 1 || value > (1 << 24)) return mrk_fail(MRK_E_INVAL, "mq_max_chunks must be 1 .. 2^24");
+    c->mq_max_chunks = (int)value;
     return MRK_OK;
   }
   if (!strcmp(key, "bitmap_inv")) {
@@ -680,6 +689,8 @@ extern "C" void mrk_batch_destroy(mrk_batch* b) {
   b->h_flags.release();
   b->h_decl.release();
   b->d_decl.release();
+  for (int i = 0; i < 2; ++i) b->d_mq_data[i].release(), b->d_mq_hdr[i].release();
+  b->d_mq_count.release();
   if (b->retry) mrk_batch_destroy(b->retry);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
@@ -702,7 +713,7 @@ extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** 
       (rc = b->h_total.reserve(nq)) || (rc = b->d_queries.reserve(nq)) ||
       (rc = b->d_state.reserve(nq * (8 + 8 + 4 + 4 + 4 + (size_t)NBINS * 4))) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
       (rc = b->d_kq.reserve(nq)) || (rc = b->d_out_keys.reserve(nq * KCAP)) || (rc = b->d_out_cnt.reserve(nq)) ||
-      (rc = b->h_flags.reserve(nq)) || (rc = b->h_cand_n.reserve(nq)) || (rc = b->h_decl.reserve(nq)) || (rc = b->d_decl.reserve(nq))) {
+      (rc = b->h_flags.reserve(nq)) || (rc = b->h_cand_n.reserve(nq)) || (rc = b->h_decl.reserve(nq)) || (rc = b->d_decl.reserve(nq)) || (rc = b->d_mq_count.reserve(2 * mrk::MQ_SHARDS))) {
     mrk_batch_destroy(b);
     return rc;
   }
@@ -725,6 +736,34 @@ extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** 
   b->weight.resize(nq * KCAP);
   b->status.assign(nq, MRK_OK);
   *out = b;
+  return MRK_OK;
+}
+
+// mirrors scan_pk_kernel: matches of these passes leave through the match queue (state rankers over more than one
+// keyword, whole-query PHRASE); `fat` = the queue whose consumer carries the word state machines
+static bool pass_queues_matches(const DevQuery& P, bool& fat) {
+  const uint32_t rk = P.ranker;
+  const bool prox_ranker = (rk == MRK_RANK_PROXIMITY_BM25 || rk == MRK_RANK_PROXIMITY)
+                               ? P.n_terms > 1
+                               : (rk == MRK_RANK_WORDCOUNT || rk == MRK_RANK_MATCHANY || rk == MRK_RANK_FIELDMASK || rk == MRK_RANK_SPH04);
+  fat = (P.tree_flags & (mrk::TF_PHRASE | mrk::TF_PHRASE_LEAF | mrk::TF_TERMPOS | mrk::TF_ORDER)) != 0;
+  return prox_ranker || (P.tree_flags & mrk::TF_PHRASE) != 0;
+}
+
+// size the batch's match queues for `chunks[q]` chunks (0 = queue unused) and point the scan arguments at them
+static int bind_match_queues(mrk_batch* b, const uint64_t chunks[2], mrk::ScanArgs& sa) {
+  for (int i = 0; i < 2; ++i) {
+    sa.mq[i] = mrk::MatchQueue{};
+    sa.mq[i].count = b->d_mq_count.p + mrk::MQ_SHARDS * i;
+    if (!chunks[i]) continue;
+    // per shard: its share of the chunks + slack for the spread between shards (workgroups are dealt round-robin)
+    const uint64_t per = chunks[i] / mrk::MQ_SHARDS + chunks[i] / (8 * mrk::MQ_SHARDS) + 64;
+    int rc;
+    if ((rc = b->d_mq_data[i].reserve((size_t)per * mrk::MQ_SHARDS * mrk::MQ_PLANES * 64)) || (rc = b->d_mq_hdr[i].reserve((size_t)per * mrk::MQ_SHARDS))) return rc;
+    sa.mq[i].data = b->d_mq_data[i].p;
+    sa.mq[i].hdr = b->d_mq_hdr[i].p;
+    sa.mq[i].cap = (uint32_t)per;
+  }
   return MRK_OK;
 }
 
@@ -769,10 +808,21 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
       b->h_queries.p[i].n_terms = 0;
     }
     max_terms = std::max(max_terms, b->h_queries.p[i].n_terms);
-    any_ext = any_ext || (b->h_queries.p[i].tree_flags & (mrk::TF_TERMPOS | mrk::TF_ORDER)) != 0 || b->h_queries.p[i].n_filters != 0;
+    any_ext = any_ext || (b->h_queries.p[i].tree_flags & (mrk::TF_TERMPOS | mrk::TF_ORDER | mrk::TF_PHRASE_LEAF)) != 0 || b->h_queries.p[i].n_filters != 0;
     b->h_list_first.p[i] = b->h_queries.p[i].item_first;
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;
+  }
+  // match queues: a pass hands over at most one entry per driver doc, plus one partial chunk per wave of its items
+  uint64_t mq_chunks[2] = {0, 0};
+  if (use_packed && any_prox) {
+    auto account = [&](const DevQuery& P) {
+      bool fat = false;
+      if (P.n_items && pass_queues_matches(P, fat)) mq_chunks[fat ? 1 : 0] += (uint64_t)P.t[0].docs / 64 + 4ull * P.n_items + 1;
+    };
+    for (uint32_t i = 0; i < n; ++i) account(b->h_queries.p[i]);
+    for (const DevQuery& P : extra) account(P);
+    for (int i = 0; i < 2; ++i) mq_chunks[i] = std::min<uint64_t>(mq_chunks[i], (uint64_t)b->ctx->mq_max_chunks);
   }
   const float plan_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count();
   const size_t n_items_pk = items.size();
@@ -839,10 +889,15 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   sa.q_flags = b->d_q_flags.p;
   sa.q_tau_bin = b->d_q_tau_bin.p;
   sa.cand = b->d_cand.p;
+  if ((rc = bind_match_queues(b, mq_chunks, sa))) return rc;
+  if (mq_chunks[0] || mq_chunks[1]) HIP_TRY(hipMemsetAsync(b->d_mq_count.p, 0, 2 * mrk::MQ_SHARDS * 4, st));
   lap("h2d+memset");
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
   if (use_packed) {
     launch_scan_pk(sa, max_terms, any_prox, any_tree, any_ext, st);
+    // the queued matches of hit-ranked queries: hit pass + state rankers (mrk_rank.hip), behind the scan on the same stream
+    if (mq_chunks[0]) launch_rank(sa, 0, st);
+    if (mq_chunks[1]) launch_rank(sa, 1, st);
     if (n_items_bm) {
       ScanArgs sb = sa;
       sb.items = b->d_items.p + n_items_pk;
@@ -989,7 +1044,20 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   sa.q_flags = r->d_q_flags.p;
   sa.q_tau_bin = r->d_q_tau_bin.p;
   sa.cand = r->d_cand.p;
-  launch_scan_pk(sa, b->last_max_terms, b->last_prox, b->last_tree, b->last_ext, st);
+  {
+    uint64_t chunks[2] = {0, 0};
+    for (size_t p = 0; p < passes.size(); ++p) {
+      bool fat = false;
+      if (pass_queues_matches(passes[p], fat)) chunks[fat ? 1 : 0] += (uint64_t)passes[p].t[0].docs / 64 + 4ull * n_items + 1;
+    }
+    for (int i = 0; i < 2; ++i)
+      if (chunks[i] > (1ull << 25)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: match queue for the rerun too large", qi);
+    if ((rc = bind_match_queues(r, chunks, sa))) return rc;
+    if (chunks[0] || chunks[1]) HIP_TRY(hipMemsetAsync(r->d_mq_count.p, 0, 2 * mrk::MQ_SHARDS * 4, st));
+    launch_scan_pk(sa, b->last_max_terms, b->last_prox, b->last_tree, b->last_ext, st);
+    if (chunks[0]) launch_rank(sa, 0, st);
+    if (chunks[1]) launch_rank(sa, 1, st);
+  }
   if (n_items > n_pk) {
     ScanArgs sb = sa;
     sb.items = r->d_items.p + n_pk;

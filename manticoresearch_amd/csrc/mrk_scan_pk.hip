@@ -10,6 +10,7 @@
 // (searchnode.cpp:2828, sphinxsearch.cpp:1112-1129).  No MFMA: integer streaming work.
 #include "mrk_kcommon.h"
 #include "mrk_kprune.h"
+#include "mrk_khits.h"
 
 #ifndef MRK_EXP
 #define MRK_EXP 0
@@ -119,590 +120,6 @@ __device__ __forceinline__ void decode_pk(const PkRaw& raw, uint32_t w, uint32_t
   r1 = bp1 + o1;
 }
 
-// one VLB-coded u32 out of the hitlist file at byte position p (GetHitlistEntry, sphinx.cpp:374-388):
-// two aligned dwords + a funnel shift give the 4-byte window; a 5th byte is fetched when needed
-__device__ __forceinline__ uint32_t read_vlb32(const uint8_t* __restrict__ spp, uint64_t& p) {
-  const uint64_t al = p & ~3ull;
-  const uint32_t w0 = *reinterpret_cast<const uint32_t*>(spp + al);
-  const uint32_t w1 = *reinterpret_cast<const uint32_t*>(spp + al + 4);
-  const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)p & 3u);
-  // branch-free for 1..4 bytes: the first byte with a clear top bit ends the value; the 7-bit groups are MSB first
-  const uint32_t stop = ~x & 0x80808080u;
-  const uint32_t n = stop ? ((uint32_t)__builtin_ctz(stop) >> 3) + 1u : 4u;
-  const uint32_t all = ((x & 0x7Fu) << 21) | ((x & 0x7F00u) << 6) | ((x >> 9) & 0x3F80u) | ((x >> 24) & 0x7Fu); // 4 groups
-  uint32_t val = all >> (7u * (4u - n));
-  uint32_t len = n;
-  if (!stop) { // 5-byte varint
-    val = (val << 7) | (spp[p + 4] & 0x7fu);
-    len = 5;
-  }
-  p += len;
-  return val;
-}
-
-// next hit of one keyword in one doc (GetNextHit, sphinx.cpp:479-501); 0 (EMPTY_HIT) when exhausted
-__device__ __forceinline__ void hit_advance(const uint8_t* __restrict__ spp, uint64_t& p, uint32_t& cur) {
-  if (!p) {
-    cur = 0;
-    return;
-  }
-  const uint32_t d = read_vlb32(spp, p);
-  if (!d) {
-    p = 0;
-    cur = 0;
-  } else
-    cur += d;
-}
-
-__device__ __forceinline__ bool field_queried(uint32_t qmask, uint32_t hitpos) {
-  const uint32_t f = hitpos >> 24;
-  return f < 32 ? ((qmask >> f) & 1u) != 0 : qmask == 0xFFFFFFFFu;
-}
-
-// TermAcceptor_T<>::IsAcceptableHit (searchnode.cpp:2264-2285): '^word' / 'word$' / '^word$' / '@field[N] word'
-__device__ __forceinline__ bool tp_accept(uint32_t kind, uint32_t max_pos, uint32_t hitpos) {
-  const uint32_t pos = hitpos & 0x7FFFFFu;
-  const bool end = ((hitpos >> 23) & 1u) != 0;
-  return kind == MRK_TERMPOS_START      ? pos == 1u
-         : kind == MRK_TERMPOS_END      ? end
-         : kind == MRK_TERMPOS_STARTEND ? (pos == 1u && end)
-         : kind == MRK_TERMPOS_LIMIT    ? pos <= max_pos
-                                        : true;
-}
-
-// FSMphrase_c (searchnode.cpp:3884-3947): live states = (index of the last word read, expected position of the
-// next one).  A first-word hit opens a state; states whose expected position was passed die; a state that reads
-// its last word completes an occurrence and resets the machine.
-struct PhraseFsm {
-  uint32_t fexp[PHRASE_STATES];
-  uint32_t ftag, fvalid;
-  bool over; // more live states than we keep: the query is failed loudly
-
-  __device__ __forceinline__ void reset() {
-#pragma unroll
-    for (int i = 0; i < PHRASE_STATES; ++i) fexp[i] = 0;
-    ftag = 0, fvalid = 0, over = false;
-  }
-  // one hit (position with field, no end bit; query position) of the merged word streams; true = occurrence complete
-  __device__ __forceinline__ bool step(uint32_t hp, uint32_t hq, uint32_t nph, uint32_t ap0, uint32_t ap1, uint32_t ap2,
-                                       uint32_t ap3) {
-    bool emit = false;
-    if (hq == (ap0 & 0xFFFFu)) {
-      const uint32_t freeb = ~fvalid & ((1u << PHRASE_STATES) - 1u);
-      if (!freeb)
-        over = true;
-      else {
-        const uint32_t idx = (uint32_t)__builtin_ctz(freeb);
-#pragma unroll
-        for (int i = 0; i < PHRASE_STATES; ++i)
-          if ((uint32_t)i == idx) fexp[i] = hp + (ap1 - ap0);
-        ftag &= ~(3u << (2 * idx));
-        fvalid |= 1u << idx;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < PHRASE_STATES; ++i) {
-      if (!emit && ((fvalid >> i) & 1u)) {
-        if (fexp[i] < hp)
-          fvalid &= ~(1u << i);
-        else {
-          uint32_t tg = (ftag >> (2 * i)) & 3u;
-          const uint32_t nextq = tg == 0 ? ap1 : tg == 1 ? ap2 : ap3;
-          if (fexp[i] == hp && tg + 1 < nph && (nextq & 0xFFFFu) == hq) {
-            ++tg;
-            const uint32_t cq = tg == 1 ? ap1 : tg == 2 ? ap2 : ap3, nq = tg == 1 ? ap2 : ap3;
-            fexp[i] = tg + 1 < nph ? hp + (nq - cq) : hp - 0x7FFFFFFFu; // FSMphrase_c: -INT_MAX past the last word
-            ftag = (ftag & ~(3u << (2 * i))) | (tg << (2 * i));
-          }
-          if (tg == nph - 1) emit = true;
-        }
-      }
-    }
-    if (emit) fvalid = 0; // ResetFSM
-    return emit;
-  }
-
-  // FSMproximity_c (searchnode.cpp:3958-4075), '"a b c"~N', on the same storage: fexp[i] = m_dProx[i] (last position
-  // of the word at query offset i, ~0 = none), ftag = m_uWords, fvalid = m_iMinQindex + 1, exp = m_uExpPos.
-  // A hit that completes "all words within qlen + dist" folds them into one hit: position / spanlen of the words
-  // gathered, weight from how many of them keep the query's relative offsets; the earliest word is then dropped.
-  uint32_t exp;
-  __device__ __forceinline__ void reset_prox() {
-#pragma unroll
-    for (int i = 0; i < PHRASE_STATES; ++i) fexp[i] = 0xFFFFFFFFu;
-    ftag = 0, fvalid = 0, over = false, exp = 0;
-  }
-  __device__ __forceinline__ bool step_prox(uint32_t hp, uint32_t hq, uint32_t nph, uint32_t min_qpos, uint32_t qlen, uint32_t dist,
-                                            uint32_t& out_pos, uint32_t& out_w, uint32_t& out_span) {
-    const uint32_t qi = hq - min_qpos;
-    int min_q = (int)fvalid - 1;
-#pragma unroll
-    for (int i = 0; i < PHRASE_STATES; ++i)
-      if ((uint32_t)i == qi) {
-        if (fexp[i] == 0xFFFFFFFFu) ++ftag;
-        fexp[i] = hp;
-      }
-    if (hp >= exp || (int)qi == min_q) {
-      min_q = (int)qi;
-      uint32_t h = hp;
-      const int min_pos = (int)(hp - qlen - dist);
-#pragma unroll
-      for (int i = 0; i < PHRASE_STATES; ++i)
-        if ((uint32_t)i <= qlen && fexp[i] != 0xFFFFFFFFu) {
-          if ((int)fexp[i] <= min_pos) {
-            fexp[i] = 0xFFFFFFFFu;
-            --ftag;
-          } else if (fexp[i] < h) {
-            min_q = i;
-            h = fexp[i];
-          }
-        }
-      uint32_t pm = 0;
-#pragma unroll
-      for (int i = 0; i < PHRASE_STATES; ++i)
-        if (i == min_q) pm = fexp[i];
-      exp = pm + qlen + dist;
-    }
-    fvalid = (uint32_t)(min_q + 1);
-    if (ftag != nph) return false;
-    // weight: sort the words' (position - query offset); runs of equal values are words in the query's order
-    int d[PHRASE_STATES];
-    uint32_t umax = 0;
-#pragma unroll
-    for (int i = 0; i < PHRASE_STATES; ++i) {
-      const bool have = (uint32_t)i <= qlen && fexp[i] != 0xFFFFFFFFu;
-      d[i] = have ? (int)(fexp[i] - (uint32_t)i) : 0x7FFFFFFF;
-      if (have && fexp[i] > umax) umax = fexp[i];
-    }
-#pragma unroll
-    for (int pass = 0; pass < PHRASE_STATES; ++pass) // odd-even transposition sort, 8 elements
-#pragma unroll
-      for (int i = pass & 1; i + 1 < PHRASE_STATES; i += 2) {
-        const int lo = d[i] < d[i + 1] ? d[i] : d[i + 1], hi = d[i] < d[i + 1] ? d[i + 1] : d[i];
-        d[i] = lo;
-        d[i + 1] = hi;
-      }
-    uint32_t cur_w = 0, w = 0;
-    int last = -0x7FFFFFFF;
-#pragma unroll
-    for (int i = 0; i < PHRASE_STATES; ++i)
-      if (d[i] != 0x7FFFFFFF) {
-        if (d[i] == last)
-          ++cur_w;
-        else {
-          w += cur_w ? 1u + cur_w : 0u;
-          cur_w = 0;
-        }
-        last = d[i];
-      }
-    w += cur_w ? 1u + cur_w : 0u;
-    if (!w) w = 1;
-    uint32_t pm = 0;
-#pragma unroll
-    for (int i = 0; i < PHRASE_STATES; ++i)
-      if (i == min_q) pm = fexp[i];
-    out_pos = pm;
-    out_w = w;
-    out_span = umax - pm; // spanlen - 1
-    // drop the earliest word and force a recompute on the next hit
-#pragma unroll
-    for (int i = 0; i < PHRASE_STATES; ++i)
-      if (i == min_q) fexp[i] = 0xFFFFFFFFu;
-    fvalid = 0;
-    --ftag;
-    exp = 0;
-    return true;
-  }
-};
-
-// The state rankers (ExtRanker_State_T<STATE>, sphinxsearch.cpp:1198-1315), one doc at a time.  All of them see the
-// same hit stream; `ranker` picks the Update / Finalize pair:
-//   PROXIMITY_BM25 / PROXIMITY  RankerState_Proximity_fn<.., false>      :1351-1437  LCS per field (BYTE arithmetic)
-//   SPH04                       RankerState_ProximityBM25Exact_fn        :1443-1530  LCS + head hit + exact hit
-//   MATCHANY                    RankerState_MatchAny_fn                  :1577-1616  LCS + matched query positions per field
-//   WORDCOUNT                   RankerState_Wordcount_fn                 :1620-1643  field weight per hit
-//   FIELDMASK                   RankerState_Fieldmask_fn                 :1647-1668  fields that hold a hit
-// m_uLCS[field] / m_uMatchMask[field] are one byte per field in a u64 (<= 8 fields on this path).
-// A doc starts from the post-Finalize state; SPH04's m_uMinExpPos survives Finalize in the reference, which cannot
-// change a doc's first hit (it either fails the delta test or both branches agree), so every doc starts it afresh.
-struct RankState {
-  uint64_t lcs, mmask;
-  uint32_t cur_lcs, min_exp_pos, head, exact, fmask;
-  int exp_delta, last_pwf, wc;
-  bool first;
-  __device__ __forceinline__ void reset() {
-    lcs = 0, mmask = 0, cur_lcs = 0, min_exp_pos = 0, head = 0, exact = 0, fmask = 0;
-    exp_delta = -1, last_pwf = -1, wc = 0, first = true;
-  }
-  // one hit: hp = position with field (no end bit), is_end = its end-of-field marker, hq = query position,
-  // hw = weight (1; word count for a folded phrase hit), hspan = spanlen - 1; w_of = field weight table
-  __device__ __forceinline__ void update(uint32_t ranker, bool dupes, uint32_t hp, bool is_end, uint32_t hq, uint32_t hw,
-                                         uint32_t hspan, const uint32_t* w_of, int max_qpos) {
-    const uint32_t f = hp >> 24;
-    const int pwf = (int)hp;
-    const int delta = pwf - (int)hq;
-    if (ranker == MRK_RANK_WORDCOUNT) {
-      wc += f < 8 ? (int)w_of[1u << f] : 0;
-      return;
-    }
-    if (ranker == MRK_RANK_FIELDMASK) {
-      fmask |= 1u << (f & 31u);
-      return;
-    }
-    if (ranker == MRK_RANK_SPH04) {
-      const int pos = (int)(hp & 0x7FFFFFu);
-      if (!first && delta == exp_delta && hp >= min_exp_pos) {
-        if (pwf > last_pwf) cur_lcs = (cur_lcs + hw) & 0xffu;
-        if (is_end && (int)hq == max_qpos && pos == max_qpos) exact |= 1u << (f & 31u);
-      } else {
-        if (pwf > last_pwf) cur_lcs = hw & 0xffu;
-        if (pos == 1) {
-          head |= 1u << (f & 31u);
-          if (is_end && max_qpos == 1) exact |= 1u << (f & 31u);
-        }
-      }
-      min_exp_pos = hp + 1u;
-      first = false;
-    } else if (dupes) {
-      // RankerState_Proximity_fn<.., true>::Update (:1370-1412): repeated query keywords -- several query positions
-      // may share a hit position.  min_exp_pos / head / exact / fmask double as m_uLcsTailPos / m_uLcsTailQposMask /
-      // m_uCurQposMask / m_uCurPos (SPH04 and FIELDMASK have no dupes variant).
-      if ((fmask >> 24) != f) exact = 0;
-      if (hp != fmask) {
-        if (cur_lcs < 2) {
-          min_exp_pos = fmask;
-          head = exact;
-          cur_lcs = 1;
-        }
-        exact = 0;
-        fmask = hp;
-        if (f < 8 && (uint32_t)((lcs >> (8 * f)) & 0xffu) < hw) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)(hw & 0xffu) << (8 * f));
-      }
-      exact |= (uint32_t)(1ull << (hq & 63u)); // 1UL << qpos stored into a DWORD: positions 32..63 add no bit
-      const int dd = (int)(fmask - min_exp_pos);
-      if (dd && dd < 32 && ((exact >> (dd & 31)) & head)) {
-        head = (uint32_t)(1ull << (hq & 63u));
-        min_exp_pos = fmask;
-        cur_lcs = (cur_lcs + hw) & 0xffu;
-        exact = 0;
-        if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu)) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
-      }
-      return;
-    } else { // the proximity family
-      if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + hw) & 0xffu;
-      if (ranker == MRK_RANK_MATCHANY && f < 8) mmask |= (uint64_t)((1u << ((hq - 1u) & 31u)) & 0xffu) << (8 * f);
-    }
-    if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu)) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
-    last_pwf = pwf;
-    exp_delta = delta + (int)hspan;
-  }
-  __device__ __forceinline__ int finalize(uint32_t ranker, uint32_t nw, const int32_t* weights, const uint32_t* w_of, int n_qwords) const {
-    if (ranker == MRK_RANK_WORDCOUNT) return wc;
-    if (ranker == MRK_RANK_FIELDMASK) return (int)fmask;
-    int rk = 0;
-    if (ranker == MRK_RANK_MATCHANY) {
-      const int phrase_k = (int)w_of[(1u << nw) - 1u] * n_qwords; // sum of the field weights x query words
-      for (uint32_t f = 0; f < nw; ++f) {
-        const uint32_t mm = (uint32_t)(mmask >> (8 * f)) & 0xffu;
-        if (mm) rk += (int)(__popc(mm) + ((int)((lcs >> (8 * f)) & 0xffu) - 1) * phrase_k) * weights[f];
-      }
-      return rk;
-    }
-    for (uint32_t f = 0; f < nw; ++f) {
-      const int l = (int)((lcs >> (8 * f)) & 0xffu);
-      rk += (ranker == MRK_RANK_SPH04 ? 4 * l + 2 * (int)((head >> f) & 1u) + (int)((exact >> f) & 1u) : l) * weights[f];
-    }
-    return rk;
-  }
-};
-
-// one value of the boolean-tree evaluation stack, for the two docs a lane owns
-struct TreeEnt {
-  bool m[2];     // subtree matches the doc
-  float v[2];    // its tfidf sum (0 when unmatched)
-  uint32_t f[2]; // its matched-fields bits
-  uint32_t a[2]; // keywords whose hits it emits
-};
-
-// what one doc's hit pass needs from the kernel (plain values: no reference to the kernel's locals survives)
-struct HitCtx {
-  const DevQuery* Q;
-  const uint8_t* spp;
-  const uint32_t* hit;    // DevSegment::pk_hit
-  const uint64_t* hbase;  // DevSegment::pk_hbase
-  uint32_t* flags;        // the query's flag word
-  uint32_t nterms, nw;
-  uint32_t ap0, ap1, ap2, ap3;
-  uint32_t nph, span;     // the query's phrase: words, distance between its first and last query position
-  uint32_t px_dist;       // 0 = exact PHRASE, else the PROXIMITY operator's distance ('"a b"~N')
-  uint32_t ranker;        // MRK_RANK_* of the state ranker fed by the pass
-  const uint32_t* w_of;   // LDS table: field-weight sum per field mask (w_of[1 << f] = weight of field f)
-  int max_qpos, n_qwords; // ExtRanker_c::m_iMaxQpos / m_iQwords
-  bool inline_hits, multi_and;
-  bool dupes;             // repeated query keywords under a proximity ranker: RankerState_Proximity_fn<.., true>
-  uint64_t apack;         // ap0..ap3, 16 bits each: indexed by shifting (a select over the four fields would be
-                          // turned into an indexed load and push the whole struct to scratch)
-  bool order;             // the keywords of pmask form a BEFORE node (ExtOrder_c), not a PHRASE
-  bool termpos;           // some keyword carries a position modifier: its stream yields acceptable hits only
-  bool quorum_hits;       // the root is an ExtQuorum_c: hits order by position without the end flag (QuorumCmpHitPos_fn)
-};
-
-// One doc's hit pass.  ref0..ref3 = where the doc sits in each keyword's packed arrays (block within the keyword << 7 |
-// slot, bit 31 = its one hit was inlined), smask = keyword slots whose hits take part, pmask = slots forming the
-// phrase (0 = none), rank = feed the state ranker (else: stop at the first phrase occurrence).
-__device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_t ref1, uint32_t ref2, uint32_t ref3, uint32_t smask,
-                                         uint32_t pmask, bool rank, bool& ph_found, uint32_t& ph_field, int& rk_out) {
-  // .spp cursor (0 = inlined hit / exhausted), current Hitpos_t (0 = exhausted), query position, field limit
-  uint64_t sp[MAX_PROX_TERMS];
-  uint32_t sc[MAX_PROX_TERMS], sq[MAX_PROX_TERMS], sm[MAX_PROX_TERMS];
-  uint32_t tpk[MAX_PROX_TERMS], tpm[MAX_PROX_TERMS]; // ExtTermPos_T: the keyword's acceptor
-#pragma unroll
-  for (int t = 0; t < MAX_PROX_TERMS; ++t) {
-    sp[t] = 0, sc[t] = 0, sq[t] = 0, sm[t] = 0, tpk[t] = 0, tpm[t] = 0;
-    if ((uint32_t)t < C.nterms && ((smask >> t) & 1u)) {
-      const DevTerm& Tt = C.Q->t[t];
-      if (C.termpos) tpk[t] = Tt.tp_kind, tpm[t] = Tt.tp_max;
-      const uint32_t h = t == 0 ? ref0 : t == 1 ? ref1 : t == 2 ? ref2 : ref3;
-      const uint32_t gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu), idx = h & 127u;
-      const bool lone = (h >> 31) != 0;
-      sq[t] = Tt.qpos;
-      sm[t] = Tt.queried32;
-      const uint32_t hv = C.hit[(uint64_t)gblk * DEVBLK + idx];
-      if (lone) // the hit travelled in the doclist entry (SeekHitlist state 1, sphinx.cpp:461-464)
-        sc[t] = hv;
-      else {
-        sp[t] = C.hbase[gblk] + hv;
-        hit_advance(C.spp, sp[t], sc[t]);
-      }
-      if (C.termpos)
-        while (sc[t] && !tp_accept(tpk[t], tpm[t], sc[t])) hit_advance(C.spp, sp[t], sc[t]);
-    }
-  }
-  // the phrase as a stream of folded hits: position = first word's, weight = word count, spanlen = span + 1
-  const uint32_t nph = C.nph, span = C.span; // the query's one phrase: word count, last - first query position
-  PhraseFsm F;
-  if (C.px_dist)
-    F.reset_prox();
-  else
-    F.reset();
-  bool phave = false, pdone = pmask == 0, first = true;
-  uint32_t pcur = 0, pfield = 0, pw = 0, pspan = 0;
-  // BEFORE (ExtOrder_c::GetMatchingHits, searchnode.cpp:4734-4829): the longest in-order run of the children's hits so far
-  // and the most recently started one (entry i = child i's hit); a full run is flushed to the ranker hit by hit
-  uint32_t ol0 = 0, ol1 = 0, ol2 = 0, ol3 = 0, or0 = 0, or1 = 0, or2 = 0, or3 = 0; // trackers
-  uint32_t oe0 = 0, oe1 = 0, oe2 = 0, oe3 = 0;                                     // flushed run waiting for the ranker
-  uint32_t olen_l = 0, olen_r = 0, opos_l = 0, opos_r = 0, ofield = 0xFFFFFFFFu, opend_i = 0, opend_n = 0, pq = C.ap0 & 0xFFFFu;
-  bool pend_is_end = false;
-  RankState X;
-  X.reset();
-  const uint32_t dmask = smask & ~pmask; // keywords whose hits reach the ranker as they are
-  const uint32_t cmpmask = C.quorum_hits ? ~(1u << 23) : 0xFFFFFFFFu; // ExtQuorum_c sorts its hits without the end flag
-  // MergeHits3 quirk (searchnode.cpp:3072-3077 + 3052-3054): once one of three streams runs dry the
-  // 2-stream merge tests fields against nodes 0 and 1, whichever streams are left, until one more is dry
-  int phase = (C.multi_and && !pmask && C.nterms == 3 && (sm[0] & sm[1] & sm[2]) != 0xFFFFFFFFu) ? 0 : 2, tl = 0, tr = 1;
-  for (;;) {
-    if (!pdone && !phave && C.order && opend_i < opend_n) { // the next hit of the run flushed last
-      const uint32_t h = opend_i == 1 ? oe1 : opend_i == 2 ? oe2 : oe3;
-      pcur = h & ~(1u << 23), pend_is_end = ((h >> 23) & 1u) != 0;
-      pq = (uint32_t)(C.apack >> (16u * opend_i)) & 0xFFFFu;
-      pw = 1u, pspan = 0u;
-      ++opend_i;
-      phave = true;
-    }
-    if (!pdone && !phave && C.order) {
-      for (;;) {
-        int best = -1;
-        uint32_t bh = 0, bkey = 0, bci = 0, bmask = 0;
-#pragma unroll
-        for (int t = 0; t < MAX_PROX_TERMS; ++t) { // GetChildIdWithNextHit (:4706-4731): least position, ties to the first child
-          const uint32_t q16 = sq[t] & 0xFFFFu;
-          const uint32_t ci = q16 == ((uint32_t)C.apack & 0xFFFFu)           ? 0u
-                              : q16 == ((uint32_t)(C.apack >> 16) & 0xFFFFu) ? 1u
-                              : q16 == ((uint32_t)(C.apack >> 32) & 0xFFFFu) ? 2u
-                                                                             : 3u;
-          const uint32_t key = sc[t] & ~(1u << 23);
-          if (((pmask >> t) & 1u) && sc[t] && (best < 0 || key < bkey || (key == bkey && ci < bci)))
-            best = t, bh = sc[t], bkey = key, bci = ci, bmask = sm[t];
-        }
-        if (best < 0) {
-          pdone = true;
-          break;
-        }
-        bool flushed = false;
-        if (field_queried(bmask, bh)) {
-          const uint32_t hf = bh >> 24, hpos = bh & 0x7FFFFFu;
-          if (hf != ofield) { // new field: both trackers start over
-            olen_l = olen_r = 0;
-            if (bci == 0) {
-              ol0 = bh, olen_l = 1, opos_l = hpos + 1u;
-              ofield = hf;
-            }
-          } else if (bci == olen_l && hpos >= opos_l) { // it extends the longest run
-            if (bci == 0) ol0 = bh;
-            if (bci == 1) ol1 = bh;
-            if (bci == 2) ol2 = bh;
-            if (bci == 3) ol3 = bh;
-            ++olen_l, opos_l = hpos + 1u;
-            if (olen_l == C.nph) {
-              oe0 = ol0, oe1 = ol1, oe2 = ol2, oe3 = ol3;
-              opend_n = olen_l, opend_i = 1;
-              olen_l = olen_r = 0;
-              opos_r = opos_l;
-              flushed = true;
-            }
-          } else if (bci == 0) { // it restarts the most recent run
-            or0 = bh, olen_r = 1, opos_r = hpos + 1u;
-            if (!olen_l) ol0 = bh, olen_l = 1, opos_l = hpos + 1u;
-          } else if (bci == olen_r && hpos >= opos_r) { // it extends the most recent run
-            if (bci == 1) or1 = bh;
-            if (bci == 2) or2 = bh;
-            if (bci == 3) or3 = bh;
-            ++olen_r, opos_r = hpos + 1u;
-            if (olen_r == olen_l) { // which just became the longest
-              ol0 = or0, ol1 = or1, ol2 = or2, ol3 = or3;
-              olen_r = 0;
-              opos_l = opos_r;
-            }
-          }
-        }
-        {
-          uint64_t ap = best == 0 ? sp[0] : best == 1 ? sp[1] : best == 2 ? sp[2] : sp[3];
-          uint32_t ac = best == 0 ? sc[0] : best == 1 ? sc[1] : best == 2 ? sc[2] : sc[3];
-          hit_advance(C.spp, ap, ac);
-          if (C.termpos) {
-            const uint32_t ak = best == 0 ? tpk[0] : best == 1 ? tpk[1] : best == 2 ? tpk[2] : tpk[3];
-            const uint32_t am = best == 0 ? tpm[0] : best == 1 ? tpm[1] : best == 2 ? tpm[2] : tpm[3];
-            while (ac && !tp_accept(ak, am, ac)) hit_advance(C.spp, ap, ac);
-          }
-#pragma unroll
-          for (int t = 0; t < MAX_PROX_TERMS; ++t)
-            if (t == best) sp[t] = ap, sc[t] = ac;
-        }
-        if (flushed) {
-          phave = true;
-          pcur = oe0 & ~(1u << 23), pend_is_end = ((oe0 >> 23) & 1u) != 0;
-          pq = C.ap0 & 0xFFFFu;
-          pw = 1u, pspan = 0u;
-          pfield = oe0 >> 24;
-          break;
-        }
-      }
-      if (first) {
-        ph_found = phave;
-        ph_field = pfield;
-        first = false;
-      }
-    }
-    if (!pdone && !phave && !C.order) { // pull the next occurrence out of the phrase's word streams
-      for (;;) {
-        int best = -1;
-        uint32_t bh = 0, bq = 0, bmask = 0;
-#pragma unroll
-        for (int t = 0; t < MAX_PROX_TERMS; ++t) // the phrase's top ExtAnd_c orders equal positions by DESCENDING qpos
-          if (((pmask >> t) & 1u) && sc[t] && (best < 0 || sc[t] < bh || (sc[t] == bh && sq[t] > bq)))
-            best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
-        if (best < 0) {
-          pdone = true;
-          break;
-        }
-        const uint32_t hp = bh & ~(1u << 23);
-        bool emit = false;
-        uint32_t e_pos = hp - span, e_w = nph, e_span = span; // exact phrase: first word's position, word count, span
-        if (field_queried(bmask, bh))
-          emit = C.px_dist ? F.step_prox(hp, bq & 0xFFFFu, nph, C.ap0 & 0xFFFFu, span, C.px_dist, e_pos, e_w, e_span)
-                           : F.step(hp, bq & 0xFFFFu, nph, C.ap0, C.ap1, C.ap2, C.ap3);
-        { // advance the chosen stream: one decode for the wave, whatever stream each lane picked
-          uint64_t ap = best == 0 ? sp[0] : best == 1 ? sp[1] : best == 2 ? sp[2] : sp[3];
-          uint32_t ac = best == 0 ? sc[0] : best == 1 ? sc[1] : best == 2 ? sc[2] : sc[3];
-          hit_advance(C.spp, ap, ac);
-#pragma unroll
-          for (int t = 0; t < MAX_PROX_TERMS; ++t)
-            if (t == best) sp[t] = ap, sc[t] = ac;
-        }
-        if (emit) {
-          phave = true;
-          pcur = e_pos, pw = e_w, pspan = e_span;
-          pfield = (bh >> 24) & 31u;
-          break;
-        }
-      }
-      if (first) {
-        ph_found = phave;
-        ph_field = pfield;
-        first = false;
-      }
-    }
-    if (!rank) break;
-    if (phase == 0 && !(sc[0] && sc[1] && sc[2])) {
-      if (!sc[0])
-        tl = 1, tr = 2;
-      else if (!sc[1])
-        tl = 0, tr = 2;
-      else
-        tl = 0, tr = 1;
-      phase = 1;
-    }
-    if (phase == 1) {
-      const uint32_t cl = tl == 0 ? sc[0] : sc[1], cr = tr == 1 ? sc[1] : sc[2];
-      if (!(cl && cr)) phase = 2;
-    }
-    int best = -1;
-    uint32_t bh = 0, bq = 0, bmask = 0;
-#pragma unroll
-    for (int t = 0; t < MAX_PROX_TERMS; ++t)
-      if (((dmask >> t) & 1u) && sc[t] &&
-          (best < 0 || (sc[t] & cmpmask) < (bh & cmpmask) || ((sc[t] & cmpmask) == (bh & cmpmask) && sq[t] < bq)))
-        best = t, bh = sc[t], bq = sq[t], bmask = sm[t];
-    // (a BEFORE node hands on plain hits: against its siblings they order by the raw position, end flag included)
-    const uint32_t pkey = pcur | (pend_is_end ? 1u << 23 : 0u);
-    if (phave && (best < 0 || pkey < bh || (pkey == bh && pq < (bq & 0xFFFFu)))) {
-      X.update(C.ranker, C.dupes, pcur, pend_is_end, pq, pw, pspan, C.w_of, C.max_qpos);
-      phave = false;
-      continue;
-    }
-    if (best < 0) break;
-    if (phase == 1) bmask = best == tl ? sm[0] : sm[1];
-    // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
-    if (field_queried(bmask, bh))
-      X.update(C.ranker, C.dupes, bh & ~(1u << 23), ((bh >> 23) & 1u) != 0, bq & 0xFFFFu, 1u, 0u, C.w_of, C.max_qpos);
-    { // advance the chosen stream: one decode for the wave, whatever stream each lane picked
-      uint64_t ap = best == 0 ? sp[0] : best == 1 ? sp[1] : best == 2 ? sp[2] : sp[3];
-      uint32_t ac = best == 0 ? sc[0] : best == 1 ? sc[1] : best == 2 ? sc[2] : sc[3];
-      hit_advance(C.spp, ap, ac);
-      if (C.termpos) {
-        const uint32_t ak = best == 0 ? tpk[0] : best == 1 ? tpk[1] : best == 2 ? tpk[2] : tpk[3];
-        const uint32_t am = best == 0 ? tpm[0] : best == 1 ? tpm[1] : best == 2 ? tpm[2] : tpm[3];
-        while (ac && !tp_accept(ak, am, ac)) hit_advance(C.spp, ap, ac);
-      }
-#pragma unroll
-      for (int t = 0; t < MAX_PROX_TERMS; ++t)
-        if (t == best) sp[t] = ap, sc[t] = ac;
-    }
-  }
-  if (rank) rk_out = X.finalize(C.ranker, C.nw, C.Q->weights, C.w_of, C.n_qwords);
-  if (F.over) atomicOr(C.flags, QF_FSM);
-}
-
-// ExtConditional_T::GetDocsChunk (searchnode.cpp:2332-2405): the keyword holds the doc iff one of its hits -- inside the
-// keyword's field limit -- is acceptable.  ref = where the doc sits in the keyword's packed arrays (as for hit_pass).
-__device__ __forceinline__ bool termpos_any(const HitCtx& C, const DevTerm& Tt, uint32_t ref) {
-  const uint32_t gblk = Tt.blk_first + ((ref >> 7) & 0xFFFFFFu), idx = ref & 127u;
-  const uint32_t hv = C.hit[(uint64_t)gblk * DEVBLK + idx];
-  uint64_t sp = 0;
-  uint32_t sc = 0;
-  if (ref >> 31)
-    sc = hv;
-  else {
-    sp = C.hbase[gblk] + hv;
-    hit_advance(C.spp, sp, sc);
-  }
-  while (sc) {
-    if (field_queried(Tt.queried32, sc) && tp_accept(Tt.tp_kind, Tt.tp_max, sc)) return true;
-    hit_advance(C.spp, sp, sc);
-  }
-  return false;
-}
-
 // EXT: the batch holds queries with position modifiers, a BEFORE node or attribute filters; batches without them run the
 // leaner instance (the extra code costs the three-keyword proximity mixes ~7 % even when it never executes)
 template <bool PROX, bool TREE, bool EXT = false>
@@ -729,7 +146,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const uint32_t req_mask = TREE ? Q->req_mask : 0u, excl_mask = TREE ? Q->excl_mask : 0u;
   const uint32_t n_nodes = TREE ? Q->n_nodes : 0u;
   const bool phrase = PROX && (Q->tree_flags & TF_PHRASE) != 0;                // the whole query is one PHRASE
-  const bool ph_leaf = TREE && PROX && (Q->tree_flags & TF_PHRASE_LEAF) != 0; // a PHRASE below other operators
+  const bool ph_leaf = EXT && TREE && PROX && (Q->tree_flags & TF_PHRASE_LEAF) != 0; // a PHRASE below other operators
   const uint32_t ph_mask = ph_leaf ? Q->ph_mask : 0u;                         // its words' keyword slots
   const uint32_t ph_n = !PROX ? 0u : phrase ? nterms : (uint32_t)__popc(ph_mask);
   const uint32_t ph_span = !PROX || ph_n < 2 ? 0u : Q->ph_atoms[ph_n - 1] - Q->ph_atoms[0];
@@ -868,8 +285,40 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
     }
   };
 
-  // hit pass over queued matches [from, from + n), n <= 64, one per lane
+  // Matched docs of hit-ranked queries leave through the HBM match queue (rank_kernel, mrk_rank.hip): 64 entries per
+  // chunk, one coalesced 256-B row per plane.  Queries with PHRASE / PROXIMITY / BEFORE nodes or position modifiers go to
+  // the second queue, whose consumer carries the word state machines.
   uint32_t mqn = 0;
+  const bool fat_q = (Q->tree_flags & (TF_PHRASE | TF_PHRASE_LEAF | TF_TERMPOS | TF_ORDER)) != 0;
+  auto flush_matches = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
+    if (!PROX) return;
+    wave_lds_fence();
+    const MatchQueue& MQ = a.mq[fat_q ? 1 : 0];
+    // a chunk from the workgroup's own shard, else from the next shard that still has room (together the shards hold
+    // every chunk the batch can produce; a single busy workgroup may need more than its own shard's share)
+    uint32_t c = 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < (uint32_t)MQ_SHARDS && c == 0xFFFFFFFFu; ++k) {
+      const uint32_t shard = (blockIdx.x + k) & (MQ_SHARDS - 1);
+      uint32_t got = 0;
+      if (lane == 0) got = atomicAdd(MQ.count + shard, 1u);
+      got = rdlane(got, 0);
+      if (got < MQ.cap) c = shard * MQ.cap + got;
+    }
+    if (c != 0xFFFFFFFFu) {
+      uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+      const uint32_t e = from + lane; // (entries past n are stale slots; the header's count masks them)
+      d[0] = L.mq_row[e];
+      d[64] = __float_as_uint(L.mq_acc[e]);
+      d[128] = L.mq_fa[e];
+#pragma unroll
+      for (int t = 0; t < MAX_PROX_TERMS; ++t) d[192 + 64 * t] = L.mq_ref[t][e];
+      if (lane == 0) MQ.hdr[c] = item.query | (n << 24);
+    } else if (lane == 0)
+      atomicOr(a.q_flags + oq, QF_OVERFLOW); // the host reruns the query alone with a queue sized for all its driver docs
+    wave_lds_fence(); // the slots may be refilled from here on
+  };
+  // in-scan hit reading (EXT instance only): does a PHRASE / BEFORE node below other operators occur in the doc, does a
+  // keyword with a position modifier hold it
   HitCtx HC;
   HC.Q = Q;
   HC.spp = a.seg.spp;
@@ -881,7 +330,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   HC.nph = ph_n, HC.span = ph_span;
   HC.px_dist = PROX ? Q->px_dist : 0u;
   HC.ranker = ranker;
-  HC.w_of = s.rank;
+  HC.fw = Q->weights; // (never read here: the in-scan passes do not rank)
   HC.max_qpos = (int)Q->max_qpos, HC.n_qwords = (int)Q->n_qwords;
   HC.inline_hits = inline_hits, HC.multi_and = multi_and;
   HC.quorum_hits = (Q->tree_flags & TF_QUORUM_HITS) != 0;
@@ -889,32 +338,6 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   HC.order = EXT && PROX && TREE && (Q->tree_flags & TF_ORDER) != 0;
   HC.apack = (uint64_t)(ap0 & 0xFFFFu) | ((uint64_t)(ap1 & 0xFFFFu) << 16) | ((uint64_t)(ap2 & 0xFFFFu) << 32) | ((uint64_t)(ap3 & 0xFFFFu) << 48);
   HC.dupes = (Q->tree_flags & TF_DUPES) != 0 && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY);
-  auto drain_hits = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
-    if (!PROX) return;
-    wave_lds_fence();
-    const bool valid = lane < n;
-    const uint32_t e = from + (valid ? lane : 0u);
-    const uint32_t rowid = L.mq_row[e], fa = L.mq_fa[e];
-    const float tfidf = L.mq_acc[e];
-    const uint32_t r0 = L.mq_ref[0][e], r1 = L.mq_ref[1][e], r2 = L.mq_ref[2][e], r3 = L.mq_ref[3][e];
-    wave_lds_fence(); // the slots may be refilled from here on
-    bool is_live = valid;
-    uint32_t fields = fa & 0xffu;
-    int rk = 0;
-    if (valid) {
-      const uint32_t all_slots = (1u << (nterms < (uint32_t)MAX_PROX_TERMS ? nterms : (uint32_t)MAX_PROX_TERMS)) - 1u;
-      const uint32_t smask = (fa >> 8) & all_slots;
-      const uint32_t pmask = phrase ? all_slots : (ph_leaf && (smask & ph_mask) == ph_mask) ? ph_mask : 0u;
-      bool found = false;
-      uint32_t ffield = 0;
-      hit_pass(HC, r0, r1, r2, r3, smask, pmask, prox_ranker, found, ffield, rk);
-      if (phrase) {
-        is_live = found;
-        fields = 1u << ffield; // the doc's field mask comes from its first occurrence (searchnode.cpp:3836)
-      }
-    }
-    emit_match(is_live, rowid, tfidf, fields, rk);
-  };
 
   for (uint32_t b = wb0; b < wb1; ++b) {
     {
@@ -1226,7 +649,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       }
 
       // ---- keywords with a position modifier: the doc holds them only through an acceptable hit
-      if (TREE && PROX && HC.termpos && __ballot(live[0] || live[1])) {
+      if (EXT && TREE && PROX && HC.termpos && __ballot(live[0] || live[1])) {
         wave_lds_fence();
         for (uint32_t j = 0; j < nterms && j < (uint32_t)MAX_PROX_TERMS; ++j) {
           const DevTerm& Tj = Q->t[j];
@@ -1248,7 +671,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       // ---- a PHRASE below other operators: whether it occurs has to be known before the tree is evaluated
       bool ph_ok[2] = {false, false};
       uint32_t ph_fld[2] = {0u, 0u};
-      if (TREE && PROX && ph_leaf && __ballot(live[0] || live[1])) {
+      if (EXT && TREE && PROX && ph_leaf && __ballot(live[0] || live[1])) {
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -1400,7 +823,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
             }
             mqn += (uint32_t)__popcll(bal);
             if (mqn >= 64u) {
-              drain_hits(mqn - 64u, 64u);
+              flush_matches(mqn - 64u, 64u);
               mqn -= 64u;
             }
           }
@@ -1411,7 +834,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
       }
     }
   }
-  if (PROX && mqn) drain_hits(0u, mqn);
+  if (PROX && mqn) flush_matches(0u, mqn);
 
   // ---- wave epilogue
   if (cn) publish();
