@@ -191,6 +191,9 @@ void mrk_ctx_destroy(mrk_ctx* ctx);
    28 % fewer bytes per dense x dense query, +14 % queries/s on the 100 M-doc bench, +1 byte per posting; default 0 --
    see DESIGN.md section 6; read at segment load);
    "bm_target_items" (work items per launch the bitmap kernel's window ranges are cut into, default 6144);
+   "bt_cover_inv" (boolean trees whose candidate cover -- the keywords whose doc lists together hold every possible match --
+   names >= 1/bt_cover_inv of the segment's docs are evaluated on doc-set bitmap words, 2048 rowids per step, instead of
+   block by block; default 32, 0 = never; read at submit);
    "mq_max_chunks" (cap of a batch's match queue -- matched docs of hit-ranked queries on their way to the ranking kernel -- in
    chunks of 64 docs / 1792 bytes, default 2^20; queries that outgrow it are rerun one by one by mrk_batch_wait);
    returns MRK_E_INVAL for unknown keys */

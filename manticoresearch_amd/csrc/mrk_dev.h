@@ -97,6 +97,7 @@ constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT =
 constexpr int QUORUM_EVENTS = 8; // keywords of a quorum node = doclists that can run dry and reorder its children
 constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
 constexpr uint32_t TF_BITMAP = 4;   // 2-keyword AND answered by the bitmap kernel (items are window ranges)
+constexpr uint32_t TF_BTREE = 256;  // boolean tree evaluated on bitmap words by the window-driven tree kernel (items are window ranges)
 constexpr uint32_t TF_ORDER = 128;      // the TF_PHRASE_LEAF node is a BEFORE operator (ExtOrder_c) over the keywords of ph_mask
 constexpr uint32_t TF_TERMPOS = 64;     // some keyword carries a position modifier (ExtTermPos_T)
 constexpr uint32_t TF_QUORUM_HITS = 32; // the root is an ExtQuorum_c: its hits sort by position WITHOUT the end flag
@@ -167,9 +168,9 @@ struct DevQuery {
 
 struct DevItem {
   uint32_t query;
-  uint32_t blk_begin; // driver-term block range [begin, end)
+  uint32_t blk_begin; // driver-term block range [begin, end); window range for the bitmap-driven kernels
   uint32_t blk_end;
-  uint32_t pad;
+  uint32_t kind;      // window-range items: 0 = scan_bm_kernel, 1 = scan_bt_kernel
 };
 
 // candidate key: bigger = better under MatchRelevanceLt_fn (weight desc, rowid asc)
@@ -254,6 +255,7 @@ void launch_scan(const ScanArgs& a, void* stream);
 void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, bool ext, void* stream);
 constexpr int MAX_PROX_TERMS = MAX_PROX_TERMS_; // keywords whose hit streams the hit kernel merges per doc
 void launch_scan_bm(const ScanArgs& a, void* stream); // a.items: (query, window range) work items
+void launch_scan_bt(const ScanArgs& a, void* stream); // the same for TF_BTREE passes (mrk_scan_bt.hip)
 // final ranking of the queued matches (mrk_rank.hip): a persistent grid drains queue `which` of a.mq
 void launch_rank(const ScanArgs& a, int which, void* stream);
 void launch_select(const SelectArgs& a, void* stream);

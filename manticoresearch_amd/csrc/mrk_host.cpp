@@ -222,6 +222,11 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
     c->bm_target_items = (int)value;
     return MRK_OK;
   }
+  if (!strcmp(key, "bt_cover_inv")) {
+    if (value < 0 || value > (1 << 20)) return mrk_fail(MRK_E_INVAL, "bt_cover_inv must be 0 (off) .. 2^20");
+    c->bt_cover_inv = (int)value;
+    return MRK_OK;
+  }
   if (!strcmp(key, "mq_max_chunks")) {
     if (value < 1 || value > (1 << 24)) return mrk_fail(MRK_E_INVAL, "mq_max_chunks must be 1 .. 2^24");
     c->mq_max_chunks = (int)value;
@@ -750,6 +755,18 @@ static bool pass_queues_matches(const DevQuery& P, bool& fat) {
   return prox_ranker || (P.tree_flags & mrk::TF_PHRASE) != 0;
 }
 
+// upper bound of the docs a pass can match: its driver's docs; the common docs for the two-bitmap AND; any keyword's docs for
+// a tree evaluated on bitmap words
+static uint64_t pass_max_matches(const DevQuery& P) {
+  if (P.tree_flags & mrk::TF_BITMAP) return std::min<uint64_t>(P.t[0].docs, P.t[1].docs);
+  if (P.tree_flags & mrk::TF_BTREE) {
+    uint64_t d = 0;
+    for (uint32_t k = 0; k < P.n_terms && k < (uint32_t)MRK_MAX_AND_TERMS; ++k) d += P.t[k].docs;
+    return d;
+  }
+  return P.t[0].docs;
+}
+
 // size the batch's match queues for `chunks[q]` chunks (0 = queue unused) and point the scan arguments at them
 static int bind_match_queues(mrk_batch* b, const uint64_t chunks[2], mrk::ScanArgs& sa) {
   for (int i = 0; i < 2; ++i) {
@@ -813,32 +830,46 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;
   }
-  // match queues: a pass hands over at most one entry per driver doc, plus one partial chunk per wave of its items
-  uint64_t mq_chunks[2] = {0, 0};
-  if (use_packed && any_prox) {
-    auto account = [&](const DevQuery& P) {
-      bool fat = false;
-      if (P.n_items && pass_queues_matches(P, fat)) mq_chunks[fat ? 1 : 0] += (uint64_t)P.t[0].docs / 64 + 4ull * P.n_items + 1;
-    };
-    for (uint32_t i = 0; i < n; ++i) account(b->h_queries.p[i]);
-    for (const DevQuery& P : extra) account(P);
-    for (int i = 0; i < 2; ++i) mq_chunks[i] = std::min<uint64_t>(mq_chunks[i], (uint64_t)b->ctx->mq_max_chunks);
-  }
   const float plan_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count();
   const size_t n_items_pk = items.size();
-  if (!items_bm.empty()) { // bitmap work items ride behind the block work items
+  // window-range work items (two-bitmap AND kernel, then the window-driven tree kernel) ride behind the block work
+  // items; each kind's whole-range entries are cut once the batch's total is known (a wave's fixed costs -- tables, final
+  // publish, atomics on the query's counters -- want long runs of windows)
+  size_t n_items_kind[2] = {0, 0};
+  for (uint32_t kind = 0; kind < 2; ++kind) {
     uint64_t total_win = 0;
-    for (const DevItem& it : items_bm) total_win += it.blk_end - it.blk_begin;
+    for (const DevItem& it : items_bm)
+      if (it.kind == kind) total_win += it.blk_end - it.blk_begin;
+    if (!total_win) continue;
     const uint64_t unit = 4 * WAVES; // one burst per wave
     uint64_t wpi = (total_win / (uint64_t)b->ctx->bm_target_items / unit) * unit;
     wpi = std::min<uint64_t>(std::max<uint64_t>(wpi, 4 * unit), 4096);
+    const size_t before = items.size();
     for (const DevItem& whole : items_bm)
-      for (uint64_t w = whole.blk_begin; w < whole.blk_end; w += wpi) {
-        DevItem it = whole;
-        it.blk_begin = (uint32_t)w;
-        it.blk_end = (uint32_t)std::min<uint64_t>(whole.blk_end, w + wpi);
-        items.push_back(it);
-      }
+      if (whole.kind == kind)
+        for (uint64_t w = whole.blk_begin; w < whole.blk_end; w += wpi) {
+          DevItem it = whole;
+          it.blk_begin = (uint32_t)w;
+          it.blk_end = (uint32_t)std::min<uint64_t>(whole.blk_end, w + wpi);
+          items.push_back(it);
+        }
+    n_items_kind[kind] = items.size() - before;
+  }
+  // match queues: a pass hands over at most one entry per doc it can match, plus one partial chunk per wave of its items
+  uint64_t mq_chunks[2] = {0, 0};
+  if (use_packed && any_prox) {
+    bool bt_feeds = false;
+    auto account = [&](const DevQuery& P) {
+      bool fat = false;
+      if (!P.n_items || !pass_queues_matches(P, fat)) return;
+      const bool bt = (P.tree_flags & mrk::TF_BTREE) != 0;
+      mq_chunks[fat ? 1 : 0] += pass_max_matches(P) / 64 + (bt ? 0 : 4ull * P.n_items) + 1;
+      bt_feeds = bt_feeds || bt;
+    };
+    for (uint32_t i = 0; i < n; ++i) account(b->h_queries.p[i]);
+    for (const DevQuery& P : extra) account(P);
+    if (bt_feeds) mq_chunks[0] += 4ull * n_items_kind[1]; // (its work items were only cut just now)
+    for (int i = 0; i < 2; ++i) mq_chunks[i] = std::min<uint64_t>(mq_chunks[i], (uint64_t)b->ctx->mq_max_chunks);
   }
   const size_t n_items_bm = items.size() - n_items_pk;
   const size_t n_items = items.size();
@@ -895,13 +926,19 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
   if (use_packed) {
     launch_scan_pk(sa, max_terms, any_prox, any_tree, any_ext, st);
-    // the queued matches of hit-ranked queries: hit pass + state rankers (mrk_rank.hip), behind the scan on the same stream
+    if (n_items_kind[1]) { // before the rank kernels: it feeds the match queue too
+      ScanArgs sb = sa;
+      sb.items = b->d_items.p + n_items_pk + n_items_kind[0];
+      sb.n_items = (uint32_t)n_items_kind[1];
+      launch_scan_bt(sb, st);
+    }
+    // the queued matches of hit-ranked queries: hit pass + state rankers (mrk_rank.hip), behind the scans on the same stream
     if (mq_chunks[0]) launch_rank(sa, 0, st);
     if (mq_chunks[1]) launch_rank(sa, 1, st);
-    if (n_items_bm) {
+    if (n_items_kind[0]) {
       ScanArgs sb = sa;
       sb.items = b->d_items.p + n_items_pk;
-      sb.n_items = (uint32_t)n_items_bm;
+      sb.n_items = (uint32_t)n_items_kind[0];
       launch_scan_bm(sb, st);
     }
   } else
@@ -1001,27 +1038,29 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   for (uint32_t e = b->n_queries; e < b->n_pass; ++e)
     if (b->h_queries.p[e].out_q == qi) passes.push_back(b->h_queries.p[e]);
   uint64_t cap = 0;
-  for (const DevQuery& p : passes) cap += (p.tree_flags & TF_BITMAP) ? std::min<uint64_t>(p.t[0].docs, p.t[1].docs) : p.t[0].docs;
+  for (const DevQuery& p : passes) cap += pass_max_matches(p);
   cap = std::max<uint64_t>(cap, 1);
   if (cap > 0xFFFFFFF0ull) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: candidate list overflowed", qi);
-  std::vector<DevItem> items_pk, items_bm;
+  std::vector<DevItem> items_pk, items_bm, items_bt;
   for (size_t p = 0; p < passes.size(); ++p) {
     DevQuery& P = passes[p];
     P.out_q = 0;
     P.cand_off = 0;
     P.cand_cap = (uint32_t)cap;
-    const bool bm = (P.tree_flags & TF_BITMAP) != 0;
-    const uint32_t n = bm ? seg->dev.n_windows : P.t[0].nblocks, step = bm ? 1024u : 256u;
+    const bool bm = (P.tree_flags & TF_BITMAP) != 0, bt = (P.tree_flags & TF_BTREE) != 0;
+    const uint32_t n = (bm || bt) ? seg->dev.n_windows : P.t[0].nblocks, step = (bm || bt) ? 1024u : 256u;
     for (uint32_t x = 0; x < n; x += step) {
       DevItem it{};
       it.query = (uint32_t)p;
       it.blk_begin = x;
       it.blk_end = std::min(n, x + step);
-      (bm ? items_bm : items_pk).push_back(it);
+      it.kind = bt ? 1u : 0u;
+      (bm ? items_bm : bt ? items_bt : items_pk).push_back(it);
     }
   }
-  const size_t n_pk = items_pk.size();
+  const size_t n_pk = items_pk.size(), n_bm = items_bm.size(), n_bt = items_bt.size();
   items_pk.insert(items_pk.end(), items_bm.begin(), items_bm.end());
+  items_pk.insert(items_pk.end(), items_bt.begin(), items_bt.end());
   const size_t n_items = items_pk.size();
   int rc;
   if ((rc = r->h_queries.reserve(passes.size())) || (rc = r->d_queries.reserve(passes.size())) || (rc = r->h_items.reserve(n_items + 1)) ||
@@ -1048,20 +1087,26 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
     uint64_t chunks[2] = {0, 0};
     for (size_t p = 0; p < passes.size(); ++p) {
       bool fat = false;
-      if (pass_queues_matches(passes[p], fat)) chunks[fat ? 1 : 0] += (uint64_t)passes[p].t[0].docs / 64 + 4ull * n_items + 1;
+      if (pass_queues_matches(passes[p], fat)) chunks[fat ? 1 : 0] += pass_max_matches(passes[p]) / 64 + 4ull * n_items + 1;
     }
     for (int i = 0; i < 2; ++i)
       if (chunks[i] > (1ull << 25)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: match queue for the rerun too large", qi);
     if ((rc = bind_match_queues(r, chunks, sa))) return rc;
     if (chunks[0] || chunks[1]) HIP_TRY(hipMemsetAsync(r->d_mq_count.p, 0, 2 * mrk::MQ_SHARDS * 4, st));
     launch_scan_pk(sa, b->last_max_terms, b->last_prox, b->last_tree, b->last_ext, st);
+    if (n_bt) {
+      ScanArgs sb = sa;
+      sb.items = r->d_items.p + n_pk + n_bm;
+      sb.n_items = (uint32_t)n_bt;
+      launch_scan_bt(sb, st);
+    }
     if (chunks[0]) launch_rank(sa, 0, st);
     if (chunks[1]) launch_rank(sa, 1, st);
   }
-  if (n_items > n_pk) {
+  if (n_bm) {
     ScanArgs sb = sa;
     sb.items = r->d_items.p + n_pk;
-    sb.n_items = (uint32_t)(n_items - n_pk);
+    sb.n_items = (uint32_t)n_bm;
     launch_scan_bm(sb, st);
   }
   SelectArgs se{};

@@ -26,6 +26,7 @@ struct mrk_ctx {
   int bitmap_inv = 64;            // terms in >= 1/bitmap_inv of the docs also get a bitmap (0 = never)
   int attr_nibbles = 0;           // also build the one-byte tf/field plane the bitmap kernel can gather from (<= 4 fields)
   int bm_target_items = 6144;     // bitmap kernel: work items per launch the window ranges are cut into
+  int bt_cover_inv = 32;          // trees whose candidate cover holds >= 1/bt_cover_inv of the docs run on bitmap words (0 = never)
   int mq_max_chunks = 1 << 20;    // cap of a batch's match queue, in 64-entry chunks of 1792 B (a fuller queue flags its queries: rerun alone)
 };
 

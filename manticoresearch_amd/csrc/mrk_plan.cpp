@@ -647,6 +647,55 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     return MRK_OK;
   }
 
+  // A tree whose candidate cover is a common keyword: evaluate it on bitmap words, 2048 rowids per step, instead of
+  // walking the cover's docs block by block (mrk_scan_bt.hip).  Needs every keyword unrestricted in fields (a bitmap bit
+  // is then "the keyword holds the doc"); sparse keywords are fine, their window words are assembled from a block cursor.
+  {
+    const uint32_t all_fields = seg->n_fields >= 32 ? 0xFFFFFFFFu : (1u << seg->n_fields) - 1u;
+    bool ok = use_packed && seg->dev.bm && seg->ctx->bitmap_inv > 0 && seg->ctx->bt_cover_inv > 0 && !T.phrase && !T.ph_leaf && !T.quorum && !T.order &&
+              !T.termpos && q.n_filters == 0 && n <= MAX_PROX_TERMS && seg->total_docs < (1ull << 32) && T.nodes.size() <= 16;
+    uint64_t cover_docs = 0;
+    for (int k : cover) cover_docs += (uint64_t)T.kws[k].docs;
+    ok = ok && cover_docs * (uint64_t)seg->ctx->bt_cover_inv >= seg->total_docs;
+    int n_dense = 0;
+    for (int k = 0; ok && k < n; ++k) {
+      ok = (T.kws[k].queried32 & all_fields) == all_fields;
+      if (T.kws[k].docs && seg->terms[T.kws[k].term_id].bm_off != ~0ull) ++n_dense;
+    }
+    if (ok && pure_and) { // (the tree program of a pure AND is its left-deep chain: at most two values on the stack)
+      int sp = 0, deep = 0;
+      for (const PlanNode& pn : T.nodes) sp += pn.op == PN_TERM ? 1 : -1, deep = std::max(deep, sp);
+      ok = deep <= TREE_STACK;
+    }
+    if (ok && n_dense > 0) {
+      dq.n_terms = (uint32_t)n;
+      for (int i = 0; i < n; ++i) fill_term(seg, T.kws[i], dq.t[i]);
+      dq.tree_flags = (pure_and ? TF_MULTIAND : 0) | (got_dupes ? TF_DUPES : 0) | TF_BTREE;
+      dq.n_nodes = (uint32_t)T.nodes.size();
+      for (size_t i = 0; i < T.nodes.size(); ++i) {
+        const PlanNode& pn = T.nodes[i];
+        dq.prog[i] = pn.op | ((uint32_t)(pn.l < 0 ? 0 : pn.l) << 8) | ((uint32_t)(pn.r < 0 ? 0 : pn.r) << 16) | ((uint32_t)(pn.kw < 0 ? 0 : pn.kw) << 24);
+      }
+      dq.item_first = (uint32_t)items_bm.size();
+      const uint64_t nwin = seg->dev.n_windows;
+      uint64_t bt_bytes = 0; // bitmaps of the dense keywords + packed blocks of the sparse ones + every keyword's tf / field words
+      for (int k = 0; k < n; ++k)
+        if (T.kws[k].docs) {
+          const HostTerm& h = seg->terms[T.kws[k].term_id];
+          bt_bytes += h.bm_off != ~0ull ? nwin * 256 + (uint64_t)h.nblocks * 256 : h.packed_bytes;
+        }
+      dev_bytes += bt_bytes - pbytes; // (pbytes was added above)
+      DevItem it{};
+      it.query = qi;
+      it.blk_begin = 0;
+      it.blk_end = (uint32_t)nwin;
+      it.kind = 1;
+      items_bm.push_back(it);
+      dq.n_items = 1;
+      return MRK_OK;
+    }
+  }
+
   const DevQuery base = dq;
   for (size_t p = 0; p < cover.size(); ++p) {
     DevQuery* P = &dq;

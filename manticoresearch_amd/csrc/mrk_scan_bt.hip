@@ -1,0 +1,423 @@
+// mrk_scan_bt.hip -- boolean trees evaluated over doc-set BITMAP WORDS, gfx950 / wave64.
+//
+// The block-scan kernel walks the docs of a tree's candidate cover one by one.  When that cover is a common keyword --
+// '(a | b) c' with b and c in millions of docs -- it decodes tens of thousands of driver blocks per query and probes
+// the other keywords once per doc.  Here the same ExtAnd_c / ExtOr_c / ExtMaybe_c / ExtAndNot_c tree
+// (searchnode.cpp:2570-2706, 3465-3694) is evaluated 32 rowids at a time:
+//
+//   window = 2048 rowids, lane l holds rowids [32 l, 32 l + 32) of it as one word per keyword:
+//     dense keyword   word l of its doc-set bitmap (one coalesced 256-B load per window, as in scan_bm_kernel);
+//     sparse keyword  assembled on the fly: a cursor walks the keyword's packed blocks (2 docs per lane in registers),
+//                     docs that fall into the window set their bit through an LDS word per lane;
+//   the tree program runs on those words (AND = &, OR = |, ANDNOT = & ~, MAYBE = its left side) and leaves the window's
+//   matches as bits.  A match's slot in each present keyword's packed arrays is its RANK in that keyword's doc list:
+//   docs before the window (rank directory / cursor, then a running count) + popcounts of the lower lanes' words (one
+//   packed wave prefix sum per two keywords) + popcount of the lower bits of the lane's own word.
+//
+// Matches are queued per wave in LDS (rowid, present keywords, one rank per keyword) and scored 64 at a time with
+// every lane busy: tf / field bytes gathered by rank, the tree's VALUE rules (tfidf sums in the reference's fp32
+// order, field masks, which keywords' hits a match emits) on a per-lane stack exactly as in scan_pk_kernel, then either
+// the weight-sum rankers + pruning histogram right here, or -- hit-reading rankers -- a 64-doc chunk written straight
+// from registers into the HBM match queue for rank_kernel.
+//
+// Only queries whose keywords are unrestricted in fields come here (a bitmap bit then IS "the keyword holds the doc",
+// searchnode.cpp:1925-1939); the planner keeps everything else on the block path.
+#include "mrk_kcommon.h"
+#include "mrk_kprune.h"
+#include "mrk_kpk.h"
+
+namespace mrk {
+
+constexpr int BT_KW = MAX_PROX_TERMS; // keywords per query on this path
+constexpr int BT_CBUF = 128;          // candidates a wave collects before it publishes them
+constexpr int BT_QCAP = 128;          // match queue entries per wave (scored in batches of 64)
+constexpr int BT_WORDS = 64;          // words per window
+
+struct __align__(16) BtWaveLds {
+  uint64_t cbuf[BT_CBUF];
+  uint32_t q_row[BT_QCAP];
+  uint32_t q_pm[BT_QCAP]; // keywords present in the doc
+  uint32_t q_rank[BT_KW][BT_QCAP];
+  uint32_t abm[BT_KW][BT_WORDS]; // the window words of sparse keywords while they are assembled
+};
+
+struct __align__(16) BtSmem {
+  BtWaveLds w[WAVES];
+  uint32_t hist[NBINS]; // publishing scratch, one per workgroup behind hist_lock
+  uint32_t hist_lock;
+  uint32_t rank[256];
+  float tfidf[BT_KW][256];
+};
+
+// the two docs lane l owns of block kj of a keyword (rowids, INF past the block's end) and the first possible rowid of the
+// NEXT block (= this block's last rowid + 1; INF after the last block)
+__device__ __forceinline__ void bt_load_block(const DevSegment& seg, const DevTerm& T, uint32_t kj, uint32_t& e0, uint32_t& e1, uint32_t& bnext) {
+  const uint32_t lane = lane_id();
+  const uint32_t g = T.blk_first + kj;
+  const uint32_t bp1 = seg.pk_base[g], w = seg.pk_w[g];
+  const uint32_t* __restrict__ dp = seg.pk_delta + seg.pk_doff[g];
+  PkRaw raw;
+  raw.attr = 0;
+  if (w == PK_WIDE) {
+    raw.lo = dp[lane];
+    raw.hi = dp[64 + lane];
+  } else {
+    const uint32_t wi = (lane * 2 * w) >> 5;
+    raw.lo = dp[wi];
+    raw.hi = dp[wi + 1];
+  }
+  bnext = kj + 1 < T.nblocks ? seg.pk_base[g + 1] : INF_ROWID;
+  const uint32_t left = T.docs - kj * DEVBLK;
+  uint32_t r0, r1, o0, o1;
+  bool ok0, ok1;
+  decode_pk(raw, w, bp1, left < (uint32_t)DEVBLK ? left : (uint32_t)DEVBLK, r0, r1, o0, o1, ok0, ok1);
+  e0 = ok0 ? r0 : INF_ROWID;
+  e1 = ok1 ? r1 : INF_ROWID;
+}
+
+__global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
+  __shared__ BtSmem s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (blockIdx.x >= a.n_items) return;
+  const DevItem item = a.items[blockIdx.x];
+  const DevQuery* __restrict__ Q = a.queries + item.query;
+  const uint32_t nterms = Q->n_terms < (uint32_t)BT_KW ? Q->n_terms : (uint32_t)BT_KW;
+  const uint32_t K = Q->k, ranker = Q->ranker, oq = Q->out_q, n_nodes = Q->n_nodes;
+  const uint32_t nw = Q->n_weights < 8u ? Q->n_weights : 8u;
+  const uint32_t index_weight = Q->index_weight;
+  const bool inline_hits = a.seg.inline_hits != 0;
+  const bool need_hits = (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY)
+                             ? nterms > 1
+                             : (ranker == MRK_RANK_WORDCOUNT || ranker == MRK_RANK_MATCHANY || ranker == MRK_RANK_FIELDMASK ||
+                                ranker == MRK_RANK_SPH04);
+  BtWaveLds& L = s.w[wave];
+  for (uint32_t j = 0; j < nterms; ++j) s.tfidf[j][tid] = term_tfidf(tid, Q->t[j].idf);
+  {
+    uint32_t rk = 0;
+    if (!tid)
+      rk = 1; // empty mask: "just fake it" (sphinxsearch.cpp:1114-1118)
+    else
+      for (uint32_t f = 0; f < nw; ++f)
+        if (tid & (1u << f)) rk += (uint32_t)Q->weights[f];
+    s.rank[tid] = rk;
+    if (!tid) s.hist_lock = 0;
+  }
+  const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
+  const int32_t bin_lo = Q->bin_lo;
+  const uint32_t cand_cap = Q->cand_cap;
+  uint64_t* __restrict__ cand = a.cand + Q->cand_off;
+  uint32_t* __restrict__ ghist = a.q_hist + (uint64_t)oq * NBINS;
+  uint32_t* __restrict__ gcount = a.q_cand_n + oq;
+  uint32_t* __restrict__ gtaubin = a.q_tau_bin + oq;
+  const uint32_t* __restrict__ dead = a.seg.dead;
+  const uint32_t* __restrict__ attr = a.seg.pk_attr;
+
+  // the tree program, once (uniform values)
+  uint32_t prog[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) prog[i] = (uint32_t)i < n_nodes ? Q->prog[i] : 0u;
+
+  const uint32_t nwin = item.blk_end - item.blk_begin;
+  const uint32_t per = (nwin + WAVES - 1) / WAVES;
+  const uint32_t w0 = item.blk_begin + wave * per;
+  const uint32_t w1 = w0 + per < item.blk_end ? w0 + per : item.blk_end;
+  __syncthreads(); // tables ready; the waves never meet again
+
+  // per keyword: dense (bitmap) or sparse (block cursor); docs before the next window (uniform)
+  bool dense[BT_KW];
+  uint32_t base[BT_KW];
+  uint32_t kj[BT_KW], e0[BT_KW], e1[BT_KW], bnext[BT_KW]; // sparse cursors: block in registers
+  const uint32_t lo_first = w0 * 2048u;
+#pragma unroll
+  for (int k = 0; k < BT_KW; ++k) {
+    dense[k] = false, base[k] = 0, kj[k] = 0, e0[k] = e1[k] = INF_ROWID, bnext[k] = INF_ROWID;
+    if ((uint32_t)k < nterms && w0 < w1) {
+      const DevTerm& T = Q->t[k];
+      dense[k] = T.nblocks != 0 && T.bm_off != ~0ull; // (a keyword without postings has an all-zero descriptor)
+      if (dense[k])
+        base[k] = a.seg.bm_dir[T.dir_off + (uint64_t)w0 * (BT_WORDS / 8)];
+      else if (T.nblocks) {
+        // the block that holds the first doc >= lo_first: the last one whose first possible rowid is <= lo_first
+        kj[k] = wave_find_block(a.seg.pk_base + T.blk_first, 0, T.nblocks, lo_first);
+        bt_load_block(a.seg, T, kj[k], e0[k], e1[k], bnext[k]);
+        base[k] = kj[k] * DEVBLK + (uint32_t)__popcll(__ballot(e0[k] < lo_first)) + (uint32_t)__popcll(__ballot(e1[k] < lo_first));
+      } else
+        kj[k] = 0xFFFFFFFFu; // keyword without postings
+    }
+  }
+
+  uint32_t total = 0, tau_bin = 0, cn = 0, qn = 0;
+
+  auto publish = [&]() {
+    if (cn) {
+      uint32_t basep = 0;
+      if (lane == 0) basep = atomicAdd(gcount, cn);
+      basep = rdlane(basep, 0);
+      const bool fits = basep + cn <= cand_cap;
+      const uint32_t npub = cn;
+      if (lane == 0) {
+        uint32_t expected = 0;
+        while (!__hip_atomic_compare_exchange_strong(&s.hist_lock, &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          expected = 0;
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      wave_lds_fence();
+      for (uint32_t i = lane; i < (uint32_t)NBINS; i += 64) s.hist[i] = 0;
+      wave_lds_fence();
+      for (uint32_t i = lane; i < cn; i += 64) {
+        const uint64_t key = L.cbuf[i];
+        if (fits) cand[basep + i] = key;
+        atomicAdd(&s.hist[bin_of(bin_mode, bin_lo, bin_shift, key_weight(key), key_rowid(key))], 1u);
+      }
+      if (!fits && lane == 0) atomicOr(a.q_flags + oq, QF_OVERFLOW);
+      wave_lds_fence();
+      flush_hist(s.hist, ghist);
+      wave_lds_fence();
+      if (lane == 0) __hip_atomic_store(&s.hist_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      cn = 0;
+      if ((basep >> 11) != ((basep + npub) >> 11) || basep == 0) {
+        const uint32_t tb = threshold_bin(ghist, K);
+        if (tb > tau_bin) {
+          tau_bin = tb;
+          if (lane == 0) atomicMax(gtaubin, tb);
+        }
+      }
+    }
+    const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gt > tau_bin) tau_bin = gt;
+  };
+
+  // score the queue entries [from, from + n), n <= 64, one per lane
+  auto score = [&](uint32_t from, uint32_t n) {
+    wave_lds_fence();
+    const bool valid = lane < n;
+    const uint32_t e = from + (valid ? lane : 0u);
+    const uint32_t row = L.q_row[e], pm = valid ? L.q_pm[e] : 0u;
+    float kv[BT_KW];
+    uint32_t kf[BT_KW], href[BT_KW];
+#pragma unroll
+    for (int k = 0; k < BT_KW; ++k) {
+      kv[k] = 0.0f, kf[k] = 0, href[k] = 0;
+      if ((uint32_t)k < nterms) {
+        const DevTerm& T = Q->t[k];
+        const bool pres = ((pm >> k) & 1u) != 0;
+        const uint32_t r = pres ? L.q_rank[k][e] : 0u;
+        // packed attr word of slot r: block r >> 7, word r & 63, byte pair (r >> 6) & 1
+        const uint32_t wd = attr[(uint64_t)(T.blk_first + (r >> 7)) * 64 + (r & 63u)];
+        const uint32_t sh = ((r >> 6) & 1u) * 8u;
+        const uint32_t tf = (wd >> sh) & 0xffu;
+        if (pres) {
+          kf[k] = (wd >> (16u + sh)) & 0xffu & T.queried32; // (all fields queried: the doc's own field bits)
+          kv[k] = tf == 255u ? term_tfidf(exc_tf(a.seg, T, row), T.idf) : s.tfidf[k][tf];
+          href[k] = ((inline_hits && tf == 1u) ? 0x80000000u : 0u) | r;
+        }
+      }
+    }
+    // the tree's value rules on a per-lane stack (ExtAnd_c / ExtOr_c / ExtMaybe_c / ExtAndNot_c, searchnode.cpp:2585-2594,
+    // 3494-3540, 3587-3600, 3650-3680): tfidf adds left + right where both sides hold the doc, fields OR together
+    bool m0 = false, m1 = false, m2 = false, m3 = false;
+    float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if ((uint32_t)i < n_nodes) {
+        const uint32_t ins = prog[i], op = ins & 0xffu, kw = ins >> 24;
+        if (op == PN_TERM) {
+          m3 = m2, v3 = v2, f3 = f2, a3 = a2;
+          m2 = m1, v2 = v1, f2 = f1, a2 = a1;
+          m1 = m0, v1 = v0, f1 = f0, a1 = a0;
+          const bool m = ((pm >> kw) & 1u) != 0;
+          const float v = kw == 0 ? kv[0] : kw == 1 ? kv[1] : kw == 2 ? kv[2] : kv[3];
+          const uint32_t f = kw == 0 ? kf[0] : kw == 1 ? kf[1] : kw == 2 ? kf[2] : kf[3];
+          m0 = m, v0 = m ? v : 0.0f, f0 = m ? f : 0u, a0 = m ? 1u << kw : 0u;
+        } else {
+          bool m;
+          if (op == PN_AND)
+            m = m1 && m0;
+          else if (op == PN_OR)
+            m = m1 || m0;
+          else if (op == PN_MAYBE)
+            m = m1;
+          else
+            m = m1 && !m0;
+          const bool both = op != PN_ANDNOT; // ANDNOT passes its left side through
+          const float v = m ? (both ? v1 + v0 : v1) : 0.0f; // x + 0.0f == x: an absent side adds nothing
+          const uint32_t f = m ? (both ? f1 | f0 : f1) : 0u, av = m ? (both ? a1 | a0 : a1) : 0u;
+          m0 = m, v0 = v, f0 = f, a0 = av;
+          m1 = m2, v1 = v2, f1 = f2, a1 = a2;
+          m2 = m3, v2 = v3, f2 = f3, a2 = a3;
+        }
+      }
+    }
+    const bool live = valid && m0; // (every queued doc matched bitwise: m0 holds for all valid lanes)
+    if (need_hits) {
+      // a 64-doc chunk of the HBM match queue straight from registers (rank_kernel does the hit pass and the ranking)
+      const MatchQueue& MQ = a.mq[0];
+      uint32_t c = 0xFFFFFFFFu;
+      for (uint32_t k = 0; k < (uint32_t)MQ_SHARDS && c == 0xFFFFFFFFu; ++k) {
+        const uint32_t shard = (blockIdx.x + k) & (MQ_SHARDS - 1);
+        uint32_t got = 0;
+        if (lane == 0) got = atomicAdd(MQ.count + shard, 1u);
+        got = rdlane(got, 0);
+        if (got < MQ.cap) c = shard * MQ.cap + got;
+      }
+      if (c != 0xFFFFFFFFu) {
+        uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+        d[0] = row;
+        d[64] = __float_as_uint(v0);
+        d[128] = (f0 & 0xffu) | (a0 << 8);
+#pragma unroll
+        for (int t = 0; t < MAX_PROX_TERMS; ++t) d[192 + 64 * t] = href[t];
+        if (lane == 0) MQ.hdr[c] = item.query | (n << 24);
+      } else if (lane == 0)
+        atomicOr(a.q_flags + oq, QF_OVERFLOW);
+      return;
+    }
+    bool push = false;
+    uint64_t key = 0;
+    if (live) {
+      ++total;
+      uint32_t weight;
+      if (ranker == MRK_RANK_NONE)
+        weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
+      else if (ranker == MRK_RANK_PROXIMITY)
+        weight = s.rank[f0 & 0xffu]; // single keyword: ExtRanker_WeightSum_c<> without BM25
+      else {
+        // ExtRanker_WeightSum_c<BM25>, sphinxsearch.cpp:1070, 1112-1129
+        const int32_t bm = (int32_t)((v0 + 0.5f) * 1000.0f);
+        weight = (uint32_t)bm + s.rank[f0 & 0xffu] * 1000u;
+      }
+      weight *= index_weight; // MatchExtended, sphinx.cpp:12220
+      const uint32_t grow = a.seg.rowid_base + row;
+      if (bin_of(bin_mode, bin_lo, bin_shift, (int32_t)weight, grow) >= tau_bin) {
+        push = true;
+        key = make_key((int32_t)weight, grow);
+      }
+    }
+    const uint64_t bal = __ballot(push);
+    if (bal) {
+      const uint32_t np = (uint32_t)__popcll(bal);
+      if (cn + np > (uint32_t)BT_CBUF) publish();
+      if (push) L.cbuf[cn + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+      cn += np;
+      if (cn >= (uint32_t)BT_CBUF - 64u) publish();
+    }
+  };
+
+  for (uint32_t w = w0; w < w1; ++w) {
+    const uint32_t lo = w * 2048u, hi_m1 = lo + 2047u; // window = rowids [lo, hi_m1]
+    uint32_t word[BT_KW];
+    uint32_t dv = 0;
+    // dense keywords: one coalesced load each (issued together, used after the sparse words are built)
+#pragma unroll
+    for (int k = 0; k < BT_KW; ++k) {
+      word[k] = 0;
+      if ((uint32_t)k < nterms && dense[k]) word[k] = a.seg.bm[Q->t[k].bm_off + (uint64_t)w * BT_WORDS + lane];
+    }
+    if (dead) dv = dead[(uint64_t)w * BT_WORDS + lane];
+    // sparse keywords: the cursor's docs that fall into the window
+#pragma unroll
+    for (int k = 0; k < BT_KW; ++k) {
+      if ((uint32_t)k < nterms && !dense[k] && kj[k] != 0xFFFFFFFFu) {
+        const DevTerm& T = Q->t[k];
+        bool zeroed = false;
+        for (;;) {
+          const bool in0 = e0[k] >= lo && e0[k] <= hi_m1, in1 = e1[k] >= lo && e1[k] <= hi_m1;
+          if (__ballot(in0 || in1)) {
+            if (!zeroed) {
+              L.abm[k][lane] = 0;
+              wave_lds_fence();
+              zeroed = true;
+            }
+            if (in0) atomicOr(&L.abm[k][(e0[k] >> 5) & 63u], 1u << (e0[k] & 31u));
+            if (in1) atomicOr(&L.abm[k][(e1[k] >> 5) & 63u], 1u << (e1[k] & 31u));
+          }
+          // the next block starts at bnext: beyond the window -> this block served it
+          if (bnext[k] > hi_m1) break;
+          ++kj[k];
+          bt_load_block(a.seg, T, kj[k], e0[k], e1[k], bnext[k]);
+        }
+        if (zeroed) {
+          wave_lds_fence();
+          word[k] = L.abm[k][lane];
+        }
+      }
+    }
+    {
+      const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (gt > tau_bin) tau_bin = gt;
+    }
+    // the tree on 32 rowids per lane
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if ((uint32_t)i < n_nodes) {
+        const uint32_t ins = prog[i], op = ins & 0xffu, kw = ins >> 24;
+        if (op == PN_TERM) {
+          s3 = s2, s2 = s1, s1 = s0;
+          s0 = kw == 0 ? word[0] : kw == 1 ? word[1] : kw == 2 ? word[2] : word[3];
+        } else {
+          const uint32_t r = op == PN_AND ? (s1 & s0) : op == PN_OR ? (s1 | s0) : op == PN_MAYBE ? s1 : (s1 & ~s0);
+          s0 = r, s1 = s2, s2 = s3;
+        }
+      }
+    }
+    uint32_t m = s0 & ~dv;
+    // ranks of the lane's first bit: one prefix sum carries two keywords' popcounts
+    uint32_t r0[BT_KW];
+#pragma unroll
+    for (int k = 0; k < BT_KW; k += 2) {
+      r0[k] = r0[k + 1] = 0;
+      if ((uint32_t)k < nterms) {
+        const uint32_t pc = (uint32_t)__popc(word[k]) | ((uint32_t)__popc(word[k + 1]) << 16);
+        const uint32_t incl = wave_incl_scan(pc);
+        const uint32_t excl = incl - pc;
+        r0[k] = base[k] + (excl & 0xFFFFu);
+        r0[k + 1] = base[k + 1] + (excl >> 16);
+        const uint32_t tot = rdlane(incl, 63);
+        base[k] += tot & 0xFFFFu;
+        base[k + 1] += tot >> 16;
+      }
+    }
+    const uint32_t rowbase = lo + lane * 32u;
+    uint64_t bal;
+    while ((bal = __ballot(m != 0)) != 0) {
+      const bool has = m != 0;
+      const uint32_t bit = has ? (uint32_t)__builtin_ctz(m) : 0u;
+      const uint32_t below = (1u << bit) - 1u;
+      const uint32_t pos = qn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      if (has) {
+        uint32_t pm = 0;
+#pragma unroll
+        for (int k = 0; k < BT_KW; ++k) {
+          pm |= ((word[k] >> bit) & 1u) << k;
+          if ((uint32_t)k < nterms) L.q_rank[k][pos] = r0[k] + (uint32_t)__popc(word[k] & below);
+        }
+        L.q_row[pos] = rowbase + bit;
+        L.q_pm[pos] = pm;
+      }
+      qn += (uint32_t)__popcll(bal);
+      m &= m - 1u;
+      if (qn >= 64u) {
+        score(qn - 64u, 64u);
+        qn -= 64u;
+        wave_lds_fence(); // the scored entries' slots may be rewritten
+      }
+    }
+  }
+  if (qn) score(0, qn);
+  if (cn) publish();
+  {
+    uint32_t t = total;
+    for (int dlt = 32; dlt; dlt >>= 1) t += __shfl_down(t, dlt, 64);
+    if (lane == 0 && t) atomicAdd((unsigned long long*)(a.q_total + oq), (unsigned long long)t);
+  }
+}
+
+void launch_scan_bt(const ScanArgs& a, void* stream) {
+  if (!a.n_items) return;
+  hipLaunchKernelGGL(scan_bt_kernel, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
+}
+
+} // namespace mrk
