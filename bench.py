@@ -424,16 +424,7 @@ def main() -> None:
     # BASELINE config 3 on the same corpus, outside the timed region: 3-term mixes a b c / (a|b) c / a (b|c) / a b -c under
     # SPH_RANK_PROXIMITY_BM25 (hitlist decode); a = selective keyword, b and c = common ones.  Extra information only.
     if rank == 0 and world == 1 and not sharded and not args.no_config3 and args.path == 0 and set(names) == {"cc", "sc", "ss"}:
-        OR_, ANDNOT_ = m.SPH_QUERY_OR, m.SPH_QUERY_ANDNOT
-        c3 = []
-        for i in range(nq):
-            a_, b_ = strata["sc"][i]
-            c_ = strata["cc"][i][0] if strata["cc"][i][0] != b_ else strata["cc"][i][1]
-            ka, kb, kc = kw(a_, 1), kw(b_, 2), kw(c_, 3)
-            root = [m.XQNode.AND(ka, kb, kc), m.XQNode.AND(m.XQNode(OR_, [ka, kb]), kc), m.XQNode.AND(ka, m.XQNode(OR_, [kb, kc])),
-                    m.XQNode(ANDNOT_, [m.XQNode.AND(ka, kb), kc])][i % 4]
-            c3.append(m.Query(root, ranker=m.SPH_RANK_PROXIMITY_BM25, max_matches=K, total_docs=int(total_docs),
-                              local_docs={t: int(global_docs[t]) for t in (a_, b_, c_)}))
+        c3 = config3_queries(m, strata, nq, K, total_docs, global_docs)
         cq3 = m.prepare(c3)
         b3 = [m.Batch(ctx, nq), m.Batch(ctx, nq)]
         for bb in b3:
@@ -472,6 +463,23 @@ def main() -> None:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def config3_queries(m, strata, nq, K, total_docs, global_docs):
+    """BASELINE config 3: 3-term mixes a b c / (a|b) c / a (b|c) / a b -c under SPH_RANK_PROXIMITY_BM25 (hitlist decode);
+    a = the selective keyword of the i-th sc pair, b = its common one, c = a common keyword of the i-th cc pair."""
+    kw = m.XQNode.keyword
+    OR_, ANDNOT_ = m.SPH_QUERY_OR, m.SPH_QUERY_ANDNOT
+    c3 = []
+    for i in range(nq):
+        a_, b_ = strata["sc"][i]
+        c_ = strata["cc"][i][0] if strata["cc"][i][0] != b_ else strata["cc"][i][1]
+        ka, kb, kc = kw(a_, 1), kw(b_, 2), kw(c_, 3)
+        root = [m.XQNode.AND(ka, kb, kc), m.XQNode.AND(m.XQNode(OR_, [ka, kb]), kc), m.XQNode.AND(ka, m.XQNode(OR_, [kb, kc])),
+                m.XQNode(ANDNOT_, [m.XQNode.AND(ka, kb), kc])][i % 4]
+        c3.append(m.Query(root, ranker=m.SPH_RANK_PROXIMITY_BM25, max_matches=K, total_docs=int(total_docs),
+                          local_docs={t: int(global_docs[t]) for t in (a_, b_, c_)}))
+    return c3
 
 
 def spawn_ranks(n: int) -> int:

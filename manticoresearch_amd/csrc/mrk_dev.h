@@ -184,11 +184,12 @@ __host__ __device__ inline uint32_t key_rowid(uint64_t k) { return ~(uint32_t)k;
 // (structure of arrays: per chunk MQ_PLANES rows of 64 dwords -- rowid, tfidf sum, fields | contributing keywords << 8,
 // one packed-array reference per keyword -- each written and read as one coalesced 256-B row)
 constexpr int MQ_PLANES = 3 + MAX_PROX_TERMS_;
-constexpr int MQ_SHARDS = 8; // chunk allocators per queue (workgroup b uses shard b % 8): one hot atomic address would serialize the producers
+constexpr int MQ_SHARDS = 64; // chunk allocators per queue (workgroup b uses shard b % 64): a hot atomic address serializes the producers
+constexpr int MQ_BATCH = 4;   // chunks a wave reserves per atomic
 struct MatchQueue {
   uint32_t* data;  // [MQ_SHARDS * cap][MQ_PLANES][64]
   uint32_t* hdr;   // [MQ_SHARDS * cap] pass index | valid entries << 24
-  uint32_t* count; // [MQ_SHARDS] chunks handed out per shard (past cap: dropped, the query flagged QF_OVERFLOW)
+  uint32_t* count; // [MQ_SHARDS] chunks handed out per shard (past cap: never written, the query flagged QF_OVERFLOW)
   uint32_t cap;    // chunks per shard; shard s owns chunks [s * cap, (s + 1) * cap)
 };
 

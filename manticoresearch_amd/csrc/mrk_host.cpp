@@ -863,12 +863,12 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
       bool fat = false;
       if (!P.n_items || !pass_queues_matches(P, fat)) return;
       const bool bt = (P.tree_flags & mrk::TF_BTREE) != 0;
-      mq_chunks[fat ? 1 : 0] += pass_max_matches(P) / 64 + (bt ? 0 : 4ull * P.n_items) + 1;
+      mq_chunks[fat ? 1 : 0] += pass_max_matches(P) / 64 + (bt ? 0 : 4ull * (mrk::MQ_BATCH + 1) * P.n_items) + 1;
       bt_feeds = bt_feeds || bt;
     };
     for (uint32_t i = 0; i < n; ++i) account(b->h_queries.p[i]);
     for (const DevQuery& P : extra) account(P);
-    if (bt_feeds) mq_chunks[0] += 4ull * n_items_kind[1]; // (its work items were only cut just now)
+    if (bt_feeds) mq_chunks[0] += 4ull * (mrk::MQ_BATCH + 1) * n_items_kind[1]; // per wave one partial chunk + the unused rest of a reservation (its work items were only cut just now)
     for (int i = 0; i < 2; ++i) mq_chunks[i] = std::min<uint64_t>(mq_chunks[i], (uint64_t)b->ctx->mq_max_chunks);
   }
   const size_t n_items_bm = items.size() - n_items_pk;
@@ -1087,7 +1087,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
     uint64_t chunks[2] = {0, 0};
     for (size_t p = 0; p < passes.size(); ++p) {
       bool fat = false;
-      if (pass_queues_matches(passes[p], fat)) chunks[fat ? 1 : 0] += pass_max_matches(passes[p]) / 64 + 4ull * n_items + 1;
+      if (pass_queues_matches(passes[p], fat)) chunks[fat ? 1 : 0] += pass_max_matches(passes[p]) / 64 + 4ull * (mrk::MQ_BATCH + 1) * n_items + 1;
     }
     for (int i = 0; i < 2; ++i)
       if (chunks[i] > (1ull << 25)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: match queue for the rerun too large", qi);

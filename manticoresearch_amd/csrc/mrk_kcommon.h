@@ -45,10 +45,22 @@ __device__ __forceinline__ uint64_t rdlane64(uint64_t v, uint32_t l) {
 
 // LDS hand-off between lanes of ONE wave: make earlier ds_writes visible and keep the
 // compiler from moving LDS accesses across this point.
+// (MRK_WAVE_FENCE=1: wavefront-scope fences -- ordering for the compiler only.  One wave's DS instructions execute in issue
+// order, so another lane's earlier ds_write / ds_or is seen by a later ds_read without any s_waitcnt; the workgroup-scope
+// form also drains vmcnt, i.e. stalls on every global load and store still in flight.)
+#ifndef MRK_WAVE_FENCE
+#define MRK_WAVE_FENCE 0
+#endif
 __device__ __forceinline__ void wave_lds_fence() {
+#if MRK_WAVE_FENCE
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
 }
 
 // bit k of the result = byte k of w is a varint terminator (bit 7 clear)

@@ -316,7 +316,6 @@ struct TreeEnt {
 
 // what one doc's hit pass needs from the kernel (plain values: no reference to the kernel's locals survives)
 struct HitCtx {
-  const DevQuery* Q;
   const uint8_t* spp;
   const uint32_t* hit;    // DevSegment::pk_hit
   const uint64_t* hbase;  // DevSegment::pk_hbase
@@ -327,6 +326,8 @@ struct HitCtx {
   uint32_t px_dist;       // 0 = exact PHRASE, else the PROXIMITY operator's distance ('"a b"~N')
   uint32_t ranker;        // MRK_RANK_* of the state ranker fed by the pass
   const int32_t* fw;      // the nw per-field weights (an LDS copy where the pass ranks; WORDCOUNT reads one per hit)
+  // per keyword slot, by value (uniform): first block in the packed arrays, query position, queried fields, position modifier
+  uint32_t tb[MAX_PROX_TERMS], tq[MAX_PROX_TERMS], tm[MAX_PROX_TERMS], tpk[MAX_PROX_TERMS], tpm[MAX_PROX_TERMS];
   int max_qpos, n_qwords; // ExtRanker_c::m_iMaxQpos / m_iQwords
   bool inline_hits, multi_and;
   bool dupes;             // repeated query keywords under a proximity ranker: RankerState_Proximity_fn<.., true>
@@ -350,13 +351,12 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
   for (int t = 0; t < MAX_PROX_TERMS; ++t) {
     sp[t] = 0, sc[t] = 0, sq[t] = 0, sm[t] = 0, tpk[t] = 0, tpm[t] = 0;
     if ((uint32_t)t < C.nterms && ((smask >> t) & 1u)) {
-      const DevTerm& Tt = C.Q->t[t];
-      if (C.termpos) tpk[t] = Tt.tp_kind, tpm[t] = Tt.tp_max;
+      if (C.termpos) tpk[t] = C.tpk[t], tpm[t] = C.tpm[t];
       const uint32_t h = t == 0 ? ref0 : t == 1 ? ref1 : t == 2 ? ref2 : ref3;
-      const uint32_t gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu), idx = h & 127u;
+      const uint32_t gblk = C.tb[t] + ((h >> 7) & 0xFFFFFFu), idx = h & 127u;
       const bool lone = (h >> 31) != 0;
-      sq[t] = Tt.qpos;
-      sm[t] = Tt.queried32;
+      sq[t] = C.tq[t];
+      sm[t] = C.tm[t];
       const uint32_t hv = C.hit[(uint64_t)gblk * DEVBLK + idx];
       if (lone) // the hit travelled in the doclist entry (SeekHitlist state 1, sphinx.cpp:461-464)
         sc[t] = hv;
@@ -569,7 +569,7 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
         if (t == best) sp[t] = ap, sc[t] = ac;
     }
   }
-  if (rank) rk_out = X.finalize(C.ranker, C.nw, C.Q->weights, C.n_qwords);
+  if (rank) rk_out = X.finalize(C.ranker, C.nw, C.fw, C.n_qwords);
   if (F.over) atomicOr(C.flags, QF_FSM);
 }
 
@@ -633,11 +633,10 @@ __device__ __forceinline__ int hit_rank_plain(const HitCtx& C, uint32_t ref0, ui
     on[t] = (uint32_t)t < C.nterms && ((smask >> t) & 1u);
     sq[t] = 0, sm[t] = 0, hv[t] = 0, hb[t] = 0, lone[t] = true;
     if (on[t]) {
-      const DevTerm& Tt = C.Q->t[t];
       const uint32_t h = t == 0 ? ref0 : t == 1 ? ref1 : t == 2 ? ref2 : ref3;
-      const uint32_t gblk = Tt.blk_first + ((h >> 7) & 0xFFFFFFu), idx = h & 127u;
-      sq[t] = Tt.qpos;
-      sm[t] = Tt.queried32;
+      const uint32_t gblk = C.tb[t] + ((h >> 7) & 0xFFFFFFu), idx = h & 127u;
+      sq[t] = C.tq[t];
+      sm[t] = C.tm[t];
       lone[t] = (h >> 31) != 0; // the hit travelled in the doclist entry (SeekHitlist state 1, sphinx.cpp:461-464)
       hv[t] = C.hit[(uint64_t)gblk * DEVBLK + idx];
       if (!lone[t]) hb[t] = C.hbase[gblk];
@@ -698,7 +697,114 @@ __device__ __forceinline__ int hit_rank_plain(const HitCtx& C, uint32_t ref0, ui
     for (int t = 0; t < MAX_PROX_TERMS; ++t)
       if (t == best) sp[t] = ap, sc[t] = ac, w0[t] = a0, w1[t] = a1, w2[t] = a2, w3[t] = a3, so[t] = ao;
   }
-  return X.finalize(C.ranker, C.nw, C.Q->weights, C.n_qwords);
+  return X.finalize(C.ranker, C.nw, C.fw, C.n_qwords);
+}
+
+// hit_rank_plain for the common case, specialized at compile time: NT keyword streams, the proximity family
+// (SPH_RANK_PROXIMITY_BM25 / SPH_RANK_PROXIMITY: RankerState_Proximity_fn<.., false>::Update, sphinxsearch.cpp:1351-1367 --
+// LCS per field in BYTE arithmetic), no repeated keywords, no quorum hit order, no MergeHits3 field-test quirk.  Same
+// results, about half the instructions per hit: the stream state is a window + a 32-bit offset (the 64-bit .spp position
+// is only touched at a refill), the ranker update is the three lines it is for this family, and the loop carries no
+// per-ranker branches.  rank_kernel is bound by instruction issue (vector and scalar), not by memory.
+template <int NT>
+__device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uint32_t ref1, uint32_t ref2, uint32_t ref3, uint32_t smask) {
+  uint64_t sb[NT];                                     // .spp position of the window's first byte
+  uint32_t so[NT], sc[NT], w0[NT], w1[NT], w2[NT], w3[NT]; // offset of the next undecoded byte (~0 = no hitlist left), current hit
+  uint32_t hv[NT];
+  uint64_t hb[NT];
+  bool lone[NT], on[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    on[t] = ((smask >> t) & 1u) != 0;
+    hv[t] = 0, hb[t] = 0, lone[t] = true;
+    if (on[t]) {
+      const uint32_t h = t == 0 ? ref0 : t == 1 ? ref1 : t == 2 ? ref2 : ref3;
+      const uint32_t gblk = C.tb[t] + ((h >> 7) & 0xFFFFFFu), idx = h & 127u;
+      lone[t] = (h >> 31) != 0;
+      hv[t] = C.hit[(uint64_t)gblk * DEVBLK + idx];
+      if (!lone[t]) hb[t] = C.hbase[gblk];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    sb[t] = 0, so[t] = 0xFFFFFFFFu, sc[t] = 0, w0[t] = w1[t] = w2[t] = w3[t] = 0;
+    if (on[t]) {
+      if (lone[t])
+        sc[t] = hv[t];
+      else {
+        const uint64_t p = hb[t] + hv[t];
+        sb[t] = p & ~3ull;
+        const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(C.spp + sb[t]);
+        w0[t] = v.x, w1[t] = v.y, w2[t] = v.z, w3[t] = v.w;
+        so[t] = (uint32_t)p & 3u;
+      }
+    }
+  }
+  // next hit of a stream out of its window (GetNextHit, sphinx.cpp:479-501); refills when fewer than 5 bytes are left
+  auto next = [&](uint64_t& b, uint32_t& o, uint32_t& cur, uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
+    if (o == 0xFFFFFFFFu) {
+      cur = 0;
+      return;
+    }
+    if (o > 11u) {
+      b += o & ~3u;
+      const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(C.spp + b);
+      x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+      o &= 3u;
+    }
+    const uint32_t i = o >> 2;
+    const uint32_t lo = i == 0 ? x0 : i == 1 ? x1 : x2, hi = i == 0 ? x1 : i == 1 ? x2 : x3;
+    const uint32_t x = __builtin_amdgcn_alignbyte(hi, lo, o & 3u);
+    const uint32_t stop = ~x & 0x80808080u;
+    const uint32_t n = stop ? ((uint32_t)__builtin_ctz(stop) >> 3) + 1u : 4u;
+    const uint32_t all = ((x & 0x7Fu) << 21) | ((x & 0x7F00u) << 6) | ((x >> 9) & 0x3F80u) | ((x >> 24) & 0x7Fu);
+    uint32_t d = all >> (7u * (4u - n)), len = n;
+    if (!stop) {
+      const uint32_t j = (o + 4u) >> 2;
+      const uint32_t wj = j == 1 ? x1 : j == 2 ? x2 : x3;
+      d = (d << 7) | ((wj >> (8u * ((o + 4u) & 3u))) & 0x7Fu);
+      len = 5;
+    }
+    o += len;
+    if (!d) {
+      o = 0xFFFFFFFFu;
+      cur = 0;
+    } else
+      cur += d;
+  };
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (on[t] && !lone[t]) next(sb[t], so[t], sc[t], w0[t], w1[t], w2[t], w3[t]);
+  uint64_t lcs = 0;
+  uint32_t cur_lcs = 0;
+  int exp_delta = -1, last_pwf = -1;
+  for (;;) {
+    // the least (hitpos, qpos) among the live streams
+    uint32_t bh = 0xFFFFFFFFu, bq = 0xFFFFFFFFu;
+    int best = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const uint32_t h = sc[t] ? sc[t] : 0xFFFFFFFFu;
+      const bool less = h < bh || (h == bh && C.tq[t] < bq);
+      if (t == 0 || less) best = t, bh = h, bq = C.tq[t];
+    }
+    if (bh == 0xFFFFFFFFu) break;
+    const uint32_t bm = best == 0 ? C.tm[0] : best == 1 ? C.tm[NT > 1 ? 1 : 0] : best == 2 ? C.tm[NT > 2 ? 2 : 0] : C.tm[NT > 3 ? 3 : 0];
+    if (field_queried(bm, bh)) { // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
+      const uint32_t hp = bh & ~(1u << 23), f = hp >> 24;
+      const int pwf = (int)hp, delta = pwf - (int)(bq & 0xFFFFu);
+      if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + 1u) & 0xffu;
+      if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu)) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
+      last_pwf = pwf;
+      exp_delta = delta;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t == best) next(sb[t], so[t], sc[t], w0[t], w1[t], w2[t], w3[t]);
+  }
+  int rk = 0;
+  for (uint32_t f = 0; f < C.nw; ++f) rk += (int)((lcs >> (8 * f)) & 0xffu) * C.fw[f];
+  return rk;
 }
 
 // ExtConditional_T::GetDocsChunk (searchnode.cpp:2332-2405): the keyword holds the doc iff one of its hits -- inside the

@@ -23,6 +23,7 @@ struct __align__(16) RkSmem {
   RkWaveLds w[WAVES];
   uint32_t hist[NBINS]; // publishing scratch, one per workgroup behind hist_lock (as in scan_bm_kernel)
   uint32_t hist_lock;
+  uint32_t pre[MQ_SHARDS + 1]; // chunks in the shards before shard s (filled prefixes laid end to end)
 };
 
 template <bool FAT>
@@ -32,17 +33,20 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
   const MatchQueue MQ = a.mq[FAT ? 1 : 0];
   RkWaveLds& L = s.w[wave];
   if (!tid) s.hist_lock = 0;
-  __syncthreads(); // the waves never meet again
-  // chunks are dealt out statically: wave w of the grid takes the virtual chunks w, w + W, w + 2W ... of the shards'
-  // filled prefixes laid end to end (64 docs of work each, hundreds per wave: the spread evens out, and a shared cursor
-  // would be one atomic address hit once per chunk by every wave of the chip)
-  uint32_t shard_n[MQ_SHARDS], n_chunks = 0;
-#pragma unroll
-  for (int i = 0; i < MQ_SHARDS; ++i) {
-    uint32_t v = __hip_atomic_load(MQ.count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    shard_n[i] = v < MQ.cap ? v : MQ.cap;
-    n_chunks += shard_n[i];
+  static_assert(MQ_SHARDS == 64, "one shard per lane of the prefix sum");
+  if (wave == 0) {
+    uint32_t v = __hip_atomic_load(MQ.count + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v > MQ.cap) v = MQ.cap;
+    const uint32_t inc = wave_incl_scan(v);
+    s.pre[lane + 1] = inc;
+    if (!lane) s.pre[0] = 0;
   }
+  __syncthreads(); // the waves never meet again
+  // chunks are dealt out statically: wave w of the grid takes runs of MQ_BATCH virtual chunks (one producer wave's
+  // reservation, i.e. one query: the per-query state below changes hands less often), w-th run of every n_waves runs, of
+  // the shards' filled prefixes laid end to end.  64 docs of work per chunk, hundreds of chunks per wave: the spread evens
+  // out, and a shared cursor would be one atomic address hit once per chunk by every wave of the chip.
+  const uint32_t n_chunks = s.pre[MQ_SHARDS];
   const uint32_t n_waves = gridDim.x * WAVES;
   const bool inline_hits = a.seg.inline_hits != 0;
 
@@ -99,75 +103,140 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
     total = 0;
   };
 
-  for (uint32_t vc = blockIdx.x * WAVES + wave; vc < n_chunks; vc += n_waves) {
-    uint32_t rem = vc, c = 0; // virtual -> physical chunk
-    bool found = false;
+  // what the current pass's descriptor says, cached as uniform values (see the loop)
+  uint32_t cur_pass = 0xFFFFFFFFu, qc_nterms = 0, qc_ranker = 0, qc_flags = 0, qc_index_weight = 1, qc_nw = 0, qc_max_qpos = 0, qc_n_qwords = 0,
+           qc_ph_mask = 0;
+  HitCtx HC;
+  HC.spp = a.seg.spp;
+  HC.hit = a.seg.pk_hit;
+  HC.hbase = a.seg.pk_hbase;
+  HC.fw = L.fw;
+  HC.inline_hits = inline_hits;
 #pragma unroll
-    for (int i = 0; i < MQ_SHARDS; ++i)
-      if (!found) {
-        if (rem < shard_n[i])
-          c = (uint32_t)i * MQ.cap + rem, found = true;
-        else
-          rem -= shard_n[i];
+  for (int t = 0; t < MAX_PROX_TERMS; ++t) HC.tb[t] = HC.tq[t] = HC.tm[t] = HC.tpk[t] = HC.tpm[t] = 0;
+  HC.ap0 = HC.ap1 = HC.ap2 = HC.ap3 = 0, HC.px_dist = 0;
+
+  // virtual -> physical chunk: the shard whose prefix range holds it (uniform binary search over 65 LDS words)
+  auto chunk_of = [&](uint32_t vc) -> uint32_t {
+    uint32_t lo = 0, hi = MQ_SHARDS; // pre[lo] <= vc < pre[hi]
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s.pre[mid] <= vc)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(lo * MQ.cap + (vc - s.pre[lo])));
+  };
+  // run r of the wave = virtual chunks [ (r * n_waves + gw) * MQ_BATCH, + MQ_BATCH )
+  const uint32_t gw = blockIdx.x * WAVES + wave;
+  auto vchunk = [&](uint32_t i) -> uint32_t { return ((i / MQ_BATCH) * n_waves + gw) * MQ_BATCH + (i % MQ_BATCH); };
+  // the chunk after the one being ranked is already on its way (header + the 7 planes): one memory round trip less in
+  // every chunk's chain of dependent loads
+  uint32_t it = 0, vc = vchunk(0);
+  uint32_t nx_hdr = 0, nx[MQ_PLANES];
+#pragma unroll
+  for (int i = 0; i < MQ_PLANES; ++i) nx[i] = 0;
+  constexpr bool PREFETCH = !FAT; // (the PHRASE & co instance would drop from 3 to 2 waves per SIMD for the 8 registers)
+  if (PREFETCH && vc < n_chunks) {
+    const uint32_t c = chunk_of(vc);
+    nx_hdr = MQ.hdr[c];
+    const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < MQ_PLANES; ++i) nx[i] = d[64 * i];
+  }
+  for (; vc < n_chunks; vc = vchunk(++it)) {
+    if (!PREFETCH) {
+      const uint32_t c = chunk_of(vc);
+      nx_hdr = MQ.hdr[c];
+      const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+#pragma unroll
+      for (int i = 0; i < MQ_PLANES; ++i) nx[i] = d[64 * i];
+    }
+    const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx_hdr);
+    uint32_t cur[MQ_PLANES];
+#pragma unroll
+    for (int i = 0; i < MQ_PLANES; ++i) cur[i] = nx[i];
+    if (PREFETCH && vchunk(it + 1) < n_chunks) {
+      const uint32_t c = chunk_of(vchunk(it + 1));
+      nx_hdr = MQ.hdr[c];
+      const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+#pragma unroll
+      for (int i = 0; i < MQ_PLANES; ++i) nx[i] = d[64 * i];
+    }
+    const uint32_t n = hdr >> 24, pass = hdr & 0xFFFFFFu;
+    if (pass != cur_pass) {
+      // another pass's chunks: fetch what the hit pass and the weighing read of its descriptor ONCE, as uniform values
+      // (one batch of independent loads; a producer wave's reservation of MQ_BATCH chunks arrives as one run).  Loads
+      // behind the kernel's own stores are not scalarized by the compiler, hence the explicit readfirstlane.
+      cur_pass = pass;
+      const DevQuery* __restrict__ Q = a.queries + pass;
+      auto U = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+      const uint32_t oq = U(Q->out_q);
+      qc_nterms = U(Q->n_terms), qc_ranker = U(Q->ranker), qc_flags = U(Q->tree_flags), qc_index_weight = U(Q->index_weight);
+      qc_nw = U(Q->n_weights < 8u ? Q->n_weights : 8u);
+      qc_max_qpos = U(Q->max_qpos), qc_n_qwords = U(Q->n_qwords);
+#pragma unroll
+      for (int t = 0; t < MAX_PROX_TERMS; ++t) {
+        HC.tb[t] = U(Q->t[t].blk_first), HC.tq[t] = U(Q->t[t].qpos), HC.tm[t] = U(Q->t[t].queried32);
+        HC.tpk[t] = FAT ? U(Q->t[t].tp_kind) : 0u, HC.tpm[t] = FAT ? U(Q->t[t].tp_max) : 0u;
       }
-    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-    const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)MQ.hdr[c]);
-    const uint32_t n = hdr >> 24;
-    const DevQuery* __restrict__ Q = a.queries + (hdr & 0xFFFFFFu);
-    const uint32_t oq = Q->out_q;
-    if (oq != cur_oq) {
-      leave_query();
-      cur_oq = oq;
-      K = Q->k, bin_mode = Q->bin_mode, bin_shift = Q->bin_shift, bin_lo = Q->bin_lo, cand_cap = Q->cand_cap;
-      cand = a.cand + Q->cand_off;
-      ghist = a.q_hist + (uint64_t)oq * NBINS;
-      gcount = a.q_cand_n + oq;
-      gtaubin = a.q_tau_bin + oq;
-      tau_bin = 0;
+      HC.ap0 = FAT ? U(Q->ph_atoms[0]) : 0u, HC.ap1 = FAT ? U(Q->ph_atoms[1]) : 0u, HC.ap2 = FAT ? U(Q->ph_atoms[2]) : 0u, HC.ap3 = FAT ? U(Q->ph_atoms[3]) : 0u;
+      qc_ph_mask = FAT ? U(Q->ph_mask) : 0u;
+      HC.px_dist = FAT ? U(Q->px_dist) : 0u;
+      const uint32_t k_ = U(Q->k), bm_ = U(Q->bin_mode), bs_ = U(Q->bin_shift), bl_ = U((uint32_t)Q->bin_lo), cc_ = U(Q->cand_cap);
+      const uint64_t co_ = ((uint64_t)U((uint32_t)(Q->cand_off >> 32)) << 32) | U((uint32_t)Q->cand_off);
+      const int32_t wl = lane < 8 ? Q->weights[lane] : 0;
+      if (oq != cur_oq) {
+        leave_query();
+        cur_oq = oq;
+        K = k_, bin_mode = bm_, bin_shift = bs_, bin_lo = (int32_t)bl_, cand_cap = cc_;
+        cand = a.cand + co_;
+        ghist = a.q_hist + (uint64_t)oq * NBINS;
+        gcount = a.q_cand_n + oq;
+        gtaubin = a.q_tau_bin + oq;
+        tau_bin = 0;
+      }
       wave_lds_fence();
-      if (lane < 8) L.fw[lane] = Q->weights[lane];
+      if (lane < 8) L.fw[lane] = wl;
       wave_lds_fence();
     }
     {
       const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (gt > tau_bin) tau_bin = gt;
     }
-    const uint32_t nterms = Q->n_terms, ranker = Q->ranker, flags = Q->tree_flags;
-    const uint32_t nw = Q->n_weights < 8u ? Q->n_weights : 8u;
+    const uint32_t nterms = qc_nterms, ranker = qc_ranker, flags = qc_flags, nw = qc_nw;
     const bool phrase = FAT && (flags & TF_PHRASE) != 0;
     const bool ph_leaf = FAT && (flags & TF_PHRASE_LEAF) != 0;
     const bool prox_ranker = (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY)
                                  ? nterms > 1
                                  : (ranker == MRK_RANK_WORDCOUNT || ranker == MRK_RANK_MATCHANY || ranker == MRK_RANK_FIELDMASK ||
                                     ranker == MRK_RANK_SPH04);
-    HitCtx HC;
-    HC.Q = Q;
-    HC.spp = a.seg.spp;
-    HC.hit = a.seg.pk_hit;
-    HC.hbase = a.seg.pk_hbase;
-    HC.flags = a.q_flags + oq;
+    HC.flags = a.q_flags + cur_oq;
     HC.nterms = nterms, HC.nw = nw;
-    HC.ap0 = FAT ? Q->ph_atoms[0] : 0u, HC.ap1 = FAT ? Q->ph_atoms[1] : 0u, HC.ap2 = FAT ? Q->ph_atoms[2] : 0u, HC.ap3 = FAT ? Q->ph_atoms[3] : 0u;
-    const uint32_t ph_mask = ph_leaf ? Q->ph_mask : 0u;
+    const uint32_t ph_mask = ph_leaf ? qc_ph_mask : 0u;
     HC.nph = !FAT ? 0u : phrase ? nterms : (uint32_t)__popc(ph_mask);
-    HC.span = !FAT || HC.nph < 2 ? 0u : Q->ph_atoms[HC.nph - 1] - Q->ph_atoms[0];
-    HC.px_dist = FAT ? Q->px_dist : 0u;
+    {
+      const uint32_t last = HC.nph == 2 ? HC.ap1 : HC.nph == 3 ? HC.ap2 : HC.ap3;
+      HC.span = !FAT || HC.nph < 2 ? 0u : last - HC.ap0;
+    }
     HC.ranker = ranker;
-    HC.fw = L.fw;
-    HC.max_qpos = (int)Q->max_qpos, HC.n_qwords = (int)Q->n_qwords;
-    HC.inline_hits = inline_hits;
+    HC.max_qpos = (int)qc_max_qpos, HC.n_qwords = (int)qc_n_qwords;
     HC.multi_and = (flags & TF_MULTIAND) != 0 && !phrase;
     HC.quorum_hits = (flags & TF_QUORUM_HITS) != 0;
     HC.termpos = FAT && (flags & TF_TERMPOS) != 0;
     HC.order = FAT && (flags & TF_ORDER) != 0;
     HC.apack = (uint64_t)(HC.ap0 & 0xFFFFu) | ((uint64_t)(HC.ap1 & 0xFFFFu) << 16) | ((uint64_t)(HC.ap2 & 0xFFFFu) << 32) | ((uint64_t)(HC.ap3 & 0xFFFFu) << 48);
     HC.dupes = (flags & TF_DUPES) != 0 && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY);
+    // the specialized pass: proximity family, distinct keywords, hits ordered by the raw position, no MergeHits3 field quirk
+    const bool fast_prox = !FAT && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && !HC.dupes && !HC.quorum_hits && nterms >= 2 &&
+                           !(HC.multi_and && nterms == 3 && (HC.tm[0] & HC.tm[1] & HC.tm[2]) != 0xFFFFFFFFu);
 
-    const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
     const bool valid = lane < n;
-    const uint32_t rowid = d[0], fa = d[128];
-    const float tfidf = __uint_as_float(d[64]);
-    const uint32_t r0 = d[192], r1 = d[256], r2 = d[320], r3 = d[384];
+    const uint32_t rowid = cur[0], fa = cur[2];
+    const float tfidf = __uint_as_float(cur[1]);
+    const uint32_t r0 = cur[3], r1 = cur[4], r2 = cur[5], r3 = cur[6];
     bool is_live = valid;
     uint32_t fields = fa & 0xffu;
     int rk = 0;
@@ -184,7 +253,11 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
           fields = 1u << ffield; // the doc's field mask comes from its first occurrence (searchnode.cpp:3836)
         }
       } else
-        rk = hit_rank_plain(HC, r0, r1, r2, r3, smask);
+        if (fast_prox) // (uniform: decided per pass)
+          rk = nterms == 2 ? hit_rank_prox<2>(HC, r0, r1, r2, r3, smask) : nterms == 3 ? hit_rank_prox<3>(HC, r0, r1, r2, r3, smask)
+                                                                                       : hit_rank_prox<4>(HC, r0, r1, r2, r3, smask);
+        else
+          rk = hit_rank_plain(HC, r0, r1, r2, r3, smask);
     }
     // the match: weight, pruning bin, candidate buffer (emit_match of scan_pk_kernel)
     bool push = false;
@@ -206,11 +279,11 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
           rsum = 1; // empty mask: "just fake it" (sphinxsearch.cpp:1114-1118)
         else
           for (uint32_t f = 0; f < nw; ++f)
-            if (fields & (1u << f)) rsum += (uint32_t)Q->weights[f];
+            if (fields & (1u << f)) rsum += (uint32_t)L.fw[f];
         const int32_t bm = (int32_t)((tfidf + 0.5f) * 1000.0f);
         weight = ranker == MRK_RANK_PROXIMITY ? rsum : (uint32_t)bm + rsum * 1000u;
       }
-      weight *= Q->index_weight; // MatchExtended, sphinx.cpp:12220
+      weight *= qc_index_weight; // MatchExtended, sphinx.cpp:12220
       const uint32_t grow = a.seg.rowid_base + rowid;
       if (bin_of(bin_mode, bin_lo, bin_shift, (int32_t)weight, grow) >= tau_bin) {
         push = true;

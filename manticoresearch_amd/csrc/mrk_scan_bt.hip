@@ -25,6 +25,11 @@
 #include "mrk_kcommon.h"
 #include "mrk_kprune.h"
 #include "mrk_kpk.h"
+#include "mrk_kmq.h"
+
+#ifndef MRK_BTEXP
+#define MRK_BTEXP 0 // ablations for profiling: 1 no match-queue write, 2 no scoring, 3 no match extraction, 4 no sparse keywords
+#endif
 
 namespace mrk {
 
@@ -32,6 +37,7 @@ constexpr int BT_KW = MAX_PROX_TERMS; // keywords per query on this path
 constexpr int BT_CBUF = 128;          // candidates a wave collects before it publishes them
 constexpr int BT_QCAP = 128;          // match queue entries per wave (scored in batches of 64)
 constexpr int BT_WORDS = 64;          // words per window
+constexpr int BT_BURST = 4;           // windows whose bitmap words are requested back to back (one memory round trip per burst)
 
 struct __align__(16) BtWaveLds {
   uint64_t cbuf[BT_CBUF];
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
   }
 
   uint32_t total = 0, tau_bin = 0, cn = 0, qn = 0;
+  MqWriter mqw;
 
   auto publish = [&]() {
     if (cn) {
@@ -253,15 +260,21 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
     const bool live = valid && m0; // (every queued doc matched bitwise: m0 holds for all valid lanes)
     if (need_hits) {
       // a 64-doc chunk of the HBM match queue straight from registers (rank_kernel does the hit pass and the ranking)
+#if MRK_BTEXP == 1
+      total += valid ? 1u : 0u;
+      return;
+#endif
       const MatchQueue& MQ = a.mq[0];
-      uint32_t c = 0xFFFFFFFFu;
-      for (uint32_t k = 0; k < (uint32_t)MQ_SHARDS && c == 0xFFFFFFFFu; ++k) {
-        const uint32_t shard = (blockIdx.x + k) & (MQ_SHARDS - 1);
-        uint32_t got = 0;
-        if (lane == 0) got = atomicAdd(MQ.count + shard, 1u);
-        got = rdlane(got, 0);
-        if (got < MQ.cap) c = shard * MQ.cap + got;
-      }
+#if MRK_BTEXP == 6 // stores without the allocator: a private slot per wave
+      const uint32_t c = (blockIdx.x * WAVES + wave) % (MQ.cap * MQ_SHARDS);
+      total += valid ? 1u : 0u;
+#else
+      const uint32_t c = mq_take(MQ, mqw);
+#endif
+#if MRK_BTEXP == 5 // the allocator without the stores
+      total += valid ? 1u : 0u;
+      return;
+#endif
       if (c != 0xFFFFFFFFu) {
         uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
         d[0] = row;
@@ -305,21 +318,37 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
     }
   };
 
-  for (uint32_t w = w0; w < w1; ++w) {
+  for (uint32_t wb = w0; wb < w1; wb += BT_BURST) {
+    // the dense keywords' words (and the dead-row words) of BT_BURST windows, requested back to back; the query's shared
+    // pruning threshold rides along
+    uint32_t wv[BT_BURST][BT_KW], dvv[BT_BURST];
+#pragma unroll
+    for (int i = 0; i < BT_BURST; ++i) {
+      const uint32_t w = wb + i < w1 ? wb + i : w1 - 1;
+#pragma unroll
+      for (int k = 0; k < BT_KW; ++k) {
+        wv[i][k] = 0;
+        if ((uint32_t)k < nterms && dense[k]) wv[i][k] = a.seg.bm[Q->t[k].bm_off + (uint64_t)w * BT_WORDS + lane];
+      }
+      dvv[i] = dead ? dead[(uint64_t)w * BT_WORDS + lane] : 0u;
+    }
+    {
+      const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (gt > tau_bin) tau_bin = gt;
+    }
+#pragma unroll
+    for (int bi = 0; bi < BT_BURST; ++bi) {
+    const uint32_t w = wb + bi;
+    if (w >= w1) break;
     const uint32_t lo = w * 2048u, hi_m1 = lo + 2047u; // window = rowids [lo, hi_m1]
     uint32_t word[BT_KW];
-    uint32_t dv = 0;
-    // dense keywords: one coalesced load each (issued together, used after the sparse words are built)
 #pragma unroll
-    for (int k = 0; k < BT_KW; ++k) {
-      word[k] = 0;
-      if ((uint32_t)k < nterms && dense[k]) word[k] = a.seg.bm[Q->t[k].bm_off + (uint64_t)w * BT_WORDS + lane];
-    }
-    if (dead) dv = dead[(uint64_t)w * BT_WORDS + lane];
+    for (int k = 0; k < BT_KW; ++k) word[k] = wv[bi][k];
+    const uint32_t dv = dvv[bi];
     // sparse keywords: the cursor's docs that fall into the window
 #pragma unroll
     for (int k = 0; k < BT_KW; ++k) {
-      if ((uint32_t)k < nterms && !dense[k] && kj[k] != 0xFFFFFFFFu) {
+      if (MRK_BTEXP != 4 && (uint32_t)k < nterms && !dense[k] && kj[k] != 0xFFFFFFFFu) {
         const DevTerm& T = Q->t[k];
         bool zeroed = false;
         for (;;) {
@@ -344,10 +373,6 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
         }
       }
     }
-    {
-      const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (gt > tau_bin) tau_bin = gt;
-    }
     // the tree on 32 rowids per lane
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
@@ -364,6 +389,10 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
       }
     }
     uint32_t m = s0 & ~dv;
+#if MRK_BTEXP == 3
+    total += (uint32_t)__popc(m);
+    m = 0;
+#endif
     // ranks of the lane's first bit: one prefix sum carries two keywords' popcounts
     uint32_t r0[BT_KW];
 #pragma unroll
@@ -400,13 +429,19 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
       qn += (uint32_t)__popcll(bal);
       m &= m - 1u;
       if (qn >= 64u) {
+#if MRK_BTEXP != 2
         score(qn - 64u, 64u);
+#else
+        total += 64u;
+#endif
         qn -= 64u;
         wave_lds_fence(); // the scored entries' slots may be rewritten
       }
     }
+    } // windows of the burst
   }
   if (qn) score(0, qn);
+  if (need_hits) mq_close(a.mq[0], mqw, item.query);
   if (cn) publish();
   {
     uint32_t t = total;

@@ -12,6 +12,7 @@
 #include "mrk_kprune.h"
 #include "mrk_khits.h"
 #include "mrk_kpk.h"
+#include "mrk_kmq.h"
 
 #ifndef MRK_EXP
 #define MRK_EXP 0
@@ -227,21 +228,13 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   // chunk, one coalesced 256-B row per plane.  Queries with PHRASE / PROXIMITY / BEFORE nodes or position modifiers go to
   // the second queue, whose consumer carries the word state machines.
   uint32_t mqn = 0;
+  MqWriter mqw;
   const bool fat_q = (Q->tree_flags & (TF_PHRASE | TF_PHRASE_LEAF | TF_TERMPOS | TF_ORDER)) != 0;
   auto flush_matches = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
     if (!PROX) return;
     wave_lds_fence();
     const MatchQueue& MQ = a.mq[fat_q ? 1 : 0];
-    // a chunk from the workgroup's own shard, else from the next shard that still has room (together the shards hold
-    // every chunk the batch can produce; a single busy workgroup may need more than its own shard's share)
-    uint32_t c = 0xFFFFFFFFu;
-    for (uint32_t k = 0; k < (uint32_t)MQ_SHARDS && c == 0xFFFFFFFFu; ++k) {
-      const uint32_t shard = (blockIdx.x + k) & (MQ_SHARDS - 1);
-      uint32_t got = 0;
-      if (lane == 0) got = atomicAdd(MQ.count + shard, 1u);
-      got = rdlane(got, 0);
-      if (got < MQ.cap) c = shard * MQ.cap + got;
-    }
+    const uint32_t c = mq_take(MQ, mqw);
     if (c != 0xFFFFFFFFu) {
       uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
       const uint32_t e = from + lane; // (entries past n are stale slots; the header's count masks them)
@@ -258,7 +251,11 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   // in-scan hit reading (EXT instance only): does a PHRASE / BEFORE node below other operators occur in the doc, does a
   // keyword with a position modifier hold it
   HitCtx HC;
-  HC.Q = Q;
+#pragma unroll
+  for (int t = 0; t < MAX_PROX_TERMS; ++t) {
+    const DevTerm& Tt = Q->t[t];
+    HC.tb[t] = Tt.blk_first, HC.tq[t] = Tt.qpos, HC.tm[t] = Tt.queried32, HC.tpk[t] = Tt.tp_kind, HC.tpm[t] = Tt.tp_max;
+  }
   HC.spp = a.seg.spp;
   HC.hit = a.seg.pk_hit;
   HC.hbase = a.seg.pk_hbase;
@@ -773,6 +770,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
     }
   }
   if (PROX && mqn) flush_matches(0u, mqn);
+  if (PROX) mq_close(a.mq[fat_q ? 1 : 0], mqw, item.query);
 
   // ---- wave epilogue
   if (cn) publish();
