@@ -20,10 +20,14 @@
  *                           (sphinxsort.cpp:681-710; sphinxrt.cpp:5945-5981)
  *   mrk_idf              <- the IDF block of sphCreateRanker (sphinxsearch.cpp:4317-4361)
  *
- * Threading: a mrk_ctx owns one HIP device + stream; a mrk_batch is used by one thread
- * at a time; different batches may be driven from different threads.  All HIP calls are
- * made on the calling thread: a host that runs rankers on small coroutine stacks
- * (coroutine.cpp:47) must call from a regular thread.
+ * Threading: a mrk_ctx owns one HIP device, its streams and ONE internal submission thread: every
+ * entry point that reaches the HIP runtime posts its work there and sleeps until it has run, so
+ * nothing of HIP executes on the caller's stack -- the reference runs rankers on 128 KB coroutine
+ * stacks (coroutine.cpp:47) -- and all of a context's host state is touched by one thread only.
+ * A mrk_batch is used by one thread at a time; different batches (and segments) of one context
+ * may be driven from different threads concurrently.  mrk_batch_wait polls the batch's stream
+ * and steps aside for other threads' submits instead of parking the submission thread.
+ * MRK_INLINE_HIP=1 in the environment runs everything on the calling thread instead.
  *
  * Errors: every function returns MRK_OK (0) or a negative code; mrk_last_error() gives
  * the message for the calling thread (the reference's convention: no exceptions, error

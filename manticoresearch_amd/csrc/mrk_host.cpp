@@ -12,6 +12,10 @@
 #include <new>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -165,7 +169,7 @@ struct mrk_batch {
 // ----------------------------------------------------------------------------------------
 // ctx
 // ----------------------------------------------------------------------------------------
-extern "C" int mrk_ctx_create(int device, mrk_ctx** out) {
+static int mrk_ctx_create_impl(int device, mrk_ctx** out) {
   if (!out) return mrk_fail(MRK_E_INVAL, "mrk_ctx_create: out is NULL");
   int n = 0;
   HIP_TRY(hipGetDeviceCount(&n));
@@ -187,7 +191,7 @@ extern "C" int mrk_ctx_create(int device, mrk_ctx** out) {
   return MRK_OK;
 }
 
-extern "C" void mrk_ctx_destroy(mrk_ctx* c) {
+static void mrk_ctx_destroy_impl(mrk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -258,7 +262,7 @@ static inline uint64_t unzip64(const uint8_t*& p, const uint8_t* end, bool& ok) 
   return res;
 }
 
-extern "C" void mrk_segment_destroy(mrk_segment* s) {
+static void mrk_segment_destroy_impl(mrk_segment* s) {
   if (!s) return;
   if (s->ctx) (void)hipSetDevice(s->ctx->device);
   if (s->d_spd) (void)hipFree(s->d_spd);
@@ -282,7 +286,7 @@ extern "C" void mrk_segment_destroy(mrk_segment* s) {
   delete s;
 }
 
-extern "C" int mrk_segment_set_dead_rows(mrk_segment* s, const uint32_t* bitmap, uint64_t n_rows) {
+static int mrk_segment_set_dead_rows_impl(mrk_segment* s, const uint32_t* bitmap, uint64_t n_rows) {
   if (!s || !s->ctx) return mrk_fail(MRK_E_INVAL, "mrk_segment_set_dead_rows: NULL segment");
   if (bitmap && n_rows < s->total_docs)
     return mrk_fail(MRK_E_INVAL, "mrk_segment_set_dead_rows: map covers %llu rows, segment has %llu", (unsigned long long)n_rows,
@@ -305,7 +309,7 @@ extern "C" int mrk_segment_set_dead_rows(mrk_segment* s, const uint32_t* bitmap,
   return MRK_OK;
 }
 
-extern "C" int mrk_segment_set_attrs(mrk_segment* s, const uint32_t* rows, uint32_t stride, uint64_t n_rows) {
+static int mrk_segment_set_attrs_impl(mrk_segment* s, const uint32_t* rows, uint32_t stride, uint64_t n_rows) {
   if (!s || !s->ctx) return mrk_fail(MRK_E_INVAL, "mrk_segment_set_attrs: NULL segment");
   if (rows && (stride == 0 || stride > 4096)) return mrk_fail(MRK_E_INVAL, "mrk_segment_set_attrs: row stride %u dwords", stride);
   if (rows && n_rows < s->total_docs)
@@ -446,7 +450,7 @@ extern "C" int mrk_segment_validate(const mrk_segment_desc* d) {
   }
 }
 
-extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_segment** out) {
+static int mrk_segment_create_impl(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_segment** out) {
   if (!ctx || !d || !out) return mrk_fail(MRK_E_INVAL, "mrk_segment_create: NULL argument");
   {
     const int rc0 = check_desc(d);
@@ -482,7 +486,7 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
   if (!packed) { // no transcode, no walk by pack_term: validate every doclist before any of it reaches the VLB kernel
     const int rcv = validate_doclists(d, {});
     if (rcv != MRK_OK) {
-      mrk_segment_destroy(s);
+      mrk_segment_destroy_impl(s);
       return rcv;
     }
   }
@@ -512,7 +516,7 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
       for (uint32_t t = 0; t < d->n_terms; ++t)
         if (errs[t].compare(0, 8, "corrupt:") == 0) { // malformed bytes: nothing of this segment may reach a kernel
           const int rc = mrk_fail(MRK_E_FORMAT, "mrk_segment_create: term %u: %s", t, errs[t].c_str() + 9);
-          mrk_segment_destroy(s);
+          mrk_segment_destroy_impl(s);
           return rc;
         }
       // e.g. field masks wider than 8 bits: this segment is served by the VLB path only.  pack_term stopped at the
@@ -524,7 +528,7 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
         if (!errs[t].empty()) rest.push_back(t);
       const int rcv = validate_doclists(d, rest);
       if (rcv != MRK_OK) {
-        mrk_segment_destroy(s);
+        mrk_segment_destroy_impl(s);
         return rcv;
       }
       for (uint32_t t = 0; t < d->n_terms; ++t)
@@ -584,12 +588,12 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
         (rc = upload(&s->d_pk_exc, pk_exc.data(), pk_exc.size() * 8, 64, ctx->stream)) != MRK_OK ||
         (rc = upload(&s->d_pk_hit, pk_hit.data(), pk_hit.size() * 4, 64, ctx->stream)) != MRK_OK ||
         (rc = upload(&s->d_pk_hbase, pk_hbase.data(), pk_hbase.size() * 8, 64, ctx->stream)) != MRK_OK) {
-      mrk_segment_destroy(s);
+      mrk_segment_destroy_impl(s);
       return rc;
     }
     if (attr1_ok && !bm_words.empty() && pk_attr1.size() == pk_hit.size()) { // only the bitmap kernel reads it
       if ((rc = upload(&s->d_pk_attr1, pk_attr1.data(), pk_attr1.size(), 64, ctx->stream)) != MRK_OK) {
-        mrk_segment_destroy(s);
+        mrk_segment_destroy_impl(s);
         return rc;
       }
       s->device_bytes += pk_attr1.size();
@@ -597,7 +601,7 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
     if (!bm_words.empty()) {
       if ((rc = upload(&s->d_bm, bm_words.data(), bm_words.size() * 4, 1024, ctx->stream)) != MRK_OK ||
           (rc = upload(&s->d_bm_dir, bm_dir.data(), bm_dir.size() * 4, 64, ctx->stream)) != MRK_OK) {
-        mrk_segment_destroy(s);
+        mrk_segment_destroy_impl(s);
         return rc;
       }
       s->device_bytes += bm_words.size() * 4 + bm_dir.size() * 4;
@@ -610,12 +614,12 @@ extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_s
       (rc = upload(&s->d_blk_base, blk_base.data(), nb * 4, 64, ctx->stream)) != MRK_OK ||
       (rc = upload(&s->d_blk_off, blk_off.data(), nb * 8, 64, ctx->stream)) != MRK_OK ||
       (rc = upload(&s->d_blk_hit, blk_hit.data(), nb * 8, 64, ctx->stream)) != MRK_OK) {
-    mrk_segment_destroy(s);
+    mrk_segment_destroy_impl(s);
     return rc;
   }
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
-    mrk_segment_destroy(s);
+    mrk_segment_destroy_impl(s);
     return mrk_fail(MRK_E_HIP, "segment upload: %s", hipGetErrorString(e));
   }
   s->device_bytes += d->spd_len + (d->spp ? d->spp_len : 0) + nb * 20 + 5 * 64;
@@ -666,7 +670,7 @@ extern "C" float mrk_idf(int64_t term_docs, int64_t total_docs, int plain_idf, i
 // ----------------------------------------------------------------------------------------
 // batch
 // ----------------------------------------------------------------------------------------
-extern "C" void mrk_batch_destroy(mrk_batch* b) {
+static void mrk_batch_destroy_impl(mrk_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
   if (b->in_flight && b->stream) (void)hipStreamSynchronize(b->stream);
@@ -696,7 +700,7 @@ extern "C" void mrk_batch_destroy(mrk_batch* b) {
   b->d_decl.release();
   for (int i = 0; i < 2; ++i) b->d_mq_data[i].release(), b->d_mq_hdr[i].release();
   b->d_mq_count.release();
-  if (b->retry) mrk_batch_destroy(b->retry);
+  if (b->retry) mrk_batch_destroy_impl(b->retry);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
   if (b->ev_scan1) (void)hipEventDestroy(b->ev_scan1);
@@ -704,7 +708,7 @@ extern "C" void mrk_batch_destroy(mrk_batch* b) {
   delete b;
 }
 
-extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** out) {
+static int mrk_batch_create_impl(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** out) {
   if (!ctx || !out || !max_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_create: bad argument");
   HIP_TRY(hipSetDevice(ctx->device));
   mrk_batch* b = new (std::nothrow) mrk_batch();
@@ -719,7 +723,7 @@ extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** 
       (rc = b->d_state.reserve(nq * (8 + 8 + 4 + 4 + 4 + (size_t)NBINS * 4))) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
       (rc = b->d_kq.reserve(nq)) || (rc = b->d_out_keys.reserve(nq * KCAP)) || (rc = b->d_out_cnt.reserve(nq)) ||
       (rc = b->h_flags.reserve(nq)) || (rc = b->h_cand_n.reserve(nq)) || (rc = b->h_decl.reserve(nq)) || (rc = b->d_decl.reserve(nq)) || (rc = b->d_mq_count.reserve(2 * mrk::MQ_SHARDS))) {
-    mrk_batch_destroy(b);
+    mrk_batch_destroy_impl(b);
     return rc;
   }
   {
@@ -734,7 +738,7 @@ extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** 
   hipError_t e1 = hipEventCreate(&b->ev_scan0), e2 = hipEventCreate(&b->ev_scan1), e3 = hipEventCreate(&b->ev_merge1);
   if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-    mrk_batch_destroy(b);
+    mrk_batch_destroy_impl(b);
     return mrk_fail(MRK_E_HIP, "hipEventCreate failed");
   }
   b->rowid.resize(nq * KCAP);
@@ -784,7 +788,7 @@ static int bind_match_queues(mrk_batch* b, const uint64_t chunks[2], mrk::ScanAr
   return MRK_OK;
 }
 
-extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n) {
+static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n) {
   if (!b || !seg || (!queries && n)) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: NULL argument");
   if (n > b->max_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: %u queries > batch capacity %u", n, b->max_queries);
   if (seg->ctx != b->ctx) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: segment and batch belong to different contexts");
@@ -1028,7 +1032,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   mrk_segment* seg = b->last_seg;
   if (!seg) return mrk_fail(MRK_E_INVAL, "query %u: candidate list overflowed and the segment is gone", qi);
   if (!b->retry) {
-    int rc = mrk_batch_create(b->ctx, 1 + MAX_PASSES, &b->retry);
+    int rc = mrk_batch_create_impl(b->ctx, 1 + MAX_PASSES, &b->retry);
     if (rc != MRK_OK) return rc;
   }
   mrk_batch* r = b->retry;
@@ -1136,7 +1140,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   return MRK_OK;
 }
 
-extern "C" int mrk_batch_wait(mrk_batch* b) {
+static int mrk_batch_wait_impl(mrk_batch* b) {
   if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_wait: NULL batch");
   if (!b->in_flight) return MRK_OK;
   HIP_TRY(hipSetDevice(b->ctx->device));
@@ -1164,7 +1168,7 @@ extern "C" int mrk_batch_wait(mrk_batch* b) {
   return MRK_OK;
 }
 
-extern "C" int mrk_batch_result(mrk_batch* b, uint32_t q, mrk_result* out) {
+static int mrk_batch_result_impl(mrk_batch* b, uint32_t q, mrk_result* out) {
   if (!b || !out) return mrk_fail(MRK_E_INVAL, "mrk_batch_result: NULL argument");
   if (b->in_flight) return mrk_fail(MRK_E_INVAL, "mrk_batch_result: call mrk_batch_wait first");
   if (q >= b->n_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_result: query %u of %u", q, b->n_queries);
@@ -1212,7 +1216,7 @@ extern "C" int mrk_batch_device_results(mrk_batch* b, const uint64_t** keys, con
   return MRK_OK;
 }
 
-extern "C" int mrk_batch_export_device(mrk_batch* b, uint64_t* keys_dst, uint32_t* counts_dst, uint64_t* totals_dst) {
+static int mrk_batch_export_device_impl(mrk_batch* b, uint64_t* keys_dst, uint32_t* counts_dst, uint64_t* totals_dst) {
   if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_export_device: NULL batch");
   HIP_TRY(hipSetDevice(b->ctx->device));
   hipStream_t st = b->stream;
@@ -1231,14 +1235,14 @@ extern "C" int mrk_batch_set_rows_dst(mrk_batch* b, uint64_t* rows_dst) {
   return MRK_OK;
 }
 
-extern "C" int mrk_batch_record_event(mrk_batch* b, void* hip_event) {
+static int mrk_batch_record_event_impl(mrk_batch* b, void* hip_event) {
   if (!b || !hip_event) return mrk_fail(MRK_E_INVAL, "mrk_batch_record_event: NULL argument");
   HIP_TRY(hipSetDevice(b->ctx->device));
   HIP_TRY(hipEventRecord((hipEvent_t)hip_event, b->stream));
   return MRK_OK;
 }
 
-extern "C" int mrk_batch_export_rows(mrk_batch* b, uint64_t* rows_dst) {
+static int mrk_batch_export_rows_impl(mrk_batch* b, uint64_t* rows_dst) {
   if (!b || !rows_dst) return mrk_fail(MRK_E_INVAL, "mrk_batch_export_rows: NULL argument");
   HIP_TRY(hipSetDevice(b->ctx->device));
   PackRowsArgs pa{};
@@ -1256,7 +1260,7 @@ extern "C" int mrk_batch_export_rows(mrk_batch* b, uint64_t* rows_dst) {
   return MRK_OK;
 }
 
-extern "C" int mrk_topk_merge_rows(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+static int mrk_topk_merge_rows_impl(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
                                    uint64_t* out_rows) {
   if (!ctx || !rows_all || !out_rows) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows: NULL argument");
   if (k == 0 || k > MRK_MAX_K) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows: k %u outside 1..%d", k, MRK_MAX_K);
@@ -1273,7 +1277,7 @@ extern "C" int mrk_topk_merge_rows(mrk_ctx* ctx, const uint64_t* rows_all, uint3
   return MRK_OK;
 }
 
-extern "C" int mrk_topk_merge_rows_async(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+static int mrk_topk_merge_rows_async_impl(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
                                          uint64_t* out_rows, void* wait_event, uint32_t slot) {
   if (!ctx || !rows_all || !out_rows) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows_async: NULL argument");
   if (k == 0 || k > MRK_MAX_K) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows_async: k %u outside 1..%d", k, MRK_MAX_K);
@@ -1295,7 +1299,7 @@ extern "C" int mrk_topk_merge_rows_async(mrk_ctx* ctx, const uint64_t* rows_all,
   return MRK_OK;
 }
 
-extern "C" int mrk_merge_wait(mrk_ctx* ctx, uint32_t slot) {
+static int mrk_merge_wait_impl(mrk_ctx* ctx, uint32_t slot) {
   if (!ctx || slot >= MRK_MERGE_SLOTS) return mrk_fail(MRK_E_INVAL, "mrk_merge_wait: bad argument");
   if (!ctx->merge_used[slot]) return MRK_OK;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1303,7 +1307,7 @@ extern "C" int mrk_merge_wait(mrk_ctx* ctx, uint32_t slot) {
   return MRK_OK;
 }
 
-extern "C" int mrk_topk_merge(mrk_ctx* ctx, const uint64_t* in_keys, const uint32_t* in_counts, uint32_t n_lists,
+static int mrk_topk_merge_impl(mrk_ctx* ctx, const uint64_t* in_keys, const uint32_t* in_counts, uint32_t n_lists,
                               uint32_t n_queries, uint32_t k, uint64_t* out_keys, uint32_t* out_counts) {
   if (!ctx || !in_keys || !in_counts || !out_keys || !out_counts) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge: NULL argument");
   if (k == 0 || k > MRK_MAX_K) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge: k %u outside 1..%d", k, MRK_MAX_K);
@@ -1323,4 +1327,198 @@ extern "C" int mrk_topk_merge(mrk_ctx* ctx, const uint64_t* in_keys, const uint3
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->merge_stream));
   return MRK_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// The C-ABI proper: every entry point that reaches the HIP runtime runs its body on the context's SUBMISSION THREAD.
+//
+// The reference runs rankers on 128 KB coroutine stacks (coroutine.cpp:47) and many of them at once on a thread pool
+// (searchd.cpp:5654); HIP runtime calls need a real thread stack, and hipSetDevice is per thread.  So a context owns one
+// worker thread: callers post a closure and sleep until it has run (plain mutex + condition variable on the caller's
+// side: nothing of HIP on the caller's stack), the worker runs closures in arrival order.  That also serializes all
+// host-side state of a context (its streams, merge slots, the segment tables): batches driven from different threads
+// are safe by construction.  A wait never parks the worker inside hipStreamSynchronize while other work is queued: it
+// polls the batch's stream and steps aside (see mrk_batch_wait below), so one thread's wait does not hold up another
+// thread's submit.  MRK_INLINE_HIP=1 (environment, read at mrk_ctx_create) runs everything on the calling thread
+// instead -- for debuggers and profilers.
+// ----------------------------------------------------------------------------------------
+struct mrk_worker {
+  std::thread th;
+  std::thread::id tid;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  bool stop = false;
+
+  void loop() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty()) return; // stop requested and nothing left to run
+        f = std::move(q.front());
+        q.pop_front();
+      }
+      f();
+    }
+  }
+  size_t pending() {
+    std::lock_guard<std::mutex> lk(mu);
+    return q.size();
+  }
+};
+
+// run f (-> int status) on the context's worker and hand back its status; the worker's error text travels with it
+template <typename F>
+static int on_worker(mrk_ctx* c, F&& f) {
+  mrk_worker* w = c ? c->worker : nullptr;
+  if (!w || std::this_thread::get_id() == w->tid) return f();
+  int rc = MRK_OK;
+  char err[sizeof g_err];
+  err[0] = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  bool done = false;
+  {
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->q.emplace_back([&] {
+      rc = f();
+      if (rc != MRK_OK) memcpy(err, g_err, sizeof err);
+      std::lock_guard<std::mutex> lk2(m);
+      done = true;
+      cv.notify_one();
+    });
+  }
+  w->cv.notify_one();
+  {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return done; });
+  }
+  if (rc != MRK_OK) memcpy(g_err, err, sizeof g_err);
+  return rc;
+}
+
+extern "C" int mrk_ctx_create(int device, mrk_ctx** out) {
+  if (!out) return mrk_fail(MRK_E_INVAL, "mrk_ctx_create: out is NULL");
+  static const bool inline_hip = getenv("MRK_INLINE_HIP") != nullptr;
+  if (inline_hip) return mrk_ctx_create_impl(device, out);
+  mrk_worker* w = new (std::nothrow) mrk_worker();
+  if (!w) return mrk_fail(MRK_E_NOMEM, "out of memory");
+  w->th = std::thread([w] { w->loop(); });
+  w->tid = w->th.get_id();
+  // the context is created ON the worker (hipSetDevice is per thread) through a stand-in that only carries the worker
+  mrk_ctx boot;
+  boot.worker = w;
+  const int rc = on_worker(&boot, [&] { return mrk_ctx_create_impl(device, out); });
+  if (rc != MRK_OK) {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->stop = true;
+    }
+    w->cv.notify_one();
+    w->th.join();
+    delete w;
+    return rc;
+  }
+  (*out)->worker = w;
+  return MRK_OK;
+}
+
+extern "C" void mrk_ctx_destroy(mrk_ctx* c) {
+  if (!c) return;
+  mrk_worker* w = c->worker;
+  if (!w) return mrk_ctx_destroy_impl(c);
+  mrk_ctx boot;
+  boot.worker = w;
+  (void)on_worker(&boot, [&] {
+    mrk_ctx_destroy_impl(c);
+    return MRK_OK;
+  });
+  {
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->stop = true;
+  }
+  w->cv.notify_one();
+  w->th.join();
+  delete w;
+}
+
+extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_segment** out) {
+  return on_worker(ctx, [&] { return mrk_segment_create_impl(ctx, d, out); });
+}
+extern "C" void mrk_segment_destroy(mrk_segment* s) {
+  if (s) (void)on_worker(s->ctx, [&] {
+    mrk_segment_destroy_impl(s);
+    return MRK_OK;
+  });
+}
+extern "C" int mrk_segment_set_dead_rows(mrk_segment* s, const uint32_t* bitmap, uint64_t n_rows) {
+  return on_worker(s ? s->ctx : nullptr, [&] { return mrk_segment_set_dead_rows_impl(s, bitmap, n_rows); });
+}
+extern "C" int mrk_segment_set_attrs(mrk_segment* s, const uint32_t* rows, uint32_t stride, uint64_t n_rows) {
+  return on_worker(s ? s->ctx : nullptr, [&] { return mrk_segment_set_attrs_impl(s, rows, stride, n_rows); });
+}
+extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** out) {
+  return on_worker(ctx, [&] { return mrk_batch_create_impl(ctx, max_queries, out); });
+}
+extern "C" void mrk_batch_destroy(mrk_batch* b) {
+  if (b) (void)on_worker(b->ctx, [&] {
+    mrk_batch_destroy_impl(b);
+    return MRK_OK;
+  });
+}
+extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n) {
+  return on_worker(b ? b->ctx : nullptr, [&] { return mrk_batch_submit_impl(b, seg, queries, n); });
+}
+
+// The wait polls instead of parking the worker in hipStreamSynchronize: while the batch's stream is still busy AND
+// other closures are queued (another thread's submit), the attempt steps aside and the caller tries again; with
+// nothing else queued the worker keeps polling itself, so a lone caller sees the result as soon as the stream drains.
+extern "C" int mrk_batch_wait(mrk_batch* b) {
+  if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_wait: NULL batch");
+  mrk_worker* w = b->ctx ? b->ctx->worker : nullptr;
+  if (!w) return mrk_batch_wait_impl(b);
+  constexpr int NOT_READY = 1;
+  for (;;) {
+    const int rc = on_worker(b->ctx, [&]() -> int {
+      if (!b->in_flight) return MRK_OK;
+      for (;;) {
+        const hipError_t e = hipStreamQuery(b->stream);
+        if (e == hipSuccess) return mrk_batch_wait_impl(b); // (drained: the synchronize inside returns at once)
+        if (e != hipErrorNotReady) return mrk_fail(MRK_E_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
+        if (w->pending()) return NOT_READY; // let the queued closures run
+        std::this_thread::yield();
+      }
+    });
+    if (rc != NOT_READY) return rc;
+    std::this_thread::yield();
+  }
+}
+
+extern "C" int mrk_batch_result(mrk_batch* b, uint32_t q, mrk_result* out) {
+  return on_worker(b ? b->ctx : nullptr, [&] { return mrk_batch_result_impl(b, q, out); });
+}
+extern "C" int mrk_batch_export_device(mrk_batch* b, uint64_t* keys_dst, uint32_t* counts_dst, uint64_t* totals_dst) {
+  return on_worker(b ? b->ctx : nullptr, [&] { return mrk_batch_export_device_impl(b, keys_dst, counts_dst, totals_dst); });
+}
+extern "C" int mrk_batch_record_event(mrk_batch* b, void* hip_event) {
+  return on_worker(b ? b->ctx : nullptr, [&] { return mrk_batch_record_event_impl(b, hip_event); });
+}
+extern "C" int mrk_batch_export_rows(mrk_batch* b, uint64_t* rows_dst) {
+  return on_worker(b ? b->ctx : nullptr, [&] { return mrk_batch_export_rows_impl(b, rows_dst); });
+}
+extern "C" int mrk_topk_merge_rows(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k, uint64_t* out_rows) {
+  return on_worker(ctx, [&] { return mrk_topk_merge_rows_impl(ctx, rows_all, n_lists, n_queries, k, out_rows); });
+}
+extern "C" int mrk_topk_merge_rows_async(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                                         uint64_t* out_rows, void* wait_event, uint32_t slot) {
+  return on_worker(ctx, [&] { return mrk_topk_merge_rows_async_impl(ctx, rows_all, n_lists, n_queries, k, out_rows, wait_event, slot); });
+}
+extern "C" int mrk_merge_wait(mrk_ctx* ctx, uint32_t slot) {
+  return on_worker(ctx, [&] { return mrk_merge_wait_impl(ctx, slot); });
+}
+extern "C" int mrk_topk_merge(mrk_ctx* ctx, const uint64_t* in_keys, const uint32_t* in_counts, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                              uint64_t* out_keys, uint32_t* out_counts) {
+  return on_worker(ctx, [&] { return mrk_topk_merge_impl(ctx, in_keys, in_counts, n_lists, n_queries, k, out_keys, out_counts); });
 }

@@ -14,7 +14,10 @@ using mrk::DevQuery;
 using mrk::DevSegment;
 using mrk::DevTerm;
 
+struct mrk_worker; // the context's submission thread (mrk_host.cpp)
+
 struct mrk_ctx {
+  mrk_worker* worker = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t merge_stream = nullptr; // mrk_topk_merge: never queued behind the scans of a following batch

@@ -40,3 +40,15 @@ def test_cpp_ranker_two_chunks(orc, tmp_path):
     allm.sort()
     want = sorted((w, r) for w, r, _ in allm[:1000])
     assert sorted((-w, r) for _, r, w in got) == want
+
+
+def test_two_host_threads_one_context(tmp_path):
+    """Different batches of one context driven from two host threads at once (include/mrk.h, "Threading"): every HIP
+    call runs on the context's submission thread, results equal the single-threaded ones round after round, error texts
+    stay with the thread that caused them."""
+    exe = str(tmp_path / "test_threads")
+    lib = os.path.join(ROOT, "manticoresearch_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "test_threads.cpp"), "-o", exe,
+                           "-L" + lib, "-lmrk", "-lpthread", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe, "400000", "60"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "two threads ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
