@@ -102,6 +102,10 @@ def main() -> None:
     # path a one-GPU box can run)
     if (args.gpus > 1 or os.environ.get("MRK_FORCE_DIST")) and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(max(1, args.gpus)))  # no torch, no HIP in this process
+    if os.environ.get("MRK_DEBUG_HANG"):  # dump every thread's Python stack if the run is still going after that many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["MRK_DEBUG_HANG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,7 +154,9 @@ def main() -> None:
     # global DF / N so that every shard ranks with the same IDF (local_df, sphinxrt.cpp:6501-6521)
     local_docs = hi.dict["docs"].astype(np.int64)
     if world > 1 or force_dist:
-        global_docs, total_docs = mdist.global_df(local_docs, shard_docs, local_rank)
+        if not os.environ.get("MRK_TORCH_EXCHANGE"):  # default: the exchange and the DF sums through the library's own RCCL communicator
+            mdist.lib_comm_init(ctx)
+        global_docs, total_docs = mdist.global_df(local_docs, shard_docs, local_rank, ctx=ctx)
     else:
         global_docs, total_docs = local_docs, shard_docs
 
@@ -456,6 +462,7 @@ def main() -> None:
     for st_ in sets:
         for bb in st_.values():
             bb.close()
+    batch.close()
     seg.close()
     ctx.close()
     if world > 1 or force_dist:

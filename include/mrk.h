@@ -186,6 +186,7 @@ typedef struct {
 const char* mrk_last_error(void);
 
 int mrk_ctx_create(int device, mrk_ctx** out);
+/* destroy a context's segments and batches BEFORE the context: their destructors run on its submission thread */
 void mrk_ctx_destroy(mrk_ctx* ctx);
 /* tunables: "item_bytes" (work-item size target); "pack" (1 = build packed doclists at segment
    load, default); "path" (0 = packed when present, 1 = VLB-direct, 2 = packed only);
@@ -275,6 +276,29 @@ int mrk_topk_merge_rows(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists
 int mrk_topk_merge_rows_async(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
                               uint64_t* out_rows, void* wait_event, uint32_t slot);
 int mrk_merge_wait(mrk_ctx* ctx, uint32_t slot);
+
+/* ------------------------------------------------------------------------------------
+ * The shard exchange inside the library (one process per GPU, segments = rowid ranges): RCCL over xGMI, loaded at run
+ * time; a C / C++ host needs no Python for it.  Stands in for SearchHandler_c::SetupLocalDF (searchd.cpp:5869-5990) and
+ * the merge of per-chunk sorters (sphinxsort.cpp:681-710, sphinxrt.cpp:5945-5950) across the local indexes of one node.
+ *
+ *   rank 0: mrk_comm_unique_id(id), ship the MRK_COMM_ID_BYTES to the other ranks by any means (file, socket, MPI ...);
+ *   every rank: mrk_comm_init(ctx, id, n_ranks, rank)            -- collective, like ncclCommInitRank;
+ *   once per index:  mrk_comm_allreduce_i64(ctx, docs, n)       -- per-keyword document counts and the document total,
+ *                    summed over the shards: the values of mrk_query.local_docs / total_docs_override (local_df);
+ *   per batch:       mrk_batch_set_rows_dst(batch, rows) once, then after each mrk_batch_submit
+ *                    mrk_shard_exchange(ctx, batch, rows, n_queries, k, out_rows, slot)
+ *                    queues event -> all-gather of the rows -> merge kernel -> out_rows (device or pinned host memory)
+ *                    as one stream-ordered chain and returns at once; mrk_merge_wait(ctx, slot) blocks until out_rows is
+ *                    written.  Rows carry MRK_ROW_RERUN / MRK_ROW_DECLINED through the merge (see above).
+ * ---------------------------------------------------------------------------------- */
+#define MRK_COMM_ID_BYTES 128
+int mrk_comm_unique_id(uint8_t id_out[MRK_COMM_ID_BYTES]);
+int mrk_comm_init(mrk_ctx* ctx, const uint8_t id[MRK_COMM_ID_BYTES], int n_ranks, int rank);
+void mrk_comm_destroy(mrk_ctx* ctx); /* also done by mrk_ctx_destroy */
+int mrk_comm_allreduce_i64(mrk_ctx* ctx, int64_t* values, uint64_t n);
+int mrk_shard_exchange(mrk_ctx* ctx, mrk_batch* batch, const uint64_t* rows, uint32_t n_queries, uint32_t k, uint64_t* out_rows,
+                       uint32_t slot);
 
 /* merge n_lists sorted partial top-K lists per query (device pointers):
    in_keys[(l*n_queries + q)*MRK_MAX_K + i], in_counts[l*n_queries + q] -> out_keys[q*MRK_MAX_K + i],

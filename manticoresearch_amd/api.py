@@ -329,15 +329,45 @@ class Matches:
 # --------------------------------------------------------------------------- device objects
 class Context:
     def __init__(self, device: int = 0):
+        import weakref
+
         self._h = C.c_void_p()
         check(lib().mrk_ctx_create(device, C.byref(self._h)))
         self.device = device
+        # segments and batches belong to the context (their destructors run on its submission thread): close() takes the
+        # ones still alive down first, so that no late __del__ ever reaches into a destroyed context
+        self._children = weakref.WeakSet()
 
     def set(self, key: str, value: int) -> None:
         check(lib().mrk_ctx_set(self._h, key.encode(), value))
 
+    # --- the shard exchange inside the library (RCCL loaded at run time; include/mrk.h "The shard exchange") ---
+    has_comm = False
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the communicator id to ship to every other rank (MRK_COMM_ID_BYTES)."""
+        buf = (C.c_uint8 * 128)()
+        check(lib().mrk_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, comm_id: bytes, n_ranks: int, rank: int) -> None:
+        """Collective over all ranks (ncclCommInitRank on this context's device)."""
+        assert len(comm_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(comm_id)
+        check(lib().mrk_comm_init(self._h, buf, n_ranks, rank))
+        self.has_comm = True
+
+    def comm_allreduce(self, values: np.ndarray) -> np.ndarray:
+        """Sum of an int64 array over the ranks (document frequencies + N: local_df)."""
+        a = np.ascontiguousarray(values, dtype=np.int64).copy()
+        check(lib().mrk_comm_allreduce_i64(self._h, a.ctypes.data, a.size))
+        return a
+
     def close(self) -> None:
         if self._h:
+            for child in list(self._children):
+                child.close()
             lib().mrk_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -374,6 +404,7 @@ class Segment:
         self.host = hi
         d = _segment_desc(hi, rowid_base)
         self._h = C.c_void_p()
+        ctx._children.add(self)
         check(lib().mrk_segment_create(ctx._h, C.byref(d), C.byref(self._h)))
 
     @property
@@ -417,6 +448,7 @@ class Batch:
         self.max_queries = max_queries
         self._h = C.c_void_p()
         check(lib().mrk_batch_create(ctx._h, max_queries, C.byref(self._h)))
+        ctx._children.add(self)
         self._cq = None
         self._n = 0
 

@@ -194,6 +194,7 @@ static int mrk_ctx_create_impl(int device, mrk_ctx** out) {
 static void mrk_ctx_destroy_impl(mrk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  mrk_comm_destroy_impl(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->merge_stream) (void)hipStreamDestroy(c->merge_stream);
   for (hipEvent_t e : c->merge_done)
@@ -1521,4 +1522,45 @@ extern "C" int mrk_merge_wait(mrk_ctx* ctx, uint32_t slot) {
 extern "C" int mrk_topk_merge(mrk_ctx* ctx, const uint64_t* in_keys, const uint32_t* in_counts, uint32_t n_lists, uint32_t n_queries, uint32_t k,
                               uint64_t* out_keys, uint32_t* out_counts) {
   return on_worker(ctx, [&] { return mrk_topk_merge_impl(ctx, in_keys, in_counts, n_lists, n_queries, k, out_keys, out_counts); });
+}
+
+// ---- the shard exchange (mrk_comm.cpp) ----
+extern "C" int mrk_comm_unique_id(uint8_t* id_out) {
+  if (!id_out) return mrk_fail(MRK_E_INVAL, "mrk_comm_unique_id: NULL argument");
+  return mrk_comm_unique_id_impl(id_out); // (no device work: ncclGetUniqueId only opens a socket)
+}
+extern "C" int mrk_comm_init(mrk_ctx* ctx, const uint8_t* id, int n_ranks, int rank) {
+  if (!ctx || !id) return mrk_fail(MRK_E_INVAL, "mrk_comm_init: NULL argument");
+  return on_worker(ctx, [&] { return mrk_comm_init_impl(ctx, id, n_ranks, rank); });
+}
+extern "C" void mrk_comm_destroy(mrk_ctx* ctx) {
+  if (ctx) (void)on_worker(ctx, [&] {
+    mrk_comm_destroy_impl(ctx);
+    return MRK_OK;
+  });
+}
+extern "C" int mrk_comm_allreduce_i64(mrk_ctx* ctx, int64_t* values, uint64_t n) {
+  if (!ctx || (!values && n)) return mrk_fail(MRK_E_INVAL, "mrk_comm_allreduce_i64: NULL argument");
+  return on_worker(ctx, [&] { return mrk_comm_allreduce_i64_impl(ctx, values, n); });
+}
+extern "C" int mrk_shard_exchange(mrk_ctx* ctx, mrk_batch* batch, const uint64_t* rows, uint32_t n_queries, uint32_t k, uint64_t* out_rows,
+                                  uint32_t slot) {
+  if (!ctx || !rows || !out_rows) return mrk_fail(MRK_E_INVAL, "mrk_shard_exchange: NULL argument");
+  if (slot >= MRK_MERGE_SLOTS) return mrk_fail(MRK_E_INVAL, "mrk_shard_exchange: slot %u of %d", slot, MRK_MERGE_SLOTS);
+  if (batch && batch->ctx != ctx) return mrk_fail(MRK_E_INVAL, "mrk_shard_exchange: batch and context do not belong together");
+  return on_worker(ctx, [&]() -> int {
+    // behind everything the batch's last submit queued on its stream (selection, the standing rows export)
+    hipEvent_t after = nullptr;
+    if (batch) {
+      after = mrk_comm_rows_ready_event(ctx);
+      if (!after) return mrk_fail(MRK_E_INVAL, "mrk_shard_exchange: no communicator (mrk_comm_init)");
+      int rc = mrk_batch_record_event_impl(batch, (void*)after);
+      if (rc != MRK_OK) return rc;
+    }
+    const uint64_t* rows_all = nullptr;
+    hipEvent_t gathered = nullptr;
+    int rc = mrk_comm_exchange_impl(ctx, rows, n_queries, after, slot, &rows_all, &gathered);
+    if (rc != MRK_OK) return rc;
+    return mrk_topk_merge_rows_async_impl(ctx, rows_all, (uint32_t)mrk_comm_ranks(ctx), n_queries, k, out_rows, (void*)gathered, slot);
+  });
 }

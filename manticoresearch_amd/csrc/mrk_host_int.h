@@ -15,9 +15,11 @@ using mrk::DevSegment;
 using mrk::DevTerm;
 
 struct mrk_worker; // the context's submission thread (mrk_host.cpp)
+struct mrk_comm;   // the context's RCCL communicator for the shard exchange (mrk_comm.cpp)
 
 struct mrk_ctx {
   mrk_worker* worker = nullptr;
+  mrk_comm* comm = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t merge_stream = nullptr; // mrk_topk_merge: never queued behind the scans of a following batch
@@ -70,6 +72,16 @@ struct mrk_segment {
   void* d_bm = nullptr;
   void* d_bm_dir = nullptr;
 };
+
+// mrk_comm.cpp (run on the submission thread)
+int mrk_comm_unique_id_impl(uint8_t* id_out);
+int mrk_comm_init_impl(mrk_ctx* ctx, const uint8_t* id_bytes, int n_ranks, int rank);
+void mrk_comm_destroy_impl(mrk_ctx* ctx);
+int mrk_comm_allreduce_i64_impl(mrk_ctx* ctx, int64_t* values, uint64_t n);
+int mrk_comm_exchange_impl(mrk_ctx* ctx, const uint64_t* rows, uint32_t n_queries, hipEvent_t after, uint32_t slot, const uint64_t** rows_all_out,
+                           hipEvent_t* gathered_event_out);
+int mrk_comm_ranks(const mrk_ctx* ctx);
+hipEvent_t mrk_comm_rows_ready_event(mrk_ctx* ctx);
 
 namespace mrk {
 

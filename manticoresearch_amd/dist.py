@@ -16,8 +16,24 @@ from . import _lib
 from ._lib import MRK_MAX_K, check, lib
 
 
-def global_df(local_docs: np.ndarray, shard_docs: int, device=None):
-    """Sum per-term document counts and the document total over all ranks."""
+def lib_comm_init(ctx):
+    """Give the context its own RCCL communicator (mrk_comm_init): rank 0's id travels over the torch.distributed group
+    the launcher set up -- any other transport would do, the library itself only needs the 128 bytes.  From here on the
+    exchange (ShardMerger) and the document-frequency sums (global_df) are C-ABI calls; torch.distributed only keeps
+    bench.py's barrier and timing reduction."""
+    import torch.distributed as dist
+
+    box = [ctx.comm_unique_id() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(box[0], dist.get_world_size(), dist.get_rank())
+
+
+def global_df(local_docs: np.ndarray, shard_docs: int, device=None, ctx=None):
+    """Sum per-term document counts and the document total over all ranks (through the library's communicator when the
+    context has one, else torch.distributed)."""
+    if ctx is not None and ctx.has_comm:
+        t = ctx.comm_allreduce(np.concatenate([local_docs.astype(np.int64), [shard_docs]]))
+        return t[:-1].copy(), int(t[-1])
     import torch
     import torch.distributed as dist
 
@@ -118,6 +134,19 @@ class ShardMerger:
         nq = n_batches * self.per_batch
         assert nq == self.nq, "merge_attached merges the whole attached set"
         t0 = time.perf_counter()
+        if self.ctx.has_comm:
+            # the library's own chain (mrk_shard_exchange): event on the batch's stream -> RCCL all-gather on the
+            # communicator's stream -> merge kernel -> out rows; nothing of torch in it
+            if after_submit:
+                assert len(self.attached[set_index]) == 1
+            bh = self.attached[set_index][0]._h if after_submit else None
+            check(lib().mrk_shard_exchange(self.ctx._h, bh, self.rows[set_index].data_ptr(), nq, self.k,
+                                           (self.host_rows if to_host else self.out_rows)[set_index].data_ptr(), set_index))
+            self.on_host[set_index] = to_host
+            if self.timing is not None:
+                self.timing["exchange"] = self.timing.get("exchange", 0.0) + (time.perf_counter() - t0) * 1e3
+                self.timing["calls"] = self.timing.get("calls", 0) + 1
+            return
         rows_all = self.rows_all[set_index]
         if after_submit:
             assert len(self.attached[set_index]) == 1

@@ -21,7 +21,7 @@ def kw(m, t, pos, mask=0xFFFFFFFF, boost=1.0):
     return m.XQNode.keyword(t, pos, mask, boost)
 
 
-def main():
+def main(lib_comm: bool):
     import torch
     import torch.distributed as dist
 
@@ -43,6 +43,10 @@ def main():
                       local_docs={a: int(gdocs[a]), b: int(gdocs[b])}) for a in range(5) for b in range(5) if a != b]
         nq = len(qs)
         ctx = m.Context(0)
+        if lib_comm:  # the exchange through the library's own communicator (mrk_comm_init / mrk_shard_exchange)
+            mdist.lib_comm_init(ctx)
+            g2, t2 = mdist.global_df(hi.dict["docs"].astype(np.int64), n_docs, 0, ctx=ctx)
+            assert t2 == n_docs and (g2 == hi.dict["docs"]).all()
         seg = m.Segment(ctx, hi, rowid_base=1000)
         n_sets = 3
         batches = [m.Batch(ctx, nq) for _ in range(n_sets)]
@@ -115,5 +119,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(lib_comm="--lib-comm" in sys.argv)
     print("dist chain ok")

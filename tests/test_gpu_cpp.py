@@ -52,3 +52,15 @@ def test_two_host_threads_one_context(tmp_path):
                            "-L" + lib, "-lmrk", "-lpthread", "-Wl,-rpath," + lib])
     out = subprocess.run([exe, "400000", "60"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "two threads ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_shard_exchange_from_a_cpp_host(tmp_path):
+    """mrk_comm_* + mrk_shard_exchange driven by a C++ program that links libmrk.so and the HIP runtime only: the
+    exchange needs no Python (RCCL is loaded by the library at run time)."""
+    exe = str(tmp_path / "test_exchange")
+    lib = os.path.join(ROOT, "manticoresearch_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "test_exchange.cpp"), "-o", exe,
+                           "-L" + lib, "-lmrk", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "exchange ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
