@@ -150,7 +150,7 @@ SYMBOLS = [
 
 def build(force: bool = False) -> str:
     """Compile libmrk.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mrk_kernels.hip", "mrk_scan_pk.hip", "mrk_kcommon.h", "mrk_host.cpp", "mrk_pack.cpp", "mrk_pack.h", "mrk_writer.cpp", "mrk_dev.h", "mrk_scan_bm.hip", "mrk_plan.cpp", "mrk_files.cpp", "mrk_diag.cpp", "mrk_kprune.h", "mrk_host_int.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mrk.h"))
     stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:

@@ -56,7 +56,9 @@ enum {
   ORC_OP_PHRASE = 5,
   ORC_OP_PROXIMITY = 6,
   ORC_OP_QUORUM = 7,
-  ORC_OP_BEFORE = 8 /* 'a << b << c' (ExtOrder_c) */
+  ORC_OP_BEFORE = 8, /* 'a << b << c' (ExtOrder_c) */
+  ORC_OP_NEAR = 9,    /* 'a NEAR/N b NEAR/N c' (ExtNWay_T<FSMmultinear_c>): opt = N */
+  ORC_OP_NOTNEAR = 10 /* 'a NOTNEAR/N b' (ExtNotNear_c): opt = N */
 };
 
 /* ---- VLB codec (src/sphinxstd.h:5545-5567, src/fileio.cpp:31-45) ---- */

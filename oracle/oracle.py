@@ -18,6 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "libcpu_ref.so")
 RANK_PROXIMITY_BM25, RANK_BM25, RANK_NONE, RANK_WORDCOUNT, RANK_PROXIMITY = 0, 1, 2, 3, 4
 RANK_MATCHANY, RANK_FIELDMASK, RANK_SPH04 = 5, 6, 7
 OP_TERM, OP_AND, OP_OR, OP_MAYBE, OP_ANDNOT, OP_PHRASE, OP_PROXIMITY, OP_QUORUM, OP_BEFORE = 0, 1, 2, 3, 4, 5, 6, 7, 8
+OP_NEAR, OP_NOTNEAR = 9, 10  # 'a NEAR/N b', 'a NOTNEAR/N b': opt = N
 ALL_FIELDS = 0xFFFFFFFF
 
 

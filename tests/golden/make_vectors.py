@@ -95,6 +95,19 @@ G = {
         "test_080": {"source": "test/test_080/test.xml (custom_insert) + model.bin", "min_word_len": 1, "ids": [2, 1],
                      "docs_spec": [{"count": 1, "fields": ["X", "Y"]},
                                    {"count": 1, "fields": ["", {"runs": [["C ", 299992], ["B A A A", 1]]}]}]},
+        # test_115 (NEAR syntax), index idx: rows 1..17, 20..22 of one text field; row 21 is built by CONCAT / REPEAT.
+        # blend_chars = '-' there: 'aleph-bet-gimel' is indexed as its parts at positions 1, 2, 3 (plus the blended token, which
+        # the queries below do not ask for) -- the same positions this fixture's tokenizer gives the parts
+        "test_115": {"source": "test/test_115/test.xml (index idx) + model.bin", "min_word_len": 1,
+                     "ids": list(range(1, 18)) + [20, 21, 22],
+                     "docs_spec": [{"count": 1, "fields": [t]} for t in
+                                   ("a b c d", "a x b c d", "a x x b c d", "a b x c d", "a b x x c d", "a b x x x c d", "a b x x x x c d",
+                                    "a x b x x x x c x d", "a x x b x x x c x x d", "c d x x x x a b", "c d x x x a b", "c d x x a b",
+                                    "c d x a b", "c d a b", '... is the clearinghouse associated with such exchange. In general, clearinghouses are backed by the corporate members of the clearinghouse who are required to share any financial burden resulting from the non-performance by one of their members and, as such, should significantly reduce this credit risk. In cases where the clearinghouse... is the clearinghouse associated with such exchange. In general, clearinghouses are backed by the corporate members of the clearinghouse who are required to share any financial burden resulting from the non-performance by one of their members and, as such, should significantly reduce this credit risk. In cases where the clearinghouse... be able to meet its obligations to a Trading Company. The counterparty for futures contracts traded in the United States and on most foreign exchanges is the clearinghouse associated with such exchange. In general, clearinghouses are backed by the corporate members of the clearinghouse who are required to share any financial...',
+                                    "one two three four five six seven eight nine ten eleven twelve thirteen fourteen fifteena",
+                                    "aleph-bet-gimel dalet he wav zajin het", "ein oy vey")] +
+                                  [{"count": 1, "fields": [{"runs": [["zwei ", 1], ["oy vey ho ho ho ", 1024]]}]},
+                                   {"count": 1, "fields": ["oy vey drei"]}]},
         "test_322": {"source": "test/test_322/test.xml + model.bin", "min_word_len": 1, "ids": [1, 2, 3, 100],
                      "docs": [["|sample program", "|program flow direct", "|sample program flow"],
                               ["|one sample program", "|program rev flow", "|one rev flow"],
@@ -315,6 +328,40 @@ for spam, exp in [(10, [[1, 25], [2, 15], [3, 15]]), (0, [[1, 5], [2, 5], [3, 5]
     G["cases"].append({"name": f"322 program flow wordcount, field_weights 1,2,{spam}", "corpus": "test_322",
                        "query": OP("and", T("program", 1), T("flow", 2)), "ranker": "wordcount",
                        "field_weights": [1, 2, spam], "expect": exp})
+
+
+# test_115: NEAR over keywords and phrases (ExtNWay_T<FSMmultinear_c>; the test's cases with AND / OR GROUPS as operands are left out:
+# the reference answers them like a NEAR over all the group's keywords, which the restatement does not reproduce -- parity unpinned
+# for that shape, which oracle and device both decline); keywords keep the positions the
+# query parser numbers them with, left to right; 'a NEAR/2 b NEAR/5 c NEAR/2 d' nests (different distances do not merge)
+def NEAR(n, *kids):
+    return OP("near", *kids, opt=n)
+
+
+A_, B_, C_, D_ = T("a", 1), T("b", 2), T("c", 3), T("d", 4)
+W4444 = lambda ids: [[i, 4444] for i in ids]
+for name, query, expect in [
+    ('"a b" NEAR/2 "c d"', NEAR(2, OP("phrase", A_, B_), OP("phrase", C_, D_)), W4444([1, 4, 13, 14])),
+    ('"c d" NEAR/2 "a b"', NEAR(2, OP("phrase", T("c", 1), T("d", 2)), OP("phrase", T("a", 3), T("b", 4))), W4444([1, 4, 13, 14])),
+    ("a b NEAR/2 c d", OP("and", A_, NEAR(2, B_, C_), D_), [[4, 4444], [1, 3444], [2, 2444], [3, 2444]]),
+    ("a NEAR/2 b NEAR/5 c NEAR/2 d", NEAR(2, NEAR(5, NEAR(2, A_, B_), C_), D_), W4444([1, 2, 4, 5, 6, 7, 8, 11, 12, 13, 14])),
+    ("a NEAR/3 b NEAR/3 c NEAR/3 d", NEAR(3, A_, B_, C_, D_), W4444([1, 2, 3, 4, 5, 12, 13, 14])),
+    ("a NEAR/3 d NEAR/3 b NEAR/3 c", NEAR(3, T("a", 1), T("d", 2), T("b", 3), T("c", 4)), W4444([1, 2, 3, 4, 5, 12, 13, 14])),
+    ('"a b" NEAR/2 "c d" NEAR/2 "f g"', NEAR(2, OP("phrase", A_, B_), OP("phrase", C_, D_), OP("phrase", T("f", 5), T("g", 6))), []),
+    ("five NEAR/3 one", NEAR(3, T("five", 1), T("one", 2)), []),
+    ("six NEAR/3 one", NEAR(3, T("six", 1), T("one", 2)), []),
+    ("aleph NEAR/2 gimel", NEAR(2, T("aleph", 1), T("gimel", 2)), [[17, 2723]]),
+    ("bet NEAR/3 he", NEAR(3, T("bet", 1), T("he", 2)), [[17, 2723]]),
+]:
+    G["cases"].append({"name": "115 " + name, "corpus": "test_115", "query": query, "ranker": "proximity_bm25", "expect": expect,
+                       "total_found": len(expect)})
+# the same test's SphinxQL section lists matching rows only (the statements carry an id filter, applied here by expect_in)
+for name, query, row, hit in [("bet NEAR/2 he", NEAR(2, T("bet", 1), T("he", 2)), 17, False),
+                              ("oy NEAR/1 vey", NEAR(1, T("oy", 1), T("vey", 2)), 22, True),
+                              ("x NEAR/2 x", NEAR(2, T("x", 1), T("x", 2)), 3, True),
+                              ("x NEAR/2 x NEAR/2 x", NEAR(2, T("x", 1), T("x", 2), T("x", 3)), 9, True)]:
+    G["cases"].append({"name": "115 sphinxql " + name, "corpus": "test_115", "query": query, "ranker": "proximity_bm25",
+                       "expect_row": [row, hit]})
 
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")

@@ -211,7 +211,9 @@ def test_reference_vectors(orc, case):
         kw["total_docs_override"] = case["total_docs"]
         kw["local_docs"] = {v[w]: n for w, n in case["local_docs"].items() if w in v}
     got, r = run(orc, idx, _golden_tree(orc, v, case["query"]), getattr(orc, "RANK_" + case["ranker"].upper()), corpus["ids"], **kw)
-    if "expect_ids" in case:  # the reference's test lists the matching rows only
+    if "expect_row" in case:  # the reference's statement filters by id: one row must (not) be among the matches
+        assert (case["expect_row"][0] in [i for i, _ in got]) == case["expect_row"][1]
+    elif "expect_ids" in case:  # the reference's test lists the matching rows only
         assert sorted(i for i, _ in got) == sorted(case["expect_ids"])
         if "expect_weights" in case:  # rows listed in id order with their weights
             assert {str(i): w for i, w in got} == case["expect_weights"]
