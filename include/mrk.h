@@ -71,7 +71,9 @@ enum {
 enum { MRK_OP_TERM = 0, MRK_OP_AND = 1, MRK_OP_OR = 2, MRK_OP_MAYBE = 3, MRK_OP_ANDNOT = 4, MRK_OP_PHRASE = 5,
        MRK_OP_PROXIMITY = 6, /* '"a b c"~N': opt = N */
        MRK_OP_BEFORE = 8, /* 'a << b << c' (ExtOrder_c): the children occur in this order inside one field */
-       MRK_OP_QUORUM = 7 /* '"a b c"/N': opt = N (ExtQuorum_c; N = 1 / N >= words as the reference rewrites them) */ };
+       MRK_OP_QUORUM = 7, /* '"a b c"/N': opt = N (ExtQuorum_c; N = 1 / N >= words as the reference rewrites them) */
+       MRK_OP_NEAR = 9,   /* 'a NEAR/N b' (ExtNWay_T<FSMmultinear_c>): opt = N; the device takes two plain keywords */
+       MRK_OP_NOTNEAR = 10 /* 'a NOTNEAR/N b' (ExtNotNear_c): opt = N */ };
 
 enum { MRK_HITFMT_PLAIN = 0, MRK_HITFMT_INLINE = 1 }; /* ESphHitFormat */
 

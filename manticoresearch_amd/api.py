@@ -28,6 +28,8 @@ SPH_QUERY_TERM, SPH_QUERY_AND, SPH_QUERY_OR, SPH_QUERY_MAYBE, SPH_QUERY_ANDNOT, 
 SPH_QUERY_PROXIMITY = 6  # '"a b c"~N': XQNode.opt = N
 SPH_QUERY_QUORUM = 7     # '"a b c"/N': XQNode.opt = N
 SPH_QUERY_BEFORE = 8     # 'a << b << c' (ExtOrder_c)
+SPH_QUERY_NEAR = 9       # 'a NEAR/N b' (ExtNWay_T<FSMmultinear_c>): XQNode.opt = N
+SPH_QUERY_NOTNEAR = 10   # 'a NOTNEAR/N b' (ExtNotNear_c): XQNode.opt = N
 SPH_HIT_FORMAT_PLAIN, SPH_HIT_FORMAT_INLINE = 0, 1
 ALL_FIELDS = 0xFFFFFFFF
 
@@ -517,6 +519,6 @@ def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool =
 
 __all__ = ["SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
-           "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE",
+           "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE", "SPH_QUERY_NEAR", "SPH_QUERY_NOTNEAR",
            "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Filter", "Matches", "Context",
            "Segment", "Batch", "prepare", "idf", "MrkError", "validate_index", "pair_stats"]

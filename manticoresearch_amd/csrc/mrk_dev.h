@@ -93,17 +93,19 @@ __device__ __forceinline__ bool row_is_dead(const DevSegment& seg, uint32_t rowi
 constexpr uint32_t PK_WIDE = 0xFFu;
 constexpr int NBINS = 1024; // pruning histogram bins per query
 constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
-constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4, PN_PHRASEFIX = 5, PN_QUORUM = 6, PN_ORDERFIX = 7; // prog[] opcodes
+constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4, PN_PHRASEFIX = 5, PN_QUORUM = 6, PN_ORDERFIX = 7, PN_NOTNEAR = 8; // prog[] opcodes
 constexpr int QUORUM_EVENTS = 8; // keywords of a quorum node = doclists that can run dry and reorder its children
 constexpr uint32_t TF_MULTIAND = 1; // the whole query is one ExtMultiAnd_T (or a single keyword)
 constexpr uint32_t TF_BITMAP = 4;   // 2-keyword AND answered by the bitmap kernel (items are window ranges)
 constexpr uint32_t TF_BTREE = 256;  // boolean tree evaluated on bitmap words by the window-driven tree kernel (items are window ranges)
 constexpr uint32_t TF_ORDER = 128;      // the TF_PHRASE_LEAF node is a BEFORE operator (ExtOrder_c) over the keywords of ph_mask
 constexpr uint32_t TF_TERMPOS = 64;     // some keyword carries a position modifier (ExtTermPos_T)
+constexpr uint32_t TF_NOTNEAR = 512;    // the tree holds a NOTNEAR node (ExtNotNear_c) over keywords nn_a (must) and nn_b (not)
 constexpr uint32_t TF_QUORUM_HITS = 32; // the root is an ExtQuorum_c: its hits sort by position WITHOUT the end flag
 constexpr uint32_t TF_DUPES = 16;      // a keyword occurs more than once in the query (HasQwordDupes, sphinxsearch.cpp:4178)
 constexpr uint32_t TF_PHRASE_LEAF = 8; // one PHRASE below other operators: ph_mask = its words' slots in t[]
 constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[] = atom positions in phrase order
+constexpr uint32_t TF_FAT = TF_PHRASE | TF_PHRASE_LEAF | TF_TERMPOS | TF_ORDER | TF_NOTNEAR; // final ranking needs the full hit pass (rank_kernel<true>)
 constexpr int PHRASE_STATES = 8;    // live FSMphrase_c states per doc (>= phrase span + 1)
 constexpr int TREE_STACK = 4;       // evaluation stack depth of the tree program
 constexpr int MAX_PASSES = 4; // driver keywords per query (size of the tree's candidate cover)
@@ -160,7 +162,8 @@ struct DevQuery {
   uint32_t qr_mask, qr_thr, qr_n;
   uint32_t qr_row[QUORUM_EVENTS];
   uint32_t qr_ord[QUORUM_EVENTS + 1];
-  uint32_t px_dist;                   // 0 = exact PHRASE; else PROXIMITY ('"a b"~N'): XQNode_t::m_iOpArg
+  uint32_t px_dist;                   // 0 = exact PHRASE; else PROXIMITY ('"a b"~N'): XQNode_t::m_iOpArg; bit 31: 'a NEAR/N b'
+  uint32_t nn_a, nn_b, nn_dist;       // TF_NOTNEAR: keyword slots of the must / not side, the distance
   uint32_t max_qpos, n_qwords;        // ExtRanker_c::m_iMaxQpos (largest query position) / m_iQwords (distinct words)
   int32_t weights[32];
   DevTerm t[MRK_MAX_AND_TERMS];

@@ -756,7 +756,7 @@ static bool pass_queues_matches(const DevQuery& P, bool& fat) {
   const bool prox_ranker = (rk == MRK_RANK_PROXIMITY_BM25 || rk == MRK_RANK_PROXIMITY)
                                ? P.n_terms > 1
                                : (rk == MRK_RANK_WORDCOUNT || rk == MRK_RANK_MATCHANY || rk == MRK_RANK_FIELDMASK || rk == MRK_RANK_SPH04);
-  fat = (P.tree_flags & (mrk::TF_PHRASE | mrk::TF_PHRASE_LEAF | mrk::TF_TERMPOS | mrk::TF_ORDER)) != 0;
+  fat = (P.tree_flags & mrk::TF_FAT) != 0;
   return prox_ranker || (P.tree_flags & mrk::TF_PHRASE) != 0;
 }
 
@@ -830,7 +830,7 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
       b->h_queries.p[i].n_terms = 0;
     }
     max_terms = std::max(max_terms, b->h_queries.p[i].n_terms);
-    any_ext = any_ext || (b->h_queries.p[i].tree_flags & (mrk::TF_TERMPOS | mrk::TF_ORDER | mrk::TF_PHRASE_LEAF)) != 0 || b->h_queries.p[i].n_filters != 0;
+    any_ext = any_ext || (b->h_queries.p[i].tree_flags & (mrk::TF_TERMPOS | mrk::TF_ORDER | mrk::TF_PHRASE_LEAF | mrk::TF_NOTNEAR)) != 0 || b->h_queries.p[i].n_filters != 0;
     b->h_list_first.p[i] = b->h_queries.p[i].item_first;
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;

@@ -114,6 +114,36 @@ struct PhraseFsm {
   // of the word at query offset i, ~0 = none), ftag = m_uWords, fvalid = m_iMinQindex + 1, exp = m_uExpPos.
   // A hit that completes "all words within qlen + dist" folds them into one hit: position / spanlen of the words
   // gathered, weight from how many of them keep the query's relative offsets; the earliest word is then dropped.
+  // FSMmultinear_c (searchnode.cpp:4096-4288) for exactly TWO keyword operands ('a NEAR/N b'), on the same storage:
+  // fexp[0] = m_uLastP, [1] = m_uFirstHit, [2] = m_uFirstNpos, [3] = m_uFirstQpos, [4] = m_uWeight.  Keyword hits have
+  // weight, match length and span 1, which leaves the pre-last roll-back and the overlap special case of HitFSM dead.  (With
+  // three or more operands the reference's emitted query position depends on the docs seen before -- m_uFirstQpos is never
+  // reset for the ring form -- so only the twofer is offered on the device.)
+  __device__ __forceinline__ void reset_near() {
+#pragma unroll
+    for (int i = 0; i < PHRASE_STATES; ++i) fexp[i] = 0;
+    ftag = 0, fvalid = 0, over = false, exp = 0;
+  }
+  __device__ __forceinline__ bool step_near2(uint32_t hp, uint32_t npos, uint32_t qpos, uint32_t dist, uint32_t& out_pos, uint32_t& out_w, uint32_t& out_q) {
+    if (fexp[0] == hp) { // dupe hit: the leftmost (in the query) of the words at this position leads ('a NEAR/2 a')
+      if (npos < fexp[2]) fexp[3] = qpos, fexp[2] = npos;
+      return false;
+    }
+    if (fexp[0] == 0 || fexp[0] + 1u + dist <= hp) { // probably a new chain
+      fexp[1] = fexp[0] = hp, fexp[4] = 1, fexp[3] = qpos, fexp[2] = npos;
+      return false;
+    }
+    if (npos == fexp[2]) { // the same operand again: the chain restarts from it
+      if (fexp[0] < hp) fexp[1] = fexp[0] = hp, fexp[4] = 1, fexp[3] = qpos, fexp[2] = npos;
+      return false;
+    }
+    out_pos = fexp[1];
+    out_w = fexp[4] + 1u;
+    out_q = fexp[3] < qpos ? fexp[3] : qpos;
+    fexp[1] = fexp[0] = hp, fexp[4] = 1, fexp[3] = qpos; // two operands may overlap: shift the chain, do not reset it
+    return true;
+  }
+
   uint32_t exp;
   __device__ __forceinline__ void reset_prox() {
 #pragma unroll
@@ -323,7 +353,7 @@ struct HitCtx {
   uint32_t nterms, nw;
   uint32_t ap0, ap1, ap2, ap3;
   uint32_t nph, span;     // the query's phrase: words, distance between its first and last query position
-  uint32_t px_dist;       // 0 = exact PHRASE, else the PROXIMITY operator's distance ('"a b"~N')
+  uint32_t px_dist;       // 0 = exact PHRASE, else the PROXIMITY operator's distance ('"a b"~N'); bit 31: a NEAR/N node, N below it
   uint32_t ranker;        // MRK_RANK_* of the state ranker fed by the pass
   const int32_t* fw;      // the nw per-field weights (an LDS copy where the pass ranks; WORDCOUNT reads one per hit)
   // per keyword slot, by value (uniform): first block in the packed arrays, query position, queried fields, position modifier
@@ -336,13 +366,29 @@ struct HitCtx {
   bool order;             // the keywords of pmask form a BEFORE node (ExtOrder_c), not a PHRASE
   bool termpos;           // some keyword carries a position modifier: its stream yields acceptable hits only
   bool quorum_hits;       // the root is an ExtQuorum_c: hits order by position without the end flag (QuorumCmpHitPos_fn)
+  // NOTNEAR (ExtNotNear_c): keyword slot nn_a's hits survive only if no hit of slot nn_b at or behind them comes within nn_dist
+  uint32_t nn_a, nn_b, nn_dist; // nn_dist = 0: no such node
 };
+
+// ExtNotNear_c::FilterHits (searchnode.cpp:5352-5380) for two keywords: (ap, ac) = the must side's cursor on a candidate hit,
+// (np, nc) = the not side's; drops candidates until one survives -- no not-hit left at or behind it, or the next one farther
+// than the distance (keyword hits are one position long) -- or the must side runs dry.  Not-hits outside that keyword's
+// field limit do not exist for the node.
+__device__ __forceinline__ void notnear_filter(const uint8_t* __restrict__ spp, uint64_t& ap, uint32_t& ac, uint64_t& np, uint32_t& nc, uint32_t mask_b,
+                                               uint32_t dist) {
+  while (ac) {
+    const uint32_t pm = ac & ~(1u << 23);
+    while (nc && ((nc & ~(1u << 23)) < pm || !field_queried(mask_b, nc))) hit_advance(spp, np, nc);
+    if (!nc || pm + dist < (nc & ~(1u << 23))) break;
+    hit_advance(spp, ap, ac);
+  }
+}
 
 // One doc's hit pass.  ref0..ref3 = where the doc sits in each keyword's packed arrays (block within the keyword << 7 |
 // slot, bit 31 = its one hit was inlined), smask = keyword slots whose hits take part, pmask = slots forming the
 // phrase (0 = none), rank = feed the state ranker (else: stop at the first phrase occurrence).
 __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_t ref1, uint32_t ref2, uint32_t ref3, uint32_t smask,
-                                         uint32_t pmask, bool rank, bool& ph_found, uint32_t& ph_field, int& rk_out) {
+                                         uint32_t pmask, bool rank, bool& ph_found, uint32_t& ph_field, int& rk_out, bool nn_partner = false) {
   // .spp cursor (0 = inlined hit / exhausted), current Hitpos_t (0 = exhausted), query position, field limit
   uint64_t sp[MAX_PROX_TERMS];
   uint32_t sc[MAX_PROX_TERMS], sq[MAX_PROX_TERMS], sm[MAX_PROX_TERMS];
@@ -368,10 +414,33 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
         while (sc[t] && !tp_accept(tpk[t], tpm[t], sc[t])) hit_advance(C.spp, sp[t], sc[t]);
     }
   }
+  // NOTNEAR: the not side's own cursor (its hits never reach the ranker), and the must side's first surviving hit
+  const bool nn = C.nn_dist != 0 && nn_partner;
+  uint64_t nnp = 0;
+  uint32_t nnc = 0;
+  if (nn) {
+    const uint32_t h = C.nn_b == 0 ? ref0 : C.nn_b == 1 ? ref1 : C.nn_b == 2 ? ref2 : ref3;
+    const uint32_t tbb = C.nn_b == 0 ? C.tb[0] : C.nn_b == 1 ? C.tb[1] : C.nn_b == 2 ? C.tb[2] : C.tb[3];
+    const uint32_t gblk = tbb + ((h >> 7) & 0xFFFFFFu), idx = h & 127u;
+    const uint32_t hv = C.hit[(uint64_t)gblk * DEVBLK + idx];
+    if (h >> 31)
+      nnc = hv;
+    else {
+      nnp = C.hbase[gblk] + hv;
+      hit_advance(C.spp, nnp, nnc);
+    }
+#pragma unroll
+    for (int t = 0; t < MAX_PROX_TERMS; ++t)
+      if ((uint32_t)t == C.nn_a) notnear_filter(C.spp, sp[t], sc[t], nnp, nnc, (C.nn_b == 0 ? C.tm[0] : C.nn_b == 1 ? C.tm[1] : C.nn_b == 2 ? C.tm[2] : C.tm[3]), C.nn_dist);
+  }
   // the phrase as a stream of folded hits: position = first word's, weight = word count, spanlen = span + 1
   const uint32_t nph = C.nph, span = C.span; // the query's one phrase: word count, last - first query position
   PhraseFsm F;
-  if (C.px_dist)
+  const bool near2 = (C.px_dist >> 31) != 0; // 'a NEAR/N b' (two keyword operands)
+  const uint32_t px_dist = C.px_dist & 0x7FFFFFFFu;
+  if (near2)
+    F.reset_near();
+  else if (px_dist)
     F.reset_prox();
   else
     F.reset();
@@ -497,10 +566,15 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
         }
         const uint32_t hp = bh & ~(1u << 23);
         bool emit = false;
-        uint32_t e_pos = hp - span, e_w = nph, e_span = span; // exact phrase: first word's position, word count, span
-        if (field_queried(bmask, bh))
-          emit = C.px_dist ? F.step_prox(hp, bq & 0xFFFFu, nph, C.ap0 & 0xFFFFu, span, C.px_dist, e_pos, e_w, e_span)
+        uint32_t e_pos = hp - span, e_w = nph, e_span = span, e_q = C.ap0 & 0xFFFFu; // exact phrase: first word's position, word count, span
+        if (field_queried(bmask, bh)) {
+          if (near2) { // the operand's place in the node = the hit's m_uNodepos (SetNodePos, searchnode.cpp:3767-3786)
+            e_span = 1u;
+            emit = F.step_near2(hp, (bq & 0xFFFFu) == (C.ap0 & 0xFFFFu) ? 1u : 2u, bq & 0xFFFFu, px_dist, e_pos, e_w, e_q);
+          } else
+            emit = px_dist ? F.step_prox(hp, bq & 0xFFFFu, nph, C.ap0 & 0xFFFFu, span, px_dist, e_pos, e_w, e_span)
                            : F.step(hp, bq & 0xFFFFu, nph, C.ap0, C.ap1, C.ap2, C.ap3);
+        }
         { // advance the chosen stream: one decode for the wave, whatever stream each lane picked
           uint64_t ap = best == 0 ? sp[0] : best == 1 ? sp[1] : best == 2 ? sp[2] : sp[3];
           uint32_t ac = best == 0 ? sc[0] : best == 1 ? sc[1] : best == 2 ? sc[2] : sc[3];
@@ -511,7 +585,7 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
         }
         if (emit) {
           phave = true;
-          pcur = e_pos, pw = e_w, pspan = e_span;
+          pcur = e_pos, pw = e_w, pspan = e_span, pq = e_q;
           pfield = (bh >> 24) & 31u;
           break;
         }
@@ -564,6 +638,7 @@ __device__ __forceinline__ void hit_pass(const HitCtx& C, uint32_t ref0, uint32_
         const uint32_t am = best == 0 ? tpm[0] : best == 1 ? tpm[1] : best == 2 ? tpm[2] : tpm[3];
         while (ac && !tp_accept(ak, am, ac)) hit_advance(C.spp, ap, ac);
       }
+      if (nn && (uint32_t)best == C.nn_a) notnear_filter(C.spp, ap, ac, nnp, nnc, (C.nn_b == 0 ? C.tm[0] : C.nn_b == 1 ? C.tm[1] : C.nn_b == 2 ? C.tm[2] : C.tm[3]), C.nn_dist);
 #pragma unroll
       for (int t = 0; t < MAX_PROX_TERMS; ++t)
         if (t == best) sp[t] = ap, sc[t] = ac;
@@ -825,6 +900,34 @@ __device__ __forceinline__ bool termpos_any(const HitCtx& C, const DevTerm& Tt, 
     hit_advance(C.spp, sp, sc);
   }
   return false;
+}
+
+// ExtNotNear_c::GetDocsChunk for a doc both keywords hold: it stays iff a must-hit (inside the must keyword's field limit)
+// survives the filter.  ref_a / ref_b = where the doc sits in the two keywords' packed arrays (as for hit_pass).
+__device__ __forceinline__ bool notnear_any(const HitCtx& C, uint32_t ref_a, uint32_t ref_b) {
+  uint64_t p[2] = {0, 0};
+  uint32_t c[2] = {0, 0};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint32_t slot = i ? C.nn_b : C.nn_a, ref = i ? ref_b : ref_a;
+    const uint32_t tbs = slot == 0 ? C.tb[0] : slot == 1 ? C.tb[1] : slot == 2 ? C.tb[2] : C.tb[3];
+    const uint32_t gblk = tbs + ((ref >> 7) & 0xFFFFFFu), idx = ref & 127u;
+    const uint32_t hv = C.hit[(uint64_t)gblk * DEVBLK + idx];
+    if (ref >> 31)
+      c[i] = hv;
+    else {
+      p[i] = C.hbase[gblk] + hv;
+      hit_advance(C.spp, p[i], c[i]);
+    }
+  }
+  const uint32_t mask_a = C.nn_a == 0 ? C.tm[0] : C.nn_a == 1 ? C.tm[1] : C.nn_a == 2 ? C.tm[2] : C.tm[3];
+  const uint32_t mask_b = C.nn_b == 0 ? C.tm[0] : C.nn_b == 1 ? C.tm[1] : C.nn_b == 2 ? C.tm[2] : C.tm[3];
+  for (;;) {
+    notnear_filter(C.spp, p[0], c[0], p[1], c[1], mask_b, C.nn_dist);
+    if (!c[0]) return false;
+    if (field_queried(mask_a, c[0])) return true;
+    hit_advance(C.spp, p[0], c[0]);
+  }
 }
 
 } // namespace mrk

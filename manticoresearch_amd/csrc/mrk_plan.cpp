@@ -79,6 +79,8 @@ struct PlanTree {
   bool quorum = false, quorum_root = false;
   bool order = false;           // the ph_leaf node is a BEFORE operator (ExtOrder_c), not a PHRASE
   bool termpos = false;         // some keyword carries a position modifier ('^word', 'word$', '@field[N] word')
+  bool notnear = false;         // one NOTNEAR node over two plain keywords: kws[nn_a] NOTNEAR/nn_dist kws[nn_b]
+  int nn_a = 0, nn_b = 0, nn_dist = 0;
   int q_kw0 = 0, q_n = 0, q_thr = 0;
   IntVec atoms;                 // its words' query positions, phrase order
 };
@@ -119,7 +121,8 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     return (int)T.nodes.size() - 1;
   };
   if (n.op == MRK_OP_TERM) return leaf(ni);
-  const bool nway = n.op == MRK_OP_PHRASE || n.op == MRK_OP_PROXIMITY; // ExtNWay_T<FSMphrase_c / FSMproximity_c>
+  const bool near = n.op == MRK_OP_NEAR; // ExtNWay_T<FSMmultinear_c>: the same node with a third state machine
+  const bool nway = n.op == MRK_OP_PHRASE || n.op == MRK_OP_PROXIMITY || near; // ExtNWay_T<FSMphrase_c / FSMproximity_c / FSMmultinear_c>
   if (nway && (T.phrase || T.ph_leaf))
     return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: more than one PHRASE (device path: one per query)", qi), -1;
   if (n.op == MRK_OP_QUORUM) {
@@ -184,6 +187,28 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     T.force_tree = true; // an ExtAnd_c chain is not an ExtMultiAnd_T (no MergeHits3 quirk): always the tree program
     return cur;
   }
+  if (n.op == MRK_OP_NOTNEAR) {
+    // ExtNotNear_c (generic create, searchnode.cpp:1785-1803): the must side's docs; where the not side holds the doc too, only
+    // the must hits no later not-hit comes within the distance of survive, and the doc stays iff one does
+    if (T.notnear || T.phrase || T.ph_leaf || T.order)
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR next to another NOTNEAR / PHRASE / BEFORE node (device path: one such node per query)", qi), -1;
+    if (n.n_children != 2 || n.first_child < 0) return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR over %d operands (device path: two plain keywords)", qi, n.n_children), -1;
+    if (n.opt <= 0 || n.opt > (1 << 20)) return err = mrk_fail(MRK_E_INVAL, "query %u: NOTNEAR distance %d", qi, n.opt), -1;
+    int kid[2];
+    for (int i = 0; i < 2; ++i) {
+      kid[i] = q.children[n.first_child + i];
+      if (kid[i] < 0 || kid[i] >= q.n_nodes) return err = mrk_fail(MRK_E_INVAL, "query %u: child index out of range", qi), -1;
+      if (q.nodes[kid[i]].op != MRK_OP_TERM || q.nodes[kid[i]].term_pos)
+        return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR over plain keywords only on the device path", qi), -1;
+    }
+    const int l = leaf(kid[0]);
+    T.nn_a = (int)T.kws.size() - 1;
+    const int r = leaf(kid[1]);
+    T.nn_b = (int)T.kws.size() - 1;
+    T.nn_dist = n.opt;
+    T.notnear = T.force_tree = true;
+    return join(PN_NOTNEAR, l, r);
+  }
   if (n.op == MRK_OP_BEFORE) {
     // ExtOrder_c (CreateOrderNode, searchnode.cpp:1044-1073): children in query order, no sorting; the doc is the FIRST
     // child's doc (fields, tfidf) once all children hold it and their hits line up in order inside one field
@@ -224,10 +249,15 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
     all_terms &= q.nodes[kids[i]].op == MRK_OP_TERM;
   }
   if (nway) {
-    if (n.op == MRK_OP_PROXIMITY) {
-      if (n.opt <= 0 || n.opt > (1 << 20)) return err = mrk_fail(MRK_E_INVAL, "query %u: proximity distance %d", qi, n.opt), -1;
-      T.px_dist = n.opt;
+    if (n.op == MRK_OP_PROXIMITY || near) {
+      if (n.opt <= 0 || n.opt > (1 << 20)) return err = mrk_fail(MRK_E_INVAL, "query %u: proximity / NEAR distance %d", qi, n.opt), -1;
+      T.px_dist = n.opt | (near ? (int)0x80000000u : 0);
     }
+    // NEAR: two plain keywords on the device.  With three or more operands the reference's folded hit carries a query position
+    // that depends on the docs evaluated before (FSMmultinear_c::m_uFirstQpos is never reset for the ring form), and operands
+    // that are phrases / groups need their own hit streams: both are declined
+    if (near && (!all_terms || n.n_children != 2))
+      return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: NEAR over %d operands (device path: two plain keywords)", qi, n.n_children), -1;
     // CreateMultiNode<ExtPhrase_c / ExtProximity_c> (searchnode.cpp:984-1041): plain keywords only; ExtNWay_T::ConstructNode
     // (:3767-3787) chains them left-deep in ascending doc-count order, so docs / tfidf come out as for a MultiAnd
     if (!all_terms || n.n_children < 2 || n.n_children > MAX_PROX_TERMS)
@@ -238,7 +268,7 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
       T.atoms.push_back(q.nodes[kids[i]].atom_pos);
       if (i && T.atoms[i] <= T.atoms[i - 1]) return err = mrk_fail(MRK_E_INVAL, "query %u: phrase atom positions must ascend", qi), -1;
     }
-    if (T.atoms.back() - T.atoms.front() >= PHRASE_STATES)
+    if (!near && T.atoms.back() - T.atoms.front() >= PHRASE_STATES)
       return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: phrase spans %d positions (device path: < %d)", qi,
                             T.atoms.back() - T.atoms.front(), PHRASE_STATES), -1;
   }
@@ -380,7 +410,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   const bool single_word = T.nodes.size() == 1 && T.nodes[0].op == PN_TERM; // XQQuery_t::m_bSingleWord
   bool pure_and = !T.force_tree; // single keyword or one ExtMultiAnd_T: the kernel's N-way AND loop, no program
   for (const PlanNode& pn : T.nodes) pure_and &= pn.op == PN_TERM || pn.op == PN_AND;
-  if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE || q.nodes[q.root].op == MRK_OP_PROXIMITY))
+  if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE || q.nodes[q.root].op == MRK_OP_PROXIMITY || q.nodes[q.root].op == MRK_OP_NEAR))
     for (int i = 0; i < q.nodes[q.root].n_children; ++i) pure_and &= q.nodes[q.children[q.nodes[q.root].first_child + i]].op == MRK_OP_TERM;
   if (!pure_and && !use_packed) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: boolean trees run on the packed path only", qi);
   if (!pure_and) { // the device evaluates the program on a TREE_STACK-deep register stack
@@ -398,6 +428,12 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: a quorum below another operator with a hit ranker is not on the device path", qi);
   if (T.ph_leaf && n > MAX_PROX_TERMS)
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE in a tree of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+  if (T.notnear) { // decided over the two keywords' hits: the hit-reading kernel, <= 4 hit streams
+    if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR runs on the packed path only", qi);
+    if (n > MAX_PROX_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR in a query of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+    if (T.termpos || T.quorum) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR next to position modifiers / a quorum node", qi);
+    if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+  }
   if (T.termpos) { // whether a keyword holds a doc is decided over its hits: the hit-reading kernel, <= 4 hit streams
     if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: position modifiers run on the packed path only", qi);
     if (n > MAX_PROX_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: position modifiers in a query of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
@@ -622,7 +658,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   }
   algo_bytes += bytes;
   dev_bytes += use_packed ? pbytes : bytes;
-  prox_out = prox_out || prox || T.phrase || T.ph_leaf || T.termpos;
+  prox_out = prox_out || prox || T.phrase || T.ph_leaf || T.termpos || T.notnear;
   tree_out = tree_out || !pure_and;
 
   // two dense keywords: the bitmap kernel (mrk_scan_bm.hip) walks 2048-rowid windows instead of blocks
@@ -653,7 +689,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   {
     const uint32_t all_fields = seg->n_fields >= 32 ? 0xFFFFFFFFu : (1u << seg->n_fields) - 1u;
     bool ok = use_packed && seg->dev.bm && seg->ctx->bitmap_inv > 0 && seg->ctx->bt_cover_inv > 0 && !T.phrase && !T.ph_leaf && !T.quorum && !T.order &&
-              !T.termpos && q.n_filters == 0 && n <= MAX_PROX_TERMS && seg->total_docs < (1ull << 32) && T.nodes.size() <= 16;
+              !T.termpos && !T.notnear && q.n_filters == 0 && n <= MAX_PROX_TERMS && seg->total_docs < (1ull << 32) && T.nodes.size() <= 16;
     uint64_t cover_docs = 0;
     for (int k : cover) cover_docs += (uint64_t)T.kws[k].docs;
     ok = ok && cover_docs * (uint64_t)seg->ctx->bt_cover_inv >= seg->total_docs;
@@ -727,7 +763,8 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     P->n_terms = (uint32_t)n;
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
     P->req_mask = P->excl_mask = 0;
-    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0) | (T.order ? TF_ORDER : 0);
+    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0) | (T.order ? TF_ORDER : 0) | (T.notnear ? TF_NOTNEAR : 0);
+    P->nn_a = T.notnear ? (uint32_t)slot[T.nn_a] : 0u, P->nn_b = T.notnear ? (uint32_t)slot[T.nn_b] : 0u, P->nn_dist = (uint32_t)T.nn_dist;
     P->px_dist = (uint32_t)T.px_dist;
     P->qr_mask = P->qr_thr = P->qr_n = 0;
     if (T.quorum) {

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
 #pragma unroll
   for (int t = 0; t < MAX_PROX_TERMS; ++t) HC.tb[t] = HC.tq[t] = HC.tm[t] = HC.tpk[t] = HC.tpm[t] = 0;
   HC.ap0 = HC.ap1 = HC.ap2 = HC.ap3 = 0, HC.px_dist = 0;
+  HC.nn_a = HC.nn_b = HC.nn_dist = 0;
 
   // virtual -> physical chunk: the shard whose prefix range holds it (uniform binary search over 65 LDS words)
   auto chunk_of = [&](uint32_t vc) -> uint32_t {
@@ -185,6 +186,10 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
       HC.ap0 = FAT ? U(Q->ph_atoms[0]) : 0u, HC.ap1 = FAT ? U(Q->ph_atoms[1]) : 0u, HC.ap2 = FAT ? U(Q->ph_atoms[2]) : 0u, HC.ap3 = FAT ? U(Q->ph_atoms[3]) : 0u;
       qc_ph_mask = FAT ? U(Q->ph_mask) : 0u;
       HC.px_dist = FAT ? U(Q->px_dist) : 0u;
+      {
+        const bool nnq = FAT && (U(Q->tree_flags) & TF_NOTNEAR) != 0;
+        HC.nn_a = nnq ? U(Q->nn_a) : 0u, HC.nn_b = nnq ? U(Q->nn_b) : 0u, HC.nn_dist = nnq ? U(Q->nn_dist) : 0u;
+      }
       const uint32_t k_ = U(Q->k), bm_ = U(Q->bin_mode), bs_ = U(Q->bin_shift), bl_ = U((uint32_t)Q->bin_lo), cc_ = U(Q->cand_cap);
       const uint64_t co_ = ((uint64_t)U((uint32_t)(Q->cand_off >> 32)) << 32) | U((uint32_t)Q->cand_off);
       const int32_t wl = lane < 8 ? Q->weights[lane] : 0;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
         const uint32_t pmask = phrase ? all_slots : (ph_leaf && (smask & ph_mask) == ph_mask) ? ph_mask : 0u;
         bool found = false;
         uint32_t ffield = 0;
-        hit_pass(HC, r0, r1, r2, r3, smask, pmask, prox_ranker, found, ffield, rk);
+        hit_pass(HC, r0, r1, r2, r3, smask, pmask, prox_ranker, found, ffield, rk, ((fa >> 16) & 1u) != 0);
         if (phrase) {
           is_live = found;
           fields = 1u << ffield; // the doc's field mask comes from its first occurrence (searchnode.cpp:3836)

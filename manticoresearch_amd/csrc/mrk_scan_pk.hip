@@ -229,7 +229,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   // the second queue, whose consumer carries the word state machines.
   uint32_t mqn = 0;
   MqWriter mqw;
-  const bool fat_q = (Q->tree_flags & (TF_PHRASE | TF_PHRASE_LEAF | TF_TERMPOS | TF_ORDER)) != 0;
+  const bool fat_q = (Q->tree_flags & TF_FAT) != 0;
   auto flush_matches = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
     if (!PROX) return;
     wave_lds_fence();
@@ -273,6 +273,8 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   HC.order = EXT && PROX && TREE && (Q->tree_flags & TF_ORDER) != 0;
   HC.apack = (uint64_t)(ap0 & 0xFFFFu) | ((uint64_t)(ap1 & 0xFFFFu) << 16) | ((uint64_t)(ap2 & 0xFFFFu) << 32) | ((uint64_t)(ap3 & 0xFFFFu) << 48);
   HC.dupes = (Q->tree_flags & TF_DUPES) != 0 && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY);
+  const bool notnear = EXT && PROX && TREE && (Q->tree_flags & TF_NOTNEAR) != 0;
+  HC.nn_a = notnear ? Q->nn_a : 0u, HC.nn_b = notnear ? Q->nn_b : 0u, HC.nn_dist = notnear ? Q->nn_dist : 0u;
 
   for (uint32_t b = wb0; b < wb1; ++b) {
     {
@@ -618,6 +620,20 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
           }
       }
 
+      // ---- a NOTNEAR node: where both keywords hold the doc, whether a must-hit survives has to be known before the tree is evaluated
+      bool nn_ok[2] = {true, true};
+      if (EXT && TREE && PROX && notnear && __ballot(live[0] || live[1])) {
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          if (live[r] && ((pres[r] >> HC.nn_a) & 1u) && ((pres[r] >> HC.nn_b) & 1u)) {
+            const uint32_t dref = ((inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u) ? 0x80000000u : 0u) | (b << 7) | (lane + 64 * r);
+            const uint32_t ra = HC.nn_a == 0 ? dref : L.href[(HC.nn_a - 1u) & 3u][lane + 64 * r];
+            const uint32_t rb = HC.nn_b == 0 ? dref : L.href[(HC.nn_b - 1u) & 3u][lane + 64 * r];
+            nn_ok[r] = notnear_any(HC, ra, rb);
+          }
+      }
+
       // ---- boolean tree: post-order program over the keywords' presence bits.  Value rules restate
       // ExtAnd_c / ExtOr_c / ExtMaybe_c / ExtAndNot_c (searchnode.cpp:2585-2594, 3494-3540, 3587-3600,
       // 3650-3680): tfidf adds left + right where both sides hold the doc, fields OR together.
@@ -682,6 +698,21 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
               s0.f[r] = m ? (uint32_t)L.kf[kw][lane + 64 * r] : 0u;
               s0.a[r] = m ? s0.a[r] : 0u;
             }
+          } else if (op == PN_NOTNEAR) {
+            // ExtNotNear_c over (must, not): the must side's doc, values and hits; dropped where the not side holds the doc
+            // too and no must-hit survived (searchnode.cpp:5383-5470)
+            TreeEnt o;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const bool m = s1.m[r] && (!s0.m[r] || nn_ok[r]);
+              o.m[r] = m;
+              o.v[r] = m ? s1.v[r] : 0.0f;
+              o.f[r] = m ? s1.f[r] : 0u;
+              o.a[r] = m ? s1.a[r] : 0u;
+            }
+            s0 = o;
+            s1 = s2;
+            s2 = s3;
           } else if (op == PN_PHRASEFIX) {
             // ExtNWay_T<FSMphrase_c> over the AND chain of its words just evaluated: the doc stays only if the
             // words line up; its field mask is the field of the first occurrence (searchnode.cpp:3806-3848)
@@ -751,7 +782,8 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
               const uint32_t pos = mqn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
               L.mq_row[pos] = row[r];
               L.mq_acc[pos] = acc[r];
-              L.mq_fa[pos] = (fld[r] & 0xffu) | ((TREE ? act[r] : 0xffu) << 8);
+              // (bit 16: the doc also holds the NOTNEAR node's not-keyword -- its hits filter the must side's in the final pass)
+              L.mq_fa[pos] = (fld[r] & 0xffu) | ((TREE ? act[r] & 0xffu : 0xffu) << 8) | ((notnear && ((pres[r] >> HC.nn_b) & 1u)) ? 1u << 16 : 0u);
               L.mq_ref[0][pos] = ((inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u) ? 0x80000000u : 0u) | (b << 7) | (lane + 64 * r);
 #pragma unroll
               for (int t = 1; t < MAX_PROX_TERMS; ++t) L.mq_ref[t][pos] = L.href[t - 1][lane + 64 * r];

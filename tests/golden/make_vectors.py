@@ -108,6 +108,9 @@ G = {
                                     "aleph-bet-gimel dalet he wav zajin het", "ein oy vey")] +
                                   [{"count": 1, "fields": [{"runs": [["zwei ", 1], ["oy vey ho ho ho ", 1024]]}]},
                                    {"count": 1, "fields": ["oy vey drei"]}]},
+        "test_349": {"source": "test/test_349/test.xml (index idx: the rows of test_115 with another row 21) + model.bin", "min_word_len": 1,
+                     "ids": list(range(1, 18)) + [20, 21, 22], "like": "test_115",
+                     "row_21": {"runs": [["zwei ", 1], ["oy vey ho ho ho ", 1023], ["oy vey ho h", 1]]}},
         "test_322": {"source": "test/test_322/test.xml + model.bin", "min_word_len": 1, "ids": [1, 2, 3, 100],
                      "docs": [["|sample program", "|program flow direct", "|sample program flow"],
                               ["|one sample program", "|program rev flow", "|one rev flow"],
@@ -362,6 +365,54 @@ for name, query, row, hit in [("bet NEAR/2 he", NEAR(2, T("bet", 1), T("he", 2))
                               ("x NEAR/2 x NEAR/2 x", NEAR(2, T("x", 1), T("x", 2), T("x", 3)), 9, True)]:
     G["cases"].append({"name": "115 sphinxql " + name, "corpus": "test_115", "query": query, "ranker": "proximity_bm25",
                        "expect_row": [row, hit]})
+
+# test_349: NOTNEAR (ExtNotNear_c) over keywords, phrases, OR groups, proximity and nested NOTNEAR; the test lists matching ids
+def NOTNEAR(n, a, b):
+    return OP("notnear", a, b, opt=n)
+
+
+PH = lambda *w: OP("phrase", *[T(x, i + 1) for i, x in enumerate(w)])
+for name, query, ids in [
+    ("a NOTNEAR/1 c", NOTNEAR(1, T("a", 1), T("c", 2)), list(range(1, 16))),
+    ("a NOTNEAR/2 c", NOTNEAR(2, T("a", 1), T("c", 2)), list(range(2, 16))),
+    ("a NOTNEAR/3 c", NOTNEAR(3, T("a", 1), T("c", 2)), [3] + list(range(5, 16))),
+    ("a NOTNEAR/5 c", NOTNEAR(5, T("a", 1), T("c", 2)), list(range(7, 16))),
+    ("a NOTNEAR/6 c", NOTNEAR(6, T("a", 1), T("c", 2)), list(range(8, 16))),
+    ("a NOTNEAR/7 c", NOTNEAR(7, T("a", 1), T("c", 2)), list(range(10, 16))),
+    ("a NOTNEAR/15 c", NOTNEAR(15, T("a", 1), T("c", 2)), list(range(10, 16))),
+    ("b NOTNEAR/1 c", NOTNEAR(1, T("b", 1), T("c", 2)), list(range(4, 15))),
+    ("b NOTNEAR/2 c", NOTNEAR(2, T("b", 1), T("c", 2)), list(range(5, 15))),
+    ('"a b" NOTNEAR/2 c', NOTNEAR(2, PH("a", "b"), T("c", 3)), [5, 6, 7, 10, 11, 12, 13, 14]),
+    ('"a b" NOTNEAR/3 c', NOTNEAR(3, PH("a", "b"), T("c", 3)), [6, 7, 10, 11, 12, 13, 14]),
+    ("a NOTNEAR/3 (c | d)", NOTNEAR(3, T("a", 1), OP("or", T("c", 2), T("d", 3))), [3] + list(range(5, 16))),
+    ('a NOTNEAR/3 "c x d"', NOTNEAR(3, T("a", 1), OP("phrase", T("c", 2), T("x", 3), T("d", 4))), list(range(1, 16))),
+    ('a NOTNEAR/9 "c x d"', NOTNEAR(9, T("a", 1), OP("phrase", T("c", 2), T("x", 3), T("d", 4))), [1, 2, 3, 4, 5, 6, 7] + list(range(9, 16))),
+    ('a NOTNEAR/11 "c x x d"', NOTNEAR(11, T("a", 1), OP("phrase", T("c", 2), T("x", 3), T("x", 4), T("d", 5))), list(range(1, 9)) + list(range(10, 16))),
+    ("oy NOTNEAR/1 ho", NOTNEAR(1, T("oy", 1), T("ho", 2)), [20, 21, 22]),
+    ("oy NOTNEAR/2 ho", NOTNEAR(2, T("oy", 1), T("ho", 2)), [20, 22]),
+    ("zwei NOTNEAR/2 ho", NOTNEAR(2, T("zwei", 1), T("ho", 2)), [21]),
+    ("zwei NOTNEAR/4 ho", NOTNEAR(4, T("zwei", 1), T("ho", 2)), []),
+    ("zwei NOTNEAR/1 vey", NOTNEAR(1, T("zwei", 1), T("vey", 2)), [21]),
+    ("zwei NOTNEAR/2 vey", NOTNEAR(2, T("zwei", 1), T("vey", 2)), []),
+    ("vey NOTNEAR/1 ho", NOTNEAR(1, T("vey", 1), T("ho", 2)), [20, 22]),
+    ("vey NOTNEAR/1 oy", NOTNEAR(1, T("vey", 1), T("oy", 2)), [20, 21, 22]),
+    ("d NOTNEAR/1 a", NOTNEAR(1, T("d", 1), T("a", 2)), list(range(1, 14))),
+    ("d NOTNEAR/3 a", NOTNEAR(3, T("d", 1), T("a", 2)), list(range(1, 12))),
+    ("c NOTNEAR/1 x", NOTNEAR(1, T("c", 1), T("x", 2)), [1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14]),
+    ("c NOTNEAR/2 x", NOTNEAR(2, T("c", 1), T("x", 2)), [1, 2, 3, 4, 5, 6, 7, 14]),
+    ("c NOTNEAR/3 x", NOTNEAR(3, T("c", 1), T("x", 2)), [1, 2, 3, 4, 5, 6, 7, 14]),
+    ("x NOTNEAR/2 c", NOTNEAR(2, T("x", 1), T("c", 2)), [3, 6, 7, 8, 9, 10, 11, 12, 13]),
+    ('("a b" NOTNEAR/3 (d |e)) NOTNEAR/2 c', NOTNEAR(2, NOTNEAR(3, PH("a", "b"), OP("or", T("d", 3), T("e", 4))), T("c", 5)), [5, 6, 7, 10, 11, 12, 13, 14]),
+    ('"a b"~4 NOTNEAR/1 c', NOTNEAR(1, OP("proximity", T("a", 1), T("b", 2), opt=4), T("c", 3)), list(range(4, 15))),
+    ('( "a b" | "a x b" ) NOTNEAR/1 c', NOTNEAR(1, OP("or", PH("a", "b"), OP("phrase", T("a", 3), T("x", 4), T("b", 5))), T("c", 6)), [4, 5, 6, 7, 8, 10, 11, 12, 13, 14]),
+]:
+    G["cases"].append({"name": "349 " + name, "corpus": "test_349", "query": query, "ranker": "proximity_bm25", "expect_ids": ids})
+
+for _name, _c in G["corpora"].items():  # a corpus given as "like another one, with row 21 replaced"
+    if "like" in _c:
+        spec = [dict(r) for r in G["corpora"][_c.pop("like")]["docs_spec"]]
+        spec[-2] = {"count": 1, "fields": [_c.pop("row_21")]}
+        _c["docs_spec"] = spec
 
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
