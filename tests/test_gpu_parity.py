@@ -216,8 +216,8 @@ def test_unsupported_shapes_fail_loudly(dev):
     m, ctx, batch = dev
     hi = m.synth_index(1000, [0.5, 0.5], seed=1)
     seg = m.Segment(ctx, hi)
-    # an operator the device path does not know (near / before / sentence ...: op codes beyond QUORUM)
-    q_or = m.Query(m.XQNode(9, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
+    # an operator the device path does not know (SENTENCE / PARAGRAPH ...: op codes beyond NOTNEAR)
+    q_or = m.Query(m.XQNode(11, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
     q_big = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25, max_matches=5000)
     q_ok = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25)
     r = batch.search(seg, [q_or, q_ok, q_big])
