@@ -178,6 +178,51 @@ def test_full_size_properties(orc):
                 want = to_orc(orc, qs[i]).run(oi)
                 g = res["bm"][0][i]
                 assert g.total_found == want.total_found and (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+        # ---- BASELINE config 3 at full size: 3-term mixes a b c | (a|b) c | a (b|c) | a b -c under SPH_RANK_PROXIMITY_BM25.
+        # The window-driven tree kernel (scan_bt_kernel + rank_kernel) and the block path (scan_pk_kernel + rank_kernel) must
+        # agree bit for bit; totals obey inclusion-exclusion; results obey the sorter's order; a rerun returns the same bytes;
+        # the selective shapes equal the oracle.
+        ctx.set("path", 0)
+        ctx.set("bitmap_inv", 64)
+        AND_, OR_, ANDNOT_ = m.XQNode.AND, (lambda *k: m.XQNode(m.SPH_QUERY_OR, list(k))), (lambda *k: m.XQNode(m.SPH_QUERY_ANDNOT, list(k)))
+        triples = [(0, 1, 2), (1, 0, 2), (3, 0, 1), (2, 1, 0), (4, 1, 2), (0, 2, 3)]
+        shapes = []
+        for a, b, c in triples:
+            ka, kb, kc = kw(m, a, 1), kw(m, b, 2), kw(m, c, 3)
+            shapes += [AND_(ka, kb, kc), AND_(OR_(ka, kb), kc), AND_(ka, OR_(kb, kc)), ANDNOT_(AND_(ka, kb), kc)]
+        q3 = [m.Query(r, ranker=m.SPH_RANK_PROXIMITY_BM25, max_matches=1000) for r in shapes]
+        qn = [m.Query(r, ranker=m.SPH_RANK_NONE, max_matches=10) for r in
+              [x for a, b, c in triples for x in (AND_(kw(m, a, 1), kw(m, c, 2)), AND_(kw(m, b, 1), kw(m, c, 2)), AND_(kw(m, a, 1), kw(m, b, 2)))]]
+        b3 = m.Batch(ctx, len(q3))
+        try:
+            out = {}
+            for name, inv in (("bt", 32), ("blocks", 0)):
+                ctx.set("bt_cover_inv", inv)
+                r1 = b3.search(seg, q3)
+                r2 = b3.search(seg, q3)
+                for x, y in zip(r1, r2):
+                    assert x.status == 0 and x.total_found == y.total_found and (x.rowid == y.rowid).all() and (x.weight == y.weight).all()
+                out[name] = r1
+            for x, y in zip(out["bt"], out["blocks"]):
+                assert x.total_found == y.total_found and (x.rowid == y.rowid).all() and (x.weight == y.weight).all()
+                check_order(x)
+            pair_tot = [r.total_found for r in b3.search(seg, qn)]
+            for t, (a, b, c) in enumerate(triples):
+                abc, aorb_c, a_borc, ab_notc = (out["bt"][4 * t + i].total_found for i in range(4))
+                ac, bc, ab = pair_tot[3 * t: 3 * t + 3]
+                assert aorb_c == ac + bc - abc      # |(A u B) n C| = |A n C| + |B n C| - |A n B n C|
+                assert a_borc == ab + ac - abc      # |A n (B u C)|
+                assert ab_notc == ab - abc          # |A n B \ C|
+                assert abc <= min(ab, ac, bc)
+            for i, q in enumerate(q3):  # the shapes driven by a selective keyword are cheap enough for the CPU
+                a = triples[i // 4][0]
+                if docs[a] < 300_000 and i % 4 != 1:
+                    want = to_orc(orc, q).run(oi)
+                    g = out["bt"][i]
+                    assert g.total_found == want.total_found and (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+        finally:
+            ctx.set("bt_cover_inv", 32)
+            b3.close()
     finally:
         ctx.set("path", 0)
         ctx.set("bitmap_inv", 64)
