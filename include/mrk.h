@@ -400,6 +400,32 @@ const uint32_t* mrk_host_index_attr_rows(const mrk_host_index* h, uint32_t* stri
 /* .spm bitmap (bit rowid & 31 of word rowid >> 5), as mrk_segment_set_dead_rows takes it; NULL = no map */
 const uint32_t* mrk_host_index_dead_rows(const mrk_host_index* h, uint64_t* n_rows);
 
+/* ---- query text -> tree (host only) ------------------------------------------------------------------------------------
+   The caller side of the path: the extended query syntax (sphParseExtendedQuery: sphinxquery.y:57-125 grammar; the lexer
+   XQParser_t::GetToken, sphinxquery.cpp:1201-1553; AddKeyword / AddOp, :1600-1678; FixupNots, :499-562) restated for the
+   operators this library evaluates:  a b   a | b   a MAYBE b   -a  !a   ( )   "a b"   "a b"~N   "a b c"/N   "a b c"/0.5
+   a << b   a NEAR/N b   a NOTNEAR/N b   @field  @(f1,f2)  @!field  @!(f1,f2)  @*  @field[N]  @@relaxed   ^a  a$  =a  a^1.5
+   and '*' inside a phrase.  The result is the flat mrk_node[] + children[] form mrk_query takes (post-order, root last):
+   query positions (atom_pos) in textual order, field limits as masks, NOT folded into ANDNOT, one-word phrases folded to
+   their word, fractional quorum thresholds resolved against the word count.  SENTENCE / PARAGRAPH / ZONE / ZONESPAN are
+   not recognised (their capitals read as keywords).
+   Tokenizing is ASCII [A-Za-z0-9_] + bytes >= 0x80, lower-casing ASCII only -- a host with a charset_table, morphology,
+   stopwords or wordforms runs its own tokenizer / dictionary over the keywords' text; what this entry point fixes is the
+   grammar.  Words shorter than min_word_len (code points) are dropped and keep their position (overshort_step = 1).
+   field_names[i] is the name of full-text field i (bit i of a field mask).  Keywords come back as text
+   (mrk_parsed_keyword); mrk_parsed_resolve fills term_id from a dict=keywords dictionary.  A syntax error returns
+   MRK_E_INVAL with the reason in mrk_last_error() (the reference's "query error: ..."). */
+typedef struct mrk_parsed_query mrk_parsed_query;
+int mrk_query_parse(const char* text, const char* const* field_names, uint32_t n_fields, uint32_t min_word_len,
+                    mrk_parsed_query** out);
+void mrk_parsed_free(mrk_parsed_query* q);
+int32_t mrk_parsed_n_nodes(const mrk_parsed_query* q);
+int32_t mrk_parsed_root(const mrk_parsed_query* q); /* -1: the query holds no keyword (matches nothing) */
+const mrk_node* mrk_parsed_nodes(const mrk_parsed_query* q);
+const int32_t* mrk_parsed_children(const mrk_parsed_query* q, int32_t* n);
+const char* mrk_parsed_keyword(const mrk_parsed_query* q, int32_t node); /* "" for operator nodes */
+int mrk_parsed_resolve(mrk_parsed_query* q, const mrk_host_index* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,14 @@ SYMBOLS = [
     ("mrk_host_index_dead_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("mrk_host_index_attr", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(AttrInfo)]),
     ("mrk_host_index_attr_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("mrk_query_parse", C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mrk_parsed_free", None, [C.c_void_p]),
+    ("mrk_parsed_n_nodes", C.c_int32, [C.c_void_p]),
+    ("mrk_parsed_root", C.c_int32, [C.c_void_p]),
+    ("mrk_parsed_nodes", C.POINTER(Node), [C.c_void_p]),
+    ("mrk_parsed_children", C.POINTER(C.c_int32), [C.c_void_p, C.POINTER(C.c_int32)]),
+    ("mrk_parsed_keyword", C.c_char_p, [C.c_void_p, C.c_int32]),
+    ("mrk_parsed_resolve", C.c_int, [C.c_void_p, C.c_void_p]),
 ]
 
 

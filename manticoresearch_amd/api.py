@@ -14,7 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence, Union
 
 import numpy as np
 
@@ -187,6 +187,7 @@ class XQKeyword:
     boost: float = 1.0        # m_fBoost
     field_start: bool = False  # m_bFieldStart: '^word'
     field_end: bool = False    # m_bFieldEnd: 'word$'
+    text: str = ""             # m_sWord, when the tree came from parse_query
 
 
 @dataclass
@@ -215,6 +216,40 @@ class XQNode:
     @staticmethod
     def AND(*kids: "XQNode") -> "XQNode":
         return XQNode(SPH_QUERY_AND, list(kids))
+
+
+def parse_query(text: str, field_names: Sequence[str] = (), min_word_len: int = 1,
+                lookup: "Union[None, HostIndex, Callable[[str], int]]" = None) -> Optional[XQNode]:
+    """The extended query syntax -> XQNode tree (mrk_query_parse: the sphinxquery.y grammar + XQParser_t lexer restated in
+    csrc/mrk_query.cpp).  lookup resolves a keyword's text to its dictionary slot: a HostIndex opened from files
+    (dict=keywords), or a callable; without it every term_id is -1 and XQKeyword.text carries the word.  None = a query
+    without keywords.  A syntax error raises MrkError with the reference's wording."""
+    L = lib()
+    names = (C.c_char_p * max(1, len(field_names)))(*[f.encode() for f in field_names])
+    pq = C.c_void_p()
+    check(L.mrk_query_parse(text.encode("utf-8"), names, len(field_names), min_word_len, C.byref(pq)))
+    try:
+        if isinstance(lookup, HostIndex):
+            check(L.mrk_parsed_resolve(pq, lookup._owner.h))
+        n, root = L.mrk_parsed_n_nodes(pq), L.mrk_parsed_root(pq)
+        if root < 0:
+            return None
+        nodes, kids = L.mrk_parsed_nodes(pq), L.mrk_parsed_children(pq, None)
+        built: List[XQNode] = []
+        for i in range(n):  # post-order: children come before their parent
+            m = nodes[i]
+            if m.op == SPH_QUERY_TERM:
+                w = L.mrk_parsed_keyword(pq, i).decode("utf-8")
+                tid = m.term_id if not callable(lookup) else int(lookup(w))
+                x = XQNode.keyword(tid, m.atom_pos, m.field_mask, m.boost, bool(m.term_pos & 1) and m.term_pos != 4,
+                                   bool(m.term_pos & 2) and m.term_pos != 4, m.field_max_pos)
+                x.word.text = w
+            else:
+                x = XQNode(m.op, [built[kids[m.first_child + j]] for j in range(m.n_children)], None, m.field_mask, m.opt)
+            built.append(x)
+        return built[root]
+    finally:
+        L.mrk_parsed_free(pq)
 
 
 @dataclass
@@ -519,6 +554,6 @@ def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool =
 
 __all__ = ["SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
-           "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE", "SPH_QUERY_NEAR", "SPH_QUERY_NOTNEAR",
+           "parse_query", "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE", "SPH_QUERY_NEAR", "SPH_QUERY_NOTNEAR",
            "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Filter", "Matches", "Context",
            "Segment", "Batch", "prepare", "idf", "MrkError", "validate_index", "pair_stats"]

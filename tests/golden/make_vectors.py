@@ -307,7 +307,8 @@ G["cases"] += [  # test_080: '@field[N]' position limits at the far end of a 299
 ]
 G["cases"] += [  # the rest of test_019's query list, as far as its trees can be written down without the query parser
     {"name": "019 \"test that\"~3 | basic", "corpus": "test_019",
-     "query": OP("or", OP("proximity", T("test", 1), T("that", 2), opt=3), T("basic", 3)), "ranker": "proximity_bm25",
+     # the keyword after '"..."~N' stands one position further on (XQNode_t::FixupAtomPos, sphinxquery.cpp:923-938)
+     "query": OP("or", OP("proximity", T("test", 1), T("that", 2), opt=3), T("basic", 4)), "ranker": "proximity_bm25",
      "expect": [[333, 1647], [111, 1551], [555, 1551]]},
     {"name": "019 \"hello program\"~3", "corpus": "test_019", "query": OP("proximity", T("hello", 1), T("program", 2), opt=3),
      "ranker": "proximity_bm25", "expect": []},
@@ -403,7 +404,7 @@ for name, query, ids in [
     ("c NOTNEAR/3 x", NOTNEAR(3, T("c", 1), T("x", 2)), [1, 2, 3, 4, 5, 6, 7, 14]),
     ("x NOTNEAR/2 c", NOTNEAR(2, T("x", 1), T("c", 2)), [3, 6, 7, 8, 9, 10, 11, 12, 13]),
     ('("a b" NOTNEAR/3 (d |e)) NOTNEAR/2 c', NOTNEAR(2, NOTNEAR(3, PH("a", "b"), OP("or", T("d", 3), T("e", 4))), T("c", 5)), [5, 6, 7, 10, 11, 12, 13, 14]),
-    ('"a b"~4 NOTNEAR/1 c', NOTNEAR(1, OP("proximity", T("a", 1), T("b", 2), opt=4), T("c", 3)), list(range(4, 15))),
+    ('"a b"~4 NOTNEAR/1 c', NOTNEAR(1, OP("proximity", T("a", 1), T("b", 2), opt=4), T("c", 4)), list(range(4, 15))),
     ('( "a b" | "a x b" ) NOTNEAR/1 c', NOTNEAR(1, OP("or", PH("a", "b"), OP("phrase", T("a", 3), T("x", 4), T("b", 5))), T("c", 6)), [4, 5, 6, 7, 8, 10, 11, 12, 13, 14]),
 ]:
     G["cases"].append({"name": "349 " + name, "corpus": "test_349", "query": query, "ranker": "proximity_bm25", "expect_ids": ids})

@@ -832,10 +832,13 @@ def test_near_and_notnear(orc, dev, block, fmt):
 
 
 # ------------------------------------------------------------------ tests/golden/reference_vectors.json on the device
-def test_golden_vectors_on_device(dev):
+@pytest.mark.parametrize("from_text", [False, True], ids=["trees", "query-text"])
+def test_golden_vectors_on_device(dev, from_text):
     """Every case of the committed golden fixture, straight from the device path (no oracle in the loop).
-    A case whose shape a path declines must say so, not answer wrongly."""
+    A case whose shape a path declines must say so, not answer wrongly.  "query-text": the tree comes from the library's
+    query parser over the query's text (the way a caller hands it over) instead of the hand-built one."""
     from test_oracle_golden import GOLDEN
+    from test_query_parser import FIELDS, query_text
     m, ctx, batch = dev
     rankers = {"proximity_bm25": m.SPH_RANK_PROXIMITY_BM25, "bm25": m.SPH_RANK_BM25, "none": m.SPH_RANK_NONE,
                "wordcount": m.SPH_RANK_WORDCOUNT, "sph04": m.SPH_RANK_SPH04, "fieldmask": m.SPH_RANK_FIELDMASK}
@@ -866,7 +869,13 @@ def test_golden_vectors_on_device(dev):
         nf = max(len(d) for d in corpus["docs"])
         seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(corpus["docs"]), n_fields=nf))
         cases = [c for c in GOLDEN["cases"] if c["corpus"] == name]
-        qs = [m.Query(tree(v, c["query"]), ranker=rankers[c["ranker"]], field_weights=c.get("field_weights"), plain_idf=bool(c.get("plain_idf")),
+        def root(c):
+            text = query_text(c["name"]) if from_text else None
+            if text is None:
+                return tree(v, c["query"])
+            return m.parse_query(text, FIELDS.get(name, []), corpus["min_word_len"], lookup=lambda w: v.get(w, -1))
+
+        qs = [m.Query(root(c), ranker=rankers[c["ranker"]], field_weights=c.get("field_weights"), plain_idf=bool(c.get("plain_idf")),
                       total_docs=c.get("total_docs", 0), local_docs={v[w]: n for w, n in c["local_docs"].items() if w in v} if "local_docs" in c else None)
               for c in cases]
         for c, r in zip(cases, batch.search(seg, qs)):

@@ -1,0 +1,148 @@
+"""The query-text front end (mrk_query_parse, csrc/mrk_query.cpp) against what the reference's parser builds.
+
+Two pins, no GPU:
+  * the reference's own parser test (src/gtests/gtests_tokenizer.cpp:703-751, QueryParser.test_many; :753-759
+    NEAR_with_NOT; :761-779 soft_whitespace1/2): query text -> sphReconstructNode() string, with the fixture's
+    settings (fields title + body, min_word_len 2).  The strings are data kept in tests/golden/query_parser_vectors.json;
+    the reconstruction below follows sphReconstructNode (sphinxquery.cpp:1907-1987) over our tree.
+  * every golden ranking case whose name carries its query text (tests/golden/reference_vectors.json): the tree the
+    parser builds from the text must equal the hand-built tree the ranking goldens were pinned with -- operators,
+    operator arguments, keyword text, query positions, field masks and position modifiers.
+"""
+import json
+import os
+import re
+
+import pytest
+
+from manticoresearch_amd import api
+from manticoresearch_amd._lib import MrkError
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_vectors.json")))
+PARSER = json.load(open(os.path.join(HERE, "golden", "query_parser_vectors.json")))
+ALL = 0xFFFFFFFF
+OPNAME = {api.SPH_QUERY_AND: "and", api.SPH_QUERY_OR: "or", api.SPH_QUERY_MAYBE: "maybe", api.SPH_QUERY_ANDNOT: "andnot",
+          api.SPH_QUERY_PHRASE: "phrase", api.SPH_QUERY_PROXIMITY: "proximity", api.SPH_QUERY_QUORUM: "quorum",
+          api.SPH_QUERY_BEFORE: "before", api.SPH_QUERY_NEAR: "near", api.SPH_QUERY_NOTNEAR: "notnear"}
+
+
+# ---------------------------------------------------------------- sphReconstructNode over an XQNode tree
+def reconstruct(n, fields):
+    if n is None:
+        return ""
+    words_ops = {api.SPH_QUERY_PHRASE: '"%s"', api.SPH_QUERY_PROXIMITY: '"%s"~' + str(n.opt), api.SPH_QUERY_QUORUM: '"%s"/' + str(n.opt)}
+    if n.word is not None or n.op in words_ops:  # a node that holds words
+        ws = [n.word.text] if n.word is not None else [k.word.text for k in n.children]
+        s = " ".join(ws)
+        if n.word is None:
+            s = words_ops[n.op] % s
+        mask = n.field_mask if n.word is not None else n.children[0].field_mask
+        if mask != ALL:
+            s = "( @%s: %s )" % (",".join(f for i, f in enumerate(fields) if mask >> i & 1), s)
+        return s
+    sop = {api.SPH_QUERY_AND: " ", api.SPH_QUERY_OR: "|", api.SPH_QUERY_MAYBE: "MAYBE", api.SPH_QUERY_ANDNOT: "AND NOT",
+           api.SPH_QUERY_BEFORE: "BEFORE", api.SPH_QUERY_NEAR: "NEAR"}[n.op]
+    s = reconstruct(n.children[0], fields)
+    for k in n.children[1:]:
+        s = "%s %s %s" % (s, sop, reconstruct(k, fields))
+    return "( %s )" % s if len(n.children) > 1 else s
+
+
+@pytest.mark.parametrize("case", PARSER["reconstruct"], ids=lambda c: c["query"])
+def test_reference_parser_vectors(case):
+    try:
+        tree = api.parse_query(case["query"], PARSER["fields"], PARSER["min_word_len"])
+    except MrkError:
+        tree = None  # the reference test reconstructs the NULL root of a failed parse as ""
+    assert reconstruct(tree, PARSER["fields"]) == case["reconstruct"]
+
+
+def test_not_inside_near_is_rejected():
+    with pytest.raises(MrkError, match="non-computable"):
+        api.parse_query("me -test NEAR/2 off", PARSER["fields"], PARSER["min_word_len"])
+    for q in ("-one", "-one -two"):
+        with pytest.raises(MrkError, match="non-computable"):
+            api.parse_query(q, PARSER["fields"], PARSER["min_word_len"])
+
+
+@pytest.mark.parametrize("q", PARSER["soft_whitespace"])
+def test_soft_whitespace_keeps_positions(q):
+    tree = api.parse_query(q, PARSER["fields"], PARSER["min_word_len"])
+    assert [(k.word.text, k.word.atom_pos) for k in tree.children] == [("me", 1), ("off", 2)]
+
+
+# ---------------------------------------------------------------- the ranking goldens' hand-built trees
+FIELDS = {"test_019": ["title", "body"], "test_019_fld": ["title", "body"], "test_037": ["title", "body"], "test_080": ["first", "second"]}
+NOT_TEXT = re.compile(r"^(weight_boundary|037 phrase |205 )")
+SUFFIX = re.compile(r"(, field_weights [-0-9,]+| wordcount| \(bm25\)| sph04| fieldmask| bm25)$")
+
+
+def query_text(name):
+    if NOT_TEXT.match(name):
+        return None
+    t = re.sub(r"^\d+(/test2)? (fld |sphinxql )?", "", name)
+    while SUFFIX.search(t):
+        t = SUFFIX.sub("", t)
+    return t
+
+
+def as_golden(n):
+    """XQNode -> the dict shape of reference_vectors.json"""
+    if n.word is not None:
+        d = {"word": n.word.text, "pos": n.word.atom_pos, "mask": n.field_mask}
+        tp = n.term_pos()
+        if tp:
+            d["tp"] = {1: "start", 2: "end", 3: "startend", 4: "limit"}[tp]
+            d["max_pos"] = n.field_max_pos
+        return d
+    return {"op": OPNAME[n.op], "kids": [as_golden(k) for k in n.children], "opt": n.opt}
+
+
+def strip_op_masks(q):
+    if "word" in q:
+        return q
+    return {"op": q["op"], "kids": [strip_op_masks(k) for k in q["kids"]], "opt": q["opt"]}
+
+
+TEXT_CASES = [(c, query_text(c["name"])) for c in GOLD["cases"] if query_text(c["name"]) is not None]
+
+
+def test_most_goldens_carry_their_text():
+    assert len(TEXT_CASES) >= 135
+
+
+@pytest.mark.parametrize("case,text", TEXT_CASES, ids=[c["name"] for c, _ in TEXT_CASES])
+def test_parsed_text_equals_the_golden_tree(case, text):
+    corpus = GOLD["corpora"][case["corpus"]]
+    tree = api.parse_query(text, FIELDS.get(case["corpus"], []), corpus["min_word_len"])
+    assert as_golden(tree) == strip_op_masks(case["query"])
+
+
+# ---------------------------------------------------------------- syntax the goldens do not reach
+def test_field_limits_modifiers_and_errors():
+    F = ["title", "body", "tags"]
+    t = api.parse_query("@(title,tags) hello @!body world @* again", F)
+    assert [(k.word.text, k.field_mask) for k in t.children] == [("hello", 0b101), ("world", ~0b010 & ALL), ("again", ALL)]
+    t = api.parse_query("^hello$ =world^2.5 tail$^0.5", F)
+    assert [(k.word.text, k.term_pos(), k.word.boost) for k in t.children] == [("hello", 3, 1.0), ("=world", 0, 2.5), ("tail", 2, 0.5)]
+    t = api.parse_query("@body[5] hello", F)
+    assert (t.field_mask, t.term_pos(), t.field_max_pos) == (0b010, 4, 5)
+    t = api.parse_query("a MAYBE b MAYBE c", F)
+    assert (t.op, len(t.children)) == (api.SPH_QUERY_MAYBE, 3)
+    t = api.parse_query("a NEAR/2 b NEAR/3 c", F)  # a different distance starts a new node (AddOp compares the argument)
+    assert (t.op, t.opt, t.children[0].op, t.children[0].opt) == (api.SPH_QUERY_NEAR, 3, api.SPH_QUERY_NEAR, 2)
+    t = api.parse_query("a NOTNEAR/1 b NOTNEAR/2 c", F)  # %left
+    assert (t.opt, t.children[0].opt, t.children[1].word.text) == (2, 1, "c")
+    t = api.parse_query('"a * * b * c"', F)  # PhraseShiftQpos
+    assert [k.word.atom_pos for k in t.children] == [1, 4, 6]
+    t = api.parse_query('"one"~3 two', F)  # FixupDegenerates
+    assert [k.word.text for k in t.children] == ["one", "two"]
+    assert api.parse_query("", F) is None and api.parse_query('""', F) is None
+    for bad, why in (("@nosuch a", "no field"), ("(a b", "parenthesis"), ('"a b', "unterminated"), ('"a b"/0', "quorum threshold"),
+                     ('"a b"/1.5', "out of bounds"), ('"a b"~0', "proximity threshold"), ("@(title,body a", "field")):
+        with pytest.raises(MrkError, match=why):
+            api.parse_query(bad, F)
+    # a callable resolves keywords; unknown words stay < 0
+    t = api.parse_query("alpha beta", F, lookup=lambda w: {"alpha": 7}.get(w, -1))
+    assert [k.word.term_id for k in t.children] == [7, -1]
