@@ -106,11 +106,13 @@ constexpr uint32_t TF_DUPES = 16;      // a keyword occurs more than once in the
 constexpr uint32_t TF_PHRASE_LEAF = 8; // one PHRASE below other operators: ph_mask = its words' slots in t[]
 constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[] = atom positions in phrase order
 constexpr uint32_t TF_FAT = TF_PHRASE | TF_PHRASE_LEAF | TF_TERMPOS | TF_ORDER | TF_NOTNEAR; // final ranking needs the full hit pass (rank_kernel<true>)
+constexpr uint32_t TF_GEN = 1024;   // answered by the generic per-doc evaluator (mrk_keval.h): matches go to queue 2 with one reference per keyword
 constexpr int PHRASE_STATES = 8;    // live FSMphrase_c states per doc (>= phrase span + 1)
 constexpr int TREE_STACK = 4;       // evaluation stack depth of the tree program
-constexpr int MAX_PASSES = 4; // driver keywords per query (size of the tree's candidate cover)
+constexpr int MAX_PASSES = 8; // driver keywords per query (size of the tree's candidate cover)
 constexpr uint32_t QF_OVERFLOW = 1; // candidate list overflowed: the host reruns the query with a list that holds every doc
 constexpr uint32_t QF_FSM = 2;      // more live phrase states than the kernel keeps: the query fails
+constexpr uint32_t QF_ARENA = 4;    // the generic evaluator ran out of hit-list memory (ctx tunable gen_spill_mb): the query fails
 constexpr int MAX_PROX_TERMS_ = 4;
 constexpr int MAPCAP = 4096; // direct-map probe window (rowids) per decoded block
 
@@ -165,6 +167,7 @@ struct DevQuery {
   uint32_t px_dist;                   // 0 = exact PHRASE; else PROXIMITY ('"a b"~N'): XQNode_t::m_iOpArg; bit 31: 'a NEAR/N b'
   uint32_t nn_a, nn_b, nn_dist;       // TF_NOTNEAR: keyword slots of the must / not side, the distance
   uint32_t max_qpos, n_qwords;        // ExtRanker_c::m_iMaxQpos (largest query position) / m_iQwords (distinct words)
+  uint32_t gen_prog;                  // TF_GEN: index of the pass's GenProg
   int32_t weights[32];
   DevTerm t[MRK_MAX_AND_TERMS];
 };
@@ -196,6 +199,40 @@ struct MatchQueue {
   uint32_t cap;    // chunks per shard; shard s owns chunks [s * cap, (s + 1) * cap)
 };
 
+// ---- the generic per-doc evaluator (mrk_keval.h): the reference's evaluation tree, one node per entry, post-order
+constexpr int GEN_MAX_NODES = 24;
+constexpr int MQ_GEN_PLANES = 1 + MRK_MAX_AND_TERMS; // queue 2: rowid + one packed-array reference per keyword slot
+constexpr uint32_t GN_TERM = 0, GN_MULTIAND = 1, GN_AND = 2, GN_OR = 3, GN_MAYBE = 4, GN_ANDNOT = 5, GN_PHRASE = 6, GN_PROX = 7, GN_NEAR = 8, GN_QUORUM = 9,
+                   GN_ORDER = 10, GN_NOTNEAR = 11;
+struct GenNode {
+  uint8_t kind;     // GN_*
+  uint8_t n_kids;
+  uint8_t flags;    // AND: 1 = m_bQPosReverse; MULTIAND: 2 = some keyword is field-limited (hits are tested against the masks)
+  uint8_t n_words;  // PHRASE / PROX: words
+  uint16_t npl, npr; // AND: node positions its sides' hits are relabelled with (0 = keep)
+  uint8_t kid[8];   // child node indices; TERM: [0] = keyword slot; MULTIAND / QUORUM: keyword slots; PHRASE / PROX / NEAR: [0] = the operands' AND chain
+  uint8_t aux[8];   // MULTIAND: node position per keyword; PHRASE / PROX: the words' keyword slots in phrase order
+  int32_t opt;      // distance / threshold
+  uint32_t pad;
+};
+struct GenProg {
+  uint32_t n_nodes, pad[7];
+  GenNode nodes[GEN_MAX_NODES];
+};
+struct GenHit { // ExtHit_t without the rowid (sphinxint.h:725-743)
+  uint32_t hitpos;
+  uint16_t qpos, nodepos, spanlen, matchlen;
+  uint32_t weight;
+};
+struct GenArgs {
+  const GenProg* progs;
+  GenHit* lane_arena;  // [lanes of the evaluator's grid][lane_hits]
+  uint32_t lane_hits, n_lanes;
+  GenHit* spill;       // lists that do not fit the lane's slice; handed out by atomicAdd, released with the launch
+  unsigned long long spill_cap;
+  unsigned long long* spill_used;
+};
+
 struct ScanArgs {
   DevSegment seg;
   const DevQuery* queries;
@@ -211,7 +248,8 @@ struct ScanArgs {
   uint32_t* q_flags;   // [n_queries]
   uint32_t* q_tau_bin; // [n_queries] running pruning threshold (bin index), atomicMax
   uint64_t* cand;      // candidate arena
-  MatchQueue mq[2];    // [0] plain boolean trees, [1] queries with PHRASE / PROXIMITY / BEFORE nodes or position modifiers
+  MatchQueue mq[3];    // [0] plain boolean trees, [1] queries with PHRASE / PROXIMITY / BEFORE nodes or position modifiers, [2] TF_GEN
+  GenArgs gen;
 };
 
 struct SelectArgs {
@@ -256,11 +294,12 @@ struct PackRowsArgs {
 void launch_pack_rows(const PackRowsArgs& a, void* stream);
 
 void launch_scan(const ScanArgs& a, void* stream);
-void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, bool ext, void* stream);
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, bool ext, void* stream, bool gen = false);
 constexpr int MAX_PROX_TERMS = MAX_PROX_TERMS_; // keywords whose hit streams the hit kernel merges per doc
 void launch_scan_bm(const ScanArgs& a, void* stream); // a.items: (query, window range) work items
 void launch_scan_bt(const ScanArgs& a, void* stream); // the same for TF_BTREE passes (mrk_scan_bt.hip)
-// final ranking of the queued matches (mrk_rank.hip): a persistent grid drains queue `which` of a.mq
+// final ranking of the queued matches (mrk_rank.hip): a persistent grid drains queue `which` of a.mq (2 = the generic evaluator)
+constexpr int GEN_GRID = 512; // its workgroups: lane arenas are sized for GEN_GRID * WG lanes
 void launch_rank(const ScanArgs& a, int which, void* stream);
 void launch_select(const SelectArgs& a, void* stream);
 void launch_merge(const MergeArgs& a, void* stream);

@@ -148,8 +148,13 @@ struct mrk_batch {
   bool decl_dirty = false; // d_decl holds non-zero words of an earlier submit
   bool any_declined = false;
   // HBM match queues of the hit-ranked queries (scan kernels -> rank_kernel): [0] plain trees, [1] PHRASE & co
-  DevBuf<uint32_t> d_mq_data[2], d_mq_hdr[2];
-  DevBuf<uint32_t> d_mq_count; // [2][MQ_SHARDS]
+  DevBuf<uint32_t> d_mq_data[3], d_mq_hdr[3];
+  DevBuf<uint32_t> d_mq_count; // [3][MQ_SHARDS]
+  // the generic evaluator (mrk_keval.h): programs of the batch's TF_GEN passes, per-lane + shared hit-list memory
+  DevBuf<mrk::GenProg> d_gen_progs;
+  DevBuf<mrk::GenHit> d_gen_lane, d_gen_spill;
+  DevBuf<unsigned long long> d_gen_used;
+  std::vector<mrk::GenProg> gen_progs;
   bool last_fat = false;
   // decoded results
   std::vector<uint32_t> rowid;
@@ -230,6 +235,16 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "bt_cover_inv")) {
     if (value < 0 || value > (1 << 20)) return mrk_fail(MRK_E_INVAL, "bt_cover_inv must be 0 (off) .. 2^20");
     c->bt_cover_inv = (int)value;
+    return MRK_OK;
+  }
+  if (!strcmp(key, "gen_lane_hits")) {
+    if (value < 16 || value > (1 << 20)) return mrk_fail(MRK_E_INVAL, "gen_lane_hits must be 16 .. 2^20");
+    c->gen_lane_hits = (int)value;
+    return MRK_OK;
+  }
+  if (!strcmp(key, "gen_spill_mb")) {
+    if (value < 1 || value > (64 << 10)) return mrk_fail(MRK_E_INVAL, "gen_spill_mb must be 1 .. 65536");
+    c->gen_spill_mb = (int)value;
     return MRK_OK;
   }
   if (!strcmp(key, "mq_max_chunks")) {
@@ -699,8 +714,9 @@ static void mrk_batch_destroy_impl(mrk_batch* b) {
   b->h_flags.release();
   b->h_decl.release();
   b->d_decl.release();
-  for (int i = 0; i < 2; ++i) b->d_mq_data[i].release(), b->d_mq_hdr[i].release();
+  for (int i = 0; i < 3; ++i) b->d_mq_data[i].release(), b->d_mq_hdr[i].release();
   b->d_mq_count.release();
+  b->d_gen_progs.release(), b->d_gen_lane.release(), b->d_gen_spill.release(), b->d_gen_used.release();
   if (b->retry) mrk_batch_destroy_impl(b->retry);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
@@ -723,7 +739,7 @@ static int mrk_batch_create_impl(mrk_ctx* ctx, uint32_t max_queries, mrk_batch**
       (rc = b->h_total.reserve(nq)) || (rc = b->d_queries.reserve(nq)) ||
       (rc = b->d_state.reserve(nq * (8 + 8 + 4 + 4 + 4 + (size_t)NBINS * 4))) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
       (rc = b->d_kq.reserve(nq)) || (rc = b->d_out_keys.reserve(nq * KCAP)) || (rc = b->d_out_cnt.reserve(nq)) ||
-      (rc = b->h_flags.reserve(nq)) || (rc = b->h_cand_n.reserve(nq)) || (rc = b->h_decl.reserve(nq)) || (rc = b->d_decl.reserve(nq)) || (rc = b->d_mq_count.reserve(2 * mrk::MQ_SHARDS))) {
+      (rc = b->h_flags.reserve(nq)) || (rc = b->h_cand_n.reserve(nq)) || (rc = b->h_decl.reserve(nq)) || (rc = b->d_decl.reserve(nq)) || (rc = b->d_mq_count.reserve(3 * mrk::MQ_SHARDS))) {
     mrk_batch_destroy_impl(b);
     return rc;
   }
@@ -753,12 +769,15 @@ static int mrk_batch_create_impl(mrk_ctx* ctx, uint32_t max_queries, mrk_batch**
 // keyword, whole-query PHRASE); `fat` = the queue whose consumer carries the word state machines
 static bool pass_queues_matches(const DevQuery& P, bool& fat) {
   const uint32_t rk = P.ranker;
+  if (P.tree_flags & mrk::TF_GEN) return fat = false, true; // (queue 2: see queue_of)
   const bool prox_ranker = (rk == MRK_RANK_PROXIMITY_BM25 || rk == MRK_RANK_PROXIMITY)
                                ? P.n_terms > 1
                                : (rk == MRK_RANK_WORDCOUNT || rk == MRK_RANK_MATCHANY || rk == MRK_RANK_FIELDMASK || rk == MRK_RANK_SPH04);
   fat = (P.tree_flags & mrk::TF_FAT) != 0;
   return prox_ranker || (P.tree_flags & mrk::TF_PHRASE) != 0;
 }
+
+static int queue_of(const DevQuery& P, bool fat) { return (P.tree_flags & mrk::TF_GEN) ? 2 : fat ? 1 : 0; }
 
 // upper bound of the docs a pass can match: its driver's docs; the common docs for the two-bitmap AND; any keyword's docs for
 // a tree evaluated on bitmap words
@@ -773,19 +792,36 @@ static uint64_t pass_max_matches(const DevQuery& P) {
 }
 
 // size the batch's match queues for `chunks[q]` chunks (0 = queue unused) and point the scan arguments at them
-static int bind_match_queues(mrk_batch* b, const uint64_t chunks[2], mrk::ScanArgs& sa) {
-  for (int i = 0; i < 2; ++i) {
+static int bind_match_queues(mrk_batch* b, const uint64_t chunks[3], mrk::ScanArgs& sa) {
+  for (int i = 0; i < 3; ++i) {
+    const int planes = i == 2 ? mrk::MQ_GEN_PLANES : mrk::MQ_PLANES;
     sa.mq[i] = mrk::MatchQueue{};
     sa.mq[i].count = b->d_mq_count.p + mrk::MQ_SHARDS * i;
     if (!chunks[i]) continue;
     // per shard: its share of the chunks + slack for the spread between shards (workgroups are dealt round-robin)
     const uint64_t per = chunks[i] / mrk::MQ_SHARDS + chunks[i] / (8 * mrk::MQ_SHARDS) + 64;
     int rc;
-    if ((rc = b->d_mq_data[i].reserve((size_t)per * mrk::MQ_SHARDS * mrk::MQ_PLANES * 64)) || (rc = b->d_mq_hdr[i].reserve((size_t)per * mrk::MQ_SHARDS))) return rc;
+    if ((rc = b->d_mq_data[i].reserve((size_t)per * mrk::MQ_SHARDS * planes * 64)) || (rc = b->d_mq_hdr[i].reserve((size_t)per * mrk::MQ_SHARDS))) return rc;
     sa.mq[i].data = b->d_mq_data[i].p;
     sa.mq[i].hdr = b->d_mq_hdr[i].p;
     sa.mq[i].cap = (uint32_t)per;
   }
+  return MRK_OK;
+}
+
+// the generic evaluator's memory: allocated the first time a batch holds such a query, kept with the batch
+static int bind_gen(mrk_batch* b, mrk_batch* owner_of_progs, mrk::ScanArgs& sa, hipStream_t st) {
+  const uint32_t n_lanes = (uint32_t)mrk::GEN_GRID * mrk::WG, lane_hits = (uint32_t)b->ctx->gen_lane_hits;
+  const size_t spill = (size_t)b->ctx->gen_spill_mb * (1u << 20) / sizeof(mrk::GenHit);
+  int rc;
+  if ((rc = b->d_gen_lane.reserve((size_t)n_lanes * lane_hits)) || (rc = b->d_gen_spill.reserve(spill)) || (rc = b->d_gen_used.reserve(1))) return rc;
+  HIP_TRY(hipMemsetAsync(b->d_gen_used.p, 0, sizeof(unsigned long long), st));
+  sa.gen.progs = owner_of_progs->d_gen_progs.p;
+  sa.gen.lane_arena = b->d_gen_lane.p;
+  sa.gen.lane_hits = lane_hits, sa.gen.n_lanes = n_lanes;
+  sa.gen.spill = b->d_gen_spill.p;
+  sa.gen.spill_cap = spill;
+  sa.gen.spill_used = b->d_gen_used.p;
   return MRK_OK;
 }
 
@@ -816,16 +852,18 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   if (b->ctx->path == 2 && !seg->has_packed) return mrk_fail(MRK_E_UNSUPPORTED, "path=packed but the segment has no packed doclists");
   const bool use_packed = seg->has_packed && b->ctx->path != 1;
   std::vector<DevQuery> extra; // passes beyond the first of tree queries; pass index = n + position
+  b->gen_progs.clear();
   for (uint32_t i = 0; i < n; ++i) {
-    const size_t extra0 = extra.size(), items0 = items.size(), items_bm0 = items_bm.size();
+    const size_t extra0 = extra.size(), items0 = items.size(), items_bm0 = items_bm.size(), gen0 = b->gen_progs.size();
     int rc = plan_query(seg, queries[i], b->ctx->item_bytes, use_packed, b->h_queries.p[i], extra, n, items, items_bm, i, algo_bytes,
-                        dev_bytes, cand_total, any_prox, any_tree);
+                        dev_bytes, cand_total, any_prox, any_tree, b->gen_progs);
     b->status[i] = rc;
     if (rc == MRK_E_INVAL) return rc;
     if (rc != MRK_OK) { // unsupported: reported per query, runs no device work
       items.resize(items0);
       items_bm.resize(items_bm0);
       extra.resize(extra0);
+      b->gen_progs.resize(gen0);
       b->h_queries.p[i].n_items = 0;
       b->h_queries.p[i].n_terms = 0;
     }
@@ -840,7 +878,7 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   // window-range work items (two-bitmap AND kernel, then the window-driven tree kernel) ride behind the block work
   // items; each kind's whole-range entries are cut once the batch's total is known (a wave's fixed costs -- tables, final
   // publish, atomics on the query's counters -- want long runs of windows)
-  size_t n_items_kind[2] = {0, 0};
+  size_t n_items_kind[3] = {0, 0, 0};
   for (uint32_t kind = 0; kind < 2; ++kind) {
     uint64_t total_win = 0;
     for (const DevItem& it : items_bm)
@@ -860,21 +898,23 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
         }
     n_items_kind[kind] = items.size() - before;
   }
+  for (const DevItem& it : items_bm) // the generic evaluator's candidates: block ranges, cut by the planner
+    if (it.kind == 2) items.push_back(it), ++n_items_kind[2];
   // match queues: a pass hands over at most one entry per doc it can match, plus one partial chunk per wave of its items
-  uint64_t mq_chunks[2] = {0, 0};
+  uint64_t mq_chunks[3] = {0, 0, 0};
   if (use_packed && any_prox) {
     bool bt_feeds = false;
     auto account = [&](const DevQuery& P) {
       bool fat = false;
       if (!P.n_items || !pass_queues_matches(P, fat)) return;
       const bool bt = (P.tree_flags & mrk::TF_BTREE) != 0;
-      mq_chunks[fat ? 1 : 0] += pass_max_matches(P) / 64 + (bt ? 0 : 4ull * (mrk::MQ_BATCH + 1) * P.n_items) + 1;
+      mq_chunks[queue_of(P, fat)] += pass_max_matches(P) / 64 + (bt ? 0 : 4ull * (mrk::MQ_BATCH + 1) * P.n_items) + 1;
       bt_feeds = bt_feeds || bt;
     };
     for (uint32_t i = 0; i < n; ++i) account(b->h_queries.p[i]);
     for (const DevQuery& P : extra) account(P);
     if (bt_feeds) mq_chunks[0] += 4ull * (mrk::MQ_BATCH + 1) * n_items_kind[1]; // per wave one partial chunk + the unused rest of a reservation (its work items were only cut just now)
-    for (int i = 0; i < 2; ++i) mq_chunks[i] = std::min<uint64_t>(mq_chunks[i], (uint64_t)b->ctx->mq_max_chunks);
+    for (int i = 0; i < 3; ++i) mq_chunks[i] = std::min<uint64_t>(mq_chunks[i], (uint64_t)b->ctx->mq_max_chunks);
   }
   const size_t n_items_bm = items.size() - n_items_pk;
   const size_t n_items = items.size();
@@ -926,7 +966,12 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   sa.q_tau_bin = b->d_q_tau_bin.p;
   sa.cand = b->d_cand.p;
   if ((rc = bind_match_queues(b, mq_chunks, sa))) return rc;
-  if (mq_chunks[0] || mq_chunks[1]) HIP_TRY(hipMemsetAsync(b->d_mq_count.p, 0, 2 * mrk::MQ_SHARDS * 4, st));
+  if (mq_chunks[0] || mq_chunks[1] || mq_chunks[2]) HIP_TRY(hipMemsetAsync(b->d_mq_count.p, 0, 3 * mrk::MQ_SHARDS * 4, st));
+  if (!b->gen_progs.empty()) {
+    if ((rc = b->d_gen_progs.reserve(b->gen_progs.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(b->d_gen_progs.p, b->gen_progs.data(), b->gen_progs.size() * sizeof(mrk::GenProg), hipMemcpyHostToDevice, st)); // (pageable: the vector lives until the next submit)
+    if ((rc = bind_gen(b, b, sa, st))) return rc;
+  }
   lap("h2d+memset");
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
   if (use_packed) {
@@ -937,9 +982,16 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
       sb.n_items = (uint32_t)n_items_kind[1];
       launch_scan_bt(sb, st);
     }
+    if (n_items_kind[2]) { // candidates of the generic evaluator
+      ScanArgs sg = sa;
+      sg.items = b->d_items.p + n_items_pk + n_items_kind[0] + n_items_kind[1];
+      sg.n_items = (uint32_t)n_items_kind[2];
+      launch_scan_pk(sg, max_terms, true, true, true, st, true);
+    }
     // the queued matches of hit-ranked queries: hit pass + state rankers (mrk_rank.hip), behind the scans on the same stream
     if (mq_chunks[0]) launch_rank(sa, 0, st);
     if (mq_chunks[1]) launch_rank(sa, 1, st);
+    if (mq_chunks[2]) launch_rank(sa, 2, st);
     if (n_items_kind[0]) {
       ScanArgs sb = sa;
       sb.items = b->d_items.p + n_items_pk;
@@ -1046,7 +1098,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   for (const DevQuery& p : passes) cap += pass_max_matches(p);
   cap = std::max<uint64_t>(cap, 1);
   if (cap > 0xFFFFFFF0ull) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: candidate list overflowed", qi);
-  std::vector<DevItem> items_pk, items_bm, items_bt;
+  std::vector<DevItem> items_pk, items_bm, items_bt, items_gen;
   for (size_t p = 0; p < passes.size(); ++p) {
     DevQuery& P = passes[p];
     P.out_q = 0;
@@ -1059,13 +1111,14 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
       it.query = (uint32_t)p;
       it.blk_begin = x;
       it.blk_end = std::min(n, x + step);
-      it.kind = bt ? 1u : 0u;
-      (bm ? items_bm : bt ? items_bt : items_pk).push_back(it);
+      it.kind = bt ? 1u : (P.tree_flags & TF_GEN) ? 2u : 0u;
+      (bm ? items_bm : bt ? items_bt : (P.tree_flags & TF_GEN) ? items_gen : items_pk).push_back(it);
     }
   }
-  const size_t n_pk = items_pk.size(), n_bm = items_bm.size(), n_bt = items_bt.size();
+  const size_t n_pk = items_pk.size(), n_bm = items_bm.size(), n_bt = items_bt.size(), n_gen = items_gen.size();
   items_pk.insert(items_pk.end(), items_bm.begin(), items_bm.end());
   items_pk.insert(items_pk.end(), items_bt.begin(), items_bt.end());
+  items_pk.insert(items_pk.end(), items_gen.begin(), items_gen.end());
   const size_t n_items = items_pk.size();
   int rc;
   if ((rc = r->h_queries.reserve(passes.size())) || (rc = r->d_queries.reserve(passes.size())) || (rc = r->h_items.reserve(n_items + 1)) ||
@@ -1089,16 +1142,23 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   sa.q_tau_bin = r->d_q_tau_bin.p;
   sa.cand = r->d_cand.p;
   {
-    uint64_t chunks[2] = {0, 0};
+    uint64_t chunks[3] = {0, 0, 0};
     for (size_t p = 0; p < passes.size(); ++p) {
       bool fat = false;
-      if (pass_queues_matches(passes[p], fat)) chunks[fat ? 1 : 0] += pass_max_matches(passes[p]) / 64 + 4ull * (mrk::MQ_BATCH + 1) * n_items + 1;
+      if (pass_queues_matches(passes[p], fat)) chunks[queue_of(passes[p], fat)] += pass_max_matches(passes[p]) / 64 + 4ull * (mrk::MQ_BATCH + 1) * n_items + 1;
     }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
       if (chunks[i] > (1ull << 25)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: match queue for the rerun too large", qi);
     if ((rc = bind_match_queues(r, chunks, sa))) return rc;
-    if (chunks[0] || chunks[1]) HIP_TRY(hipMemsetAsync(r->d_mq_count.p, 0, 2 * mrk::MQ_SHARDS * 4, st));
+    if (chunks[0] || chunks[1] || chunks[2]) HIP_TRY(hipMemsetAsync(r->d_mq_count.p, 0, 3 * mrk::MQ_SHARDS * 4, st));
+    if (n_gen && (rc = bind_gen(r, b, sa, st))) return rc; // (the programs are the submit's, still on the device)
     launch_scan_pk(sa, b->last_max_terms, b->last_prox, b->last_tree, b->last_ext, st);
+    if (n_gen) {
+      ScanArgs sg = sa;
+      sg.items = r->d_items.p + n_pk + n_bm + n_bt;
+      sg.n_items = (uint32_t)n_gen;
+      launch_scan_pk(sg, b->last_max_terms, true, true, true, st, true);
+    }
     if (n_bt) {
       ScanArgs sb = sa;
       sb.items = r->d_items.p + n_pk + n_bm;
@@ -1107,6 +1167,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
     }
     if (chunks[0]) launch_rank(sa, 0, st);
     if (chunks[1]) launch_rank(sa, 1, st);
+    if (chunks[2]) launch_rank(sa, 2, st);
   }
   if (n_bm) {
     ScanArgs sb = sa;
@@ -1136,6 +1197,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   HIP_TRY(hipMemcpyAsync(b->d_out_keys.p + (size_t)qi * KCAP, r->d_out_keys.p, (size_t)KCAP * 8, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemsetAsync(b->d_q_flags.p + qi, 0, 4, st)); // the device-side row is good again
   HIP_TRY(hipStreamSynchronize(st));
+  if (flags & QF_ARENA) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: the generic evaluator ran out of hit-list memory (ctx tunable gen_spill_mb)", qi);
   if (flags & (QF_OVERFLOW | QF_FSM)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: candidate list overflowed again on the rerun", qi);
   b->decoded = false;
   return MRK_OK;
@@ -1159,6 +1221,8 @@ static int mrk_batch_wait_impl(mrk_batch* b) {
       // never hand back a silently truncated result
       if (b->h_flags.p[i] & QF_FSM)
         b->status[i] = mrk_fail(MRK_E_UNSUPPORTED, "query %u: a doc held more live phrase states than the device path keeps", i);
+      else if (b->h_flags.p[i] & QF_ARENA)
+        b->status[i] = mrk_fail(MRK_E_UNSUPPORTED, "query %u: the generic evaluator ran out of hit-list memory (ctx tunable gen_spill_mb)", i);
       else if (b->h_flags.p[i] & QF_OVERFLOW) {
         // more matches tied at the pruning threshold than the candidate list holds (e.g. millions of docs with the
         // very same weight): run the query again, alone, with room for every doc its drivers can deliver

@@ -32,6 +32,8 @@ struct mrk_ctx {
   int attr_nibbles = 0;           // also build the one-byte tf/field plane the bitmap kernel can gather from (<= 4 fields)
   int bm_target_items = 6144;     // bitmap kernel: work items per launch the window ranges are cut into
   int bt_cover_inv = 32;          // trees whose candidate cover holds >= 1/bt_cover_inv of the docs run on bitmap words (0 = never)
+  int gen_lane_hits = 256;        // generic evaluator: hits (16 B) of per-lane list memory, GEN_GRID * 256 lanes
+  int gen_spill_mb = 1024;        // ... and the shared area for lists beyond a lane's slice (exhausted: the query fails loudly)
   int mq_max_chunks = 1 << 20;    // cap of a batch's match queue, in 64-entry chunks of 1792 B (a fuller queue flags its queries: rerun alone)
 };
 
@@ -91,6 +93,8 @@ namespace mrk {
 // `extra` and get pass indices n_queries + position; bitmap-kernel work goes to items_bm as one whole-range entry.
 int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
                std::vector<DevQuery>& extra, uint32_t n_queries, std::vector<DevItem>& items, std::vector<DevItem>& items_bm,
-               uint32_t qi, uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out);
+               uint32_t qi, uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out,
+               std::vector<mrk::GenProg>& gen_progs); // gen_progs: programs of the generic evaluator (DevQuery::gen_prog indexes it); their
+                                                      // work items go to items_bm with kind 2, already cut
 
 } // namespace mrk

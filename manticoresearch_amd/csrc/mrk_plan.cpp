@@ -4,6 +4,7 @@
 #include "mrk_host_int.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -83,6 +84,7 @@ struct PlanTree {
   int nn_a = 0, nn_b = 0, nn_dist = 0;
   int q_kw0 = 0, q_n = 0, q_thr = 0;
   IntVec atoms;                 // its words' query positions, phrase order
+  bool gen = false;             // planned for the generic per-doc evaluator: nodes = the doc-level superset tree, the real tree is a GenProg
 };
 
 // Mirrors ExtNode_i::Create (searchnode.cpp:1599-1811) for the operators the device path knows:
@@ -321,6 +323,265 @@ static int build_tree(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pl
   return cur;
 }
 
+
+// ---- the generic path: the reference's evaluation tree as a GenProg (mrk_keval.h evaluates it per candidate doc), plus
+// the doc-level superset tree the scan kernel runs to find the candidates: every PHRASE / PROXIMITY / NEAR / BEFORE node as
+// the AND of its operands, NOTNEAR / ANDNOT as their left side (MAYBE: the right side's keywords are still located).
+// Follows ExtNode_i::Create (searchnode.cpp:1599-1811) node for node; keywords enter T.kws in GetQwords traversal order.
+struct GenBuild {
+  mrk::GenProg prog;
+  int plan[mrk::GEN_MAX_NODES]; // the superset tree's node for each program node
+  int docs[mrk::GEN_MAX_NODES]; // GetDocsCount(): a plain keyword's docs, INT_MAX for everything else (searchnode.h:83)
+  int atom[mrk::GEN_MAX_NODES]; // GetAtomPos()
+  bool overflow = false;
+  GenBuild() { memset(&prog, 0, sizeof prog); }
+  int add(const mrk::GenNode& n, int plan_node, int ndocs, int natom) {
+    if (prog.n_nodes >= (uint32_t)mrk::GEN_MAX_NODES) {
+      overflow = true;
+      return 0;
+    }
+    const int i = (int)prog.n_nodes++;
+    prog.nodes[i] = n;
+    plan[i] = plan_node, docs[i] = ndocs, atom[i] = natom;
+    return i;
+  }
+};
+
+static int node_docs_key(const mrk_segment* seg, const mrk_node& t) { // what ExtNodeTF(Ext)_fn sorts operands by
+  if (t.op != MRK_OP_TERM || t.term_pos) return INT_MAX;
+  return (t.term_id >= 0 && (uint32_t)t.term_id < seg->terms.size()) ? (int)seg->terms[t.term_id].docs : 0;
+}
+
+static void sph_isort(IntVec& ord, const IntVec& key) { // sphSort's small-array path: equal keys end in reverse arrival order
+  for (int i = 1; i < (int)ord.size(); ++i)
+    for (int j = i; j > 0; --j) {
+      if (key[ord[j - 1]] < key[ord[j]]) break;
+      std::swap(ord[j], ord[j - 1]);
+    }
+}
+
+static int build_gen(const mrk_segment* seg, const mrk_query& q, int32_t ni, PlanTree& T, GenBuild& G, uint32_t qi, int depth, int& err) {
+  using namespace mrk;
+  if (ni < 0 || ni >= q.n_nodes || depth > 16) return err = mrk_fail(MRK_E_INVAL, "query %u: bad tree", qi), -1;
+  const mrk_node& n = q.nodes[ni];
+  auto pjoin = [&](uint32_t op, int l, int r) -> int {
+    PlanNode pn;
+    pn.op = op, pn.l = l, pn.r = r;
+    T.nodes.push_back(pn);
+    return (int)T.nodes.size() - 1;
+  };
+  // a keyword: its slot in T.kws + its PN_TERM node in the superset tree
+  auto keyword = [&](int32_t li, uint32_t mask_and, int& plan_node) -> int {
+    const mrk_node& t = q.nodes[li];
+    PlanKw k{};
+    k.term_id = t.term_id;
+    k.node = li;
+    k.docs = (t.term_id >= 0 && (uint32_t)t.term_id < seg->terms.size()) ? (int)seg->terms[t.term_id].docs : 0;
+    k.boost = t.boost;
+    k.queried32 = t.field_mask & mask_and;
+    k.atom_pos = t.atom_pos;
+    k.tp_kind = t.term_pos;
+    k.tp_max = t.field_max_pos;
+    T.kws.push_back(k);
+    PlanNode pn;
+    pn.op = PN_TERM;
+    pn.kw = (int)T.kws.size() - 1;
+    T.nodes.push_back(pn);
+    plan_node = (int)T.nodes.size() - 1;
+    return pn.kw;
+  };
+  auto term_node = [&](int32_t li, uint32_t mask_and) -> int {
+    int pl;
+    const int slot = keyword(li, mask_and, pl);
+    GenNode g{};
+    g.kind = GN_TERM;
+    g.kid[0] = (uint8_t)slot;
+    return G.add(g, pl, node_docs_key(seg, q.nodes[li]), q.nodes[li].atom_pos);
+  };
+  auto twofer = [&](uint32_t kind, uint32_t pop, int l, int r, int opt = 0) -> int {
+    GenNode g{};
+    g.kind = (uint8_t)kind, g.n_kids = 2, g.kid[0] = (uint8_t)l, g.kid[1] = (uint8_t)r, g.opt = opt;
+    return G.add(g, pjoin(pop, G.plan[l], G.plan[r]), INT_MAX, G.atom[l]);
+  };
+  // ExtNWay_T::ConstructNode (:3767-3802): the operands chained left-deep in ascending doc-count order, every hit relabelled
+  // with its operand's place in the query (1-based), the last ExtAnd_c emitting in reverse query-position order.  One
+  // operand at a time (operand, AND, operand, AND ...: the superset tree's program stays two values deep)
+  auto nway_step = [&](int& cur, int c, const IntVec& ord, int i) {
+    if (i == 0) {
+      cur = c;
+      return;
+    }
+    const int a = twofer(GN_AND, PN_AND, cur, c);
+    G.prog.nodes[a].npl = (uint16_t)(i == 1 ? ord[0] + 1 : 0), G.prog.nodes[a].npr = (uint16_t)(ord[i] + 1);
+    if (i + 1 == (int)ord.size()) G.prog.nodes[a].flags |= 1u;
+    cur = a;
+  };
+  if (n.op == MRK_OP_TERM) {
+    if (n.term_pos < 0 || n.term_pos > MRK_TERMPOS_LIMIT || (n.term_pos == MRK_TERMPOS_LIMIT && n.field_max_pos <= 0))
+      return err = mrk_fail(MRK_E_INVAL, "query %u: bad position modifier", qi), -1;
+    return term_node(ni, 0xFFFFFFFFu);
+  }
+  if (n.n_children < 1 || n.n_children > 16 || n.first_child < 0) return err = mrk_fail(MRK_E_INVAL, "query %u: bad child list", qi), -1;
+  IntVec kids(n.n_children);
+  bool all_terms = true, any_tp = false;
+  for (int i = 0; i < n.n_children; ++i) {
+    kids[i] = q.children[n.first_child + i];
+    if (kids[i] < 0 || kids[i] >= q.n_nodes) return err = mrk_fail(MRK_E_INVAL, "query %u: child index out of range", qi), -1;
+    all_terms &= q.nodes[kids[i]].op == MRK_OP_TERM;
+    any_tp |= q.nodes[kids[i]].op == MRK_OP_TERM && q.nodes[kids[i]].term_pos != 0;
+  }
+  IntVec ord(n.n_children), key(n.n_children);
+  for (int i = 0; i < n.n_children; ++i) ord[i] = i, key[i] = node_docs_key(seg, q.nodes[kids[i]]);
+  switch (n.op) {
+    case MRK_OP_PHRASE:
+    case MRK_OP_PROXIMITY: { // CreateMultiNode<ExtPhrase_c / ExtProximity_c> (:984-1041): plain keywords under the node's field limit
+      if (!all_terms || any_tp || n.n_children < 2 || n.n_children > MRK_MAX_AND_TERMS)
+        return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE of %d nodes (generic path: 2..%d plain keywords)", qi, n.n_children, MRK_MAX_AND_TERMS), -1;
+      if (n.op == MRK_OP_PROXIMITY && (n.opt <= 0 || n.opt > (1 << 20))) return err = mrk_fail(MRK_E_INVAL, "query %u: proximity distance %d", qi, n.opt), -1;
+      for (int i = 1; i < n.n_children; ++i)
+        if (q.nodes[kids[i]].atom_pos <= q.nodes[kids[i - 1]].atom_pos) return err = mrk_fail(MRK_E_INVAL, "query %u: phrase atom positions must ascend", qi), -1;
+      sph_isort(ord, key);
+      IntVec nodes_q(n.n_children);
+      int inner = -1;
+      for (int i = 0; i < n.n_children; ++i) { // (keywords enter in chain order)
+        nodes_q[ord[i]] = term_node(kids[ord[i]], n.field_mask);
+        nway_step(inner, nodes_q[ord[i]], ord, i);
+      }
+      GenNode g{};
+      g.kind = n.op == MRK_OP_PHRASE ? GN_PHRASE : GN_PROX;
+      g.n_kids = 1, g.kid[0] = (uint8_t)inner, g.n_words = (uint8_t)n.n_children, g.opt = n.opt;
+      for (int i = 0; i < n.n_children; ++i) g.aux[i] = G.prog.nodes[nodes_q[i]].kid[0];
+      return G.add(g, G.plan[inner], INT_MAX, G.atom[nodes_q[0]]);
+    }
+    case MRK_OP_NEAR: { // CreateMultiNode<ExtMultinear_c>: operands of any kind; two of them on the device (see mrk_keval.h)
+      if (n.n_children != 2)
+        return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: NEAR over %d operands (device path: two; the reference's folded hit of a longer chain "
+                              "carries a query position that depends on the docs evaluated before)", qi, n.n_children), -1;
+      if (n.opt <= 0 || n.opt > (1 << 20)) return err = mrk_fail(MRK_E_INVAL, "query %u: NEAR distance %d", qi, n.opt), -1;
+      for (int i = 0; i < 2; ++i) {
+        const int cop = q.nodes[kids[i]].op;
+        if (cop != MRK_OP_TERM && cop != MRK_OP_PHRASE && cop != MRK_OP_PROXIMITY && cop != MRK_OP_NEAR)
+          return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: NEAR over AND / OR groups (the reference's answer for them is not understood: parity unpinned)", qi), -1;
+      }
+      sph_isort(ord, key);
+      IntVec nodes_q(2);
+      int inner = -1;
+      for (int i = 0; i < 2; ++i) {
+        const int c = build_gen(seg, q, kids[ord[i]], T, G, qi, depth + 1, err);
+        if (c < 0) return -1;
+        nodes_q[ord[i]] = c;
+        nway_step(inner, c, ord, i);
+      }
+      GenNode g{};
+      g.kind = GN_NEAR, g.n_kids = 1, g.kid[0] = (uint8_t)inner, g.opt = n.opt;
+      return G.add(g, G.plan[inner], INT_MAX, G.atom[nodes_q[0]]);
+    }
+    case MRK_OP_QUORUM: { // :1638-1686
+      if (!all_terms || any_tp || n.n_children < 2) return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum over plain keywords only", qi), -1;
+      if (n.opt < 1) return err = mrk_fail(MRK_E_INVAL, "query %u: quorum threshold %d", qi, n.opt), -1;
+      if (n.opt != 1 && n.opt < n.n_children) { // a real ExtQuorum_c: keywords in query-position order
+        if (T.quorum || n.n_children > QUORUM_EVENTS || n.n_children > MRK_MAX_AND_TERMS)
+          return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum nodes on the device path: one per query, <= %d keywords", qi, QUORUM_EVENTS), -1;
+        for (int i = 0; i < n.n_children; ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return q.nodes[kids[a]].atom_pos < q.nodes[kids[b]].atom_pos; });
+        for (int i = 0; i < n.n_children; ++i)
+          for (int j = 0; j < i; ++j)
+            if (q.nodes[kids[i]].term_id >= 0 && q.nodes[kids[j]].term_id == q.nodes[kids[i]].term_id)
+              return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: quorum with a repeated keyword (m_bHasDupes) is not on the device path", qi), -1;
+        const uint32_t all = seg->n_fields >= 32 ? 0xFFFFFFFFu : (1u << seg->n_fields) - 1u;
+        GenNode g{};
+        g.kind = GN_QUORUM, g.n_kids = (uint8_t)n.n_children, g.opt = n.opt;
+        const size_t nodes0 = T.nodes.size();
+        T.q_kw0 = (int)T.kws.size();
+        for (int i = 0; i < n.n_children; ++i) {
+          int pl;
+          g.kid[i] = (uint8_t)keyword(kids[ord[i]], n.field_mask, pl);
+          if ((T.kws.back().queried32 & all) != all) // where a keyword's stream ends is only known for unrestricted keywords
+            return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: field-limited keywords in a quorum are not on the device path", qi), -1;
+        }
+        T.nodes.n = (int)nodes0; // the quorum node reads its keywords' presence bits itself
+        T.quorum = true;
+        T.q_n = n.n_children, T.q_thr = n.opt;
+        PlanNode pn;
+        pn.op = PN_QUORUM;
+        T.nodes.push_back(pn);
+        return G.add(g, (int)T.nodes.size() - 1, INT_MAX, q.nodes[kids[ord[0]]].atom_pos);
+      }
+      sph_isort(ord, key); // threshold 1: an ExtOr_c chain; threshold >= words: an ExtAnd_c chain; both over the words by doc count
+      int cur = term_node(kids[ord[0]], n.field_mask);
+      for (int i = 1; i < n.n_children; ++i) {
+        const int r = term_node(kids[ord[i]], n.field_mask);
+        cur = n.opt == 1 ? twofer(GN_OR, PN_OR, cur, r) : twofer(GN_AND, PN_AND, cur, r);
+      }
+      return cur;
+    }
+    case MRK_OP_BEFORE: { // CreateOrderNode (:1044-1073): children as they come
+      if (n.n_children < 2 || n.n_children > MRK_MAX_AND_TERMS) return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: BEFORE over %d nodes", qi, n.n_children), -1;
+      GenNode g{};
+      g.kind = GN_ORDER, g.n_kids = (uint8_t)n.n_children;
+      int pl = -1;
+      for (int i = 0; i < n.n_children; ++i) {
+        const int c = build_gen(seg, q, kids[i], T, G, qi, depth + 1, err);
+        if (c < 0) return -1;
+        g.kid[i] = (uint8_t)c;
+        pl = pl < 0 ? G.plan[c] : pjoin(PN_AND, pl, G.plan[c]);
+      }
+      return G.add(g, pl, INT_MAX, G.atom[g.kid[0]]);
+    }
+    case MRK_OP_AND: {
+      if (all_terms && n.n_children > 1 && any_tp) { // a position modifier rules the multi-and node out (:1724-1762): an ExtAnd_c chain by doc count
+        sph_isort(ord, key);
+        int cur = term_node(kids[ord[0]], 0xFFFFFFFFu);
+        for (int i = 1; i < n.n_children; ++i) cur = twofer(GN_AND, PN_AND, cur, term_node(kids[ord[i]], 0xFFFFFFFFu));
+        return cur;
+      }
+      if (all_terms && n.n_children > 1) { // CreateMultiAndNode (:1118-1138) + ExtMultiAnd_T ctor (:2772-2798)
+        if (n.n_children > MRK_MAX_AND_TERMS) return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d keywords (device path: <= %d)", qi, n.n_children, MRK_MAX_AND_TERMS), -1;
+        sph_isort(ord, key);
+        GenNode g{};
+        g.kind = GN_MULTIAND, g.n_kids = (uint8_t)n.n_children;
+        int pl = -1;
+        for (int i = 0; i < n.n_children; ++i) {
+          int p1;
+          g.kid[i] = (uint8_t)keyword(kids[ord[i]], 0xFFFFFFFFu, p1);
+          g.aux[i] = (uint8_t)ord[i];
+          if (q.nodes[kids[ord[i]]].field_mask != 0xFFFFFFFFu) g.flags |= 2u;
+          pl = pl < 0 ? p1 : pjoin(PN_AND, pl, p1);
+        }
+        return G.add(g, pl, INT_MAX, T.kws[g.kid[0]].atom_pos);
+      }
+      int cur = -1;
+      for (int i = 0; i < n.n_children; ++i) {
+        const int c = build_gen(seg, q, kids[i], T, G, qi, depth + 1, err);
+        if (c < 0) return -1;
+        cur = cur < 0 ? c : twofer(GN_AND, PN_AND, cur, c);
+      }
+      return cur;
+    }
+    case MRK_OP_OR:
+    case MRK_OP_MAYBE:
+    case MRK_OP_ANDNOT:
+    case MRK_OP_NOTNEAR: {
+      if (n.op == MRK_OP_NOTNEAR && (n.opt <= 0 || n.opt > (1 << 20))) return err = mrk_fail(MRK_E_INVAL, "query %u: NOTNEAR distance %d", qi, n.opt), -1;
+      int cur = -1;
+      for (int i = 0; i < n.n_children; ++i) {
+        const int c = build_gen(seg, q, kids[i], T, G, qi, depth + 1, err);
+        if (c < 0) return -1;
+        if (cur < 0)
+          cur = c;
+        else if (n.op == MRK_OP_OR)
+          cur = twofer(GN_OR, PN_OR, cur, c);
+        else if (n.op == MRK_OP_MAYBE)
+          cur = twofer(GN_MAYBE, PN_MAYBE, cur, c);
+        else // whether the right side holds the doc is only known after its hits were read: the left side carries the candidates
+          cur = twofer(n.op == MRK_OP_ANDNOT ? GN_ANDNOT : GN_NOTNEAR, PN_MAYBE, cur, c, n.opt);
+      }
+      return cur;
+    }
+    default: return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: operator %d not on the device path yet", qi, n.op), -1;
+  }
+}
+
 // keywords whose doc streams together contain every possible match of the subtree
 static void cover_of(const PlanTree& T, int ni, IntVec& out) {
   const PlanNode& n = T.nodes[ni];
@@ -389,7 +650,7 @@ static void fill_term(const mrk_segment* seg, const PlanKw& k, DevTerm& dt) {
 int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
                       std::vector<DevQuery>& extra, uint32_t n_queries, std::vector<DevItem>& items,
                       std::vector<DevItem>& items_bm, uint32_t qi,
-                      uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out) {
+                      uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out, std::vector<mrk::GenProg>& gen_progs) {
   memset(&dq, 0, sizeof dq);
   dq.item_first = (uint32_t)items.size();
   dq.out_q = qi;
@@ -398,90 +659,127 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: max_matches %d outside 1..%d", qi, q.max_matches, MRK_MAX_K);
   if (q.cutoff > 0) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: cutoff is order-dependent; not on the device path", qi);
 
+  // The specialised paths first; a shape they decline goes to the generic per-doc evaluator (mrk_keval.h) when the segment
+  // has what it reads (packed doclists + hit references), else the decline stands.
   PlanTree T;
-  int tree_err = MRK_OK;
-  const int root = build_tree(seg, q, q.root, T, qi, 0, true, tree_err);
-  if (root < 0) return tree_err;
-  if (T.kws.overflow || T.nodes.overflow || T.atoms.overflow)
-    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
-  const int n = (int)T.kws.size();
-  if (n > MRK_MAX_AND_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d keywords (device path: <= %d)", qi, n, MRK_MAX_AND_TERMS);
-  if (T.nodes.size() > 16) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
-  const bool single_word = T.nodes.size() == 1 && T.nodes[0].op == PN_TERM; // XQQuery_t::m_bSingleWord
-  bool pure_and = !T.force_tree; // single keyword or one ExtMultiAnd_T: the kernel's N-way AND loop, no program
-  for (const PlanNode& pn : T.nodes) pure_and &= pn.op == PN_TERM || pn.op == PN_AND;
-  if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE || q.nodes[q.root].op == MRK_OP_PROXIMITY || q.nodes[q.root].op == MRK_OP_NEAR))
-    for (int i = 0; i < q.nodes[q.root].n_children; ++i) pure_and &= q.nodes[q.children[q.nodes[q.root].first_child + i]].op == MRK_OP_TERM;
-  if (!pure_and && !use_packed) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: boolean trees run on the packed path only", qi);
-  if (!pure_and) { // the device evaluates the program on a TREE_STACK-deep register stack
-    int sp = 0, deep = 0;
-    for (const PlanNode& pn : T.nodes) {
-      sp += (pn.op == PN_TERM || pn.op == PN_QUORUM) ? 1 : (pn.op == PN_PHRASEFIX || pn.op == PN_ORDERFIX) ? 0 : -1;
-      deep = std::max(deep, sp);
+  GenBuild G;
+  int root = -1;
+  bool single_word = false, pure_and = false, prox = false;
+  uint32_t ranker = 0;
+  int n = 0;
+  auto shape = [&](bool gen) -> int {
+    T = PlanTree();
+    int tree_err = MRK_OK;
+    if (gen) {
+      G = GenBuild();
+      root = build_gen(seg, q, q.root, T, G, qi, 0, tree_err);
+      if (root >= 0 && G.overflow) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
+      if (root >= 0) {
+        T.gen = T.force_tree = true;
+        root = G.plan[root];
+      }
+    } else
+      root = build_tree(seg, q, q.root, T, qi, 0, true, tree_err);
+    if (root < 0) return tree_err;
+    if (T.kws.overflow || T.nodes.overflow || T.atoms.overflow)
+      return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
+    n = (int)T.kws.size();
+    if (n > MRK_MAX_AND_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d keywords (device path: <= %d)", qi, n, MRK_MAX_AND_TERMS);
+    if (T.nodes.size() > 16) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
+    single_word = T.nodes.size() == 1 && T.nodes[0].op == PN_TERM; // XQQuery_t::m_bSingleWord
+    pure_and = !T.force_tree; // single keyword or one ExtMultiAnd_T: the kernel's N-way AND loop, no program
+    for (const PlanNode& pn : T.nodes) pure_and &= pn.op == PN_TERM || pn.op == PN_AND;
+    if (pure_and && (q.nodes[q.root].op == MRK_OP_AND || q.nodes[q.root].op == MRK_OP_PHRASE || q.nodes[q.root].op == MRK_OP_PROXIMITY || q.nodes[q.root].op == MRK_OP_NEAR))
+      for (int i = 0; i < q.nodes[q.root].n_children; ++i) pure_and &= q.nodes[q.children[q.nodes[q.root].first_child + i]].op == MRK_OP_TERM;
+    if (!pure_and && !use_packed) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: boolean trees run on the packed path only", qi);
+    if (!pure_and) { // the device evaluates the program on a TREE_STACK-deep register stack
+      int sp = 0, deep = 0;
+      for (const PlanNode& pn : T.nodes) {
+        sp += (pn.op == PN_TERM || pn.op == PN_QUORUM) ? 1 : (pn.op == PN_PHRASEFIX || pn.op == PN_ORDERFIX) ? 0 : -1;
+        deep = std::max(deep, sp);
+      }
+      if (deep > TREE_STACK) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree nests deeper than the device path evaluates", qi);
     }
-    if (deep > TREE_STACK) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree nests deeper than the device path evaluates", qi);
-  }
 
-  uint32_t ranker;
-  bool prox = false;       // a state ranker reads the hit streams
-  if (T.quorum && !T.quorum_root && q.ranker != MRK_RANK_NONE && q.ranker != MRK_RANK_BM25)
-    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: a quorum below another operator with a hit ranker is not on the device path", qi);
-  if (T.ph_leaf && n > MAX_PROX_TERMS)
-    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE in a tree of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
-  if (T.notnear) { // decided over the two keywords' hits: the hit-reading kernel, <= 4 hit streams
-    if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR runs on the packed path only", qi);
-    if (n > MAX_PROX_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR in a query of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
-    if (T.termpos || T.quorum) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR next to position modifiers / a quorum node", qi);
-    if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
-  }
-  if (T.termpos) { // whether a keyword holds a doc is decided over its hits: the hit-reading kernel, <= 4 hit streams
-    if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: position modifiers run on the packed path only", qi);
-    if (n > MAX_PROX_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: position modifiers in a query of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
-    if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
-    for (const PlanKw& k : T.kws)
-      if (k.tp_kind < 0 || k.tp_kind > MRK_TERMPOS_LIMIT || (k.tp_kind == MRK_TERMPOS_LIMIT && k.tp_max <= 0))
-        return mrk_fail(MRK_E_INVAL, "query %u: bad position modifier", qi);
-  }
-  if (T.phrase || T.ph_leaf) {
-    if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE runs on the packed path only", qi);
-    if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
-  }
-  switch (q.ranker) {
-    case MRK_RANK_NONE: ranker = MRK_RANK_NONE; break;
-    case MRK_RANK_BM25: ranker = MRK_RANK_BM25; break;
-    case MRK_RANK_PROXIMITY_BM25:
-    case MRK_RANK_PROXIMITY:
-      // a single keyword is ranked by ExtRanker_WeightSum_c (sphinxsearch.cpp:4195-4196, 4216-4217)
-      if (single_word) {
-        ranker = q.ranker == MRK_RANK_PROXIMITY_BM25 ? MRK_RANK_BM25 : MRK_RANK_PROXIMITY;
-        if (ranker == MRK_RANK_PROXIMITY && !use_packed)
-          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker=proximity runs on the packed path only", qi);
-      } else {
+    prox = false; // a state ranker reads the hit streams
+    if (gen && single_word) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: a single keyword is not a case for the generic evaluator", qi);
+    if (gen) {
+      if (!use_packed || !seg->dev.pk_hit || seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: the generic evaluator runs on the packed path, < 2^31 docs per segment", qi);
+    } else if (T.quorum && !T.quorum_root && q.ranker != MRK_RANK_NONE && q.ranker != MRK_RANK_BM25)
+      return mrk_fail(MRK_E_UNSUPPORTED, "query %u: a quorum below another operator with a hit ranker is not on the device path", qi);
+    if (T.ph_leaf && n > MAX_PROX_TERMS)
+      return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE in a tree of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+    if (T.notnear) { // decided over the two keywords' hits: the hit-reading kernel, <= 4 hit streams
+      if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR runs on the packed path only", qi);
+      if (n > MAX_PROX_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR in a query of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+      if (T.termpos || T.quorum) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NOTNEAR next to position modifiers / a quorum node", qi);
+      if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+    }
+    if (T.termpos) { // whether a keyword holds a doc is decided over its hits: the hit-reading kernel, <= 4 hit streams
+      if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: position modifiers run on the packed path only", qi);
+      if (n > MAX_PROX_TERMS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: position modifiers in a query of %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+      if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+      for (const PlanKw& k : T.kws)
+        if (k.tp_kind < 0 || k.tp_kind > MRK_TERMPOS_LIMIT || (k.tp_kind == MRK_TERMPOS_LIMIT && k.tp_max <= 0))
+          return mrk_fail(MRK_E_INVAL, "query %u: bad position modifier", qi);
+    }
+    if (T.phrase || T.ph_leaf) {
+      if (!use_packed || !seg->dev.pk_hit) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: PHRASE runs on the packed path only", qi);
+      if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+    }
+    switch (q.ranker) {
+      case MRK_RANK_NONE: ranker = MRK_RANK_NONE; break;
+      case MRK_RANK_BM25: ranker = MRK_RANK_BM25; break;
+      case MRK_RANK_PROXIMITY_BM25:
+      case MRK_RANK_PROXIMITY:
+        // a single keyword is ranked by ExtRanker_WeightSum_c (sphinxsearch.cpp:4195-4196, 4216-4217)
+        if (single_word) {
+          ranker = q.ranker == MRK_RANK_PROXIMITY_BM25 ? MRK_RANK_BM25 : MRK_RANK_PROXIMITY;
+          if (ranker == MRK_RANK_PROXIMITY && !use_packed)
+            return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker=proximity runs on the packed path only", qi);
+        } else {
+          if (!use_packed || !seg->dev.pk_hit)
+            return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity rankers run on the packed path only", qi);
+          if (n > MAX_PROX_TERMS && !gen)
+            return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity over %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+          if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity path needs < 2^31 docs per segment", qi);
+          if (T.multiand3_inner && !gen) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: 3-keyword AND below another operator with a hit ranker", qi);
+          ranker = (uint32_t)q.ranker;
+          prox = true;
+        }
+        break;
+      case MRK_RANK_WORDCOUNT:
+      case MRK_RANK_MATCHANY:
+      case MRK_RANK_FIELDMASK:
+      case MRK_RANK_SPH04:
+        // always ExtRanker_State_T over the hit stream, single keyword or not (sphinxsearch.cpp:4214-4236)
         if (!use_packed || !seg->dev.pk_hit)
-          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity rankers run on the packed path only", qi);
-        if (n > MAX_PROX_TERMS)
-          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity over %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
-        if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: proximity path needs < 2^31 docs per segment", qi);
-        if (T.multiand3_inner) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: 3-keyword AND below another operator with a hit ranker", qi);
+          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit rankers run on the packed path only", qi);
+        if (n > MAX_PROX_TERMS && !gen)
+          return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit ranker over %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
+        if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
+        if (T.multiand3_inner && !gen) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: 3-keyword AND below another operator with a hit ranker", qi);
         ranker = (uint32_t)q.ranker;
         prox = true;
+        break;
+      default: return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker %d not on the device path", qi, q.ranker);
+    }
+
+    return MRK_OK;
+  };
+  {
+    int rc = shape(false);
+    if (rc == MRK_E_UNSUPPORTED && use_packed && seg->dev.pk_hit) {
+      char fast_msg[256];
+      snprintf(fast_msg, sizeof fast_msg, "%s", mrk_last_error());
+      rc = shape(true);
+      if (rc == MRK_E_UNSUPPORTED) { // both declined: say why, the specialised path's reason first
+        char gen_msg[256];
+        snprintf(gen_msg, sizeof gen_msg, "%s", mrk_last_error());
+        return mrk_fail(MRK_E_UNSUPPORTED, "%s; generic evaluator: %s", fast_msg, gen_msg);
       }
-      break;
-    case MRK_RANK_WORDCOUNT:
-    case MRK_RANK_MATCHANY:
-    case MRK_RANK_FIELDMASK:
-    case MRK_RANK_SPH04:
-      // always ExtRanker_State_T over the hit stream, single keyword or not (sphinxsearch.cpp:4214-4236)
-      if (!use_packed || !seg->dev.pk_hit)
-        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit rankers run on the packed path only", qi);
-      if (n > MAX_PROX_TERMS)
-        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit ranker over %d keywords (device path: <= %d)", qi, n, MAX_PROX_TERMS);
-      if (seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: hit path needs < 2^31 docs per segment", qi);
-      if (T.multiand3_inner) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: 3-keyword AND below another operator with a hit ranker", qi);
-      ranker = (uint32_t)q.ranker;
-      prox = true;
-      break;
-    default: return mrk_fail(MRK_E_UNSUPPORTED, "query %u: ranker %d not on the device path", qi, q.ranker);
+    }
+    if (rc != MRK_OK) return rc;
   }
 
   // attribute filters (EarlyReject): resolved locators over the segment's .spa rows
@@ -605,7 +903,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       // 32 hits per keyword span the bins, more clamp); MATCHANY bits + (LCS-1) * K, K = sum(w) * words;
       // FIELDMASK the mask itself.  Bounds only shape the pruning bins -- values outside clamp to the edge bins.
       rmin = rmax = 0;
-      int64_t top = (T.phrase || T.ph_leaf) ? 2 * n : n;
+      int64_t top = (T.phrase || T.ph_leaf || T.gen) ? 2 * n : n;
       if (ranker == MRK_RANK_SPH04) top = 4 * top + 3;
       if (ranker == MRK_RANK_WORDCOUNT) top = 32 * n;
       if (ranker == MRK_RANK_MATCHANY) {
@@ -658,7 +956,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   }
   algo_bytes += bytes;
   dev_bytes += use_packed ? pbytes : bytes;
-  prox_out = prox_out || prox || T.phrase || T.ph_leaf || T.termpos || T.notnear;
+  prox_out = prox_out || prox || T.phrase || T.ph_leaf || T.termpos || T.notnear || T.gen; // (every generic-path candidate goes through the queue)
   tree_out = tree_out || !pure_and;
 
   // two dense keywords: the bitmap kernel (mrk_scan_bm.hip) walks 2048-rowid windows instead of blocks
@@ -688,7 +986,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   // is then "the keyword holds the doc"); sparse keywords are fine, their window words are assembled from a block cursor.
   {
     const uint32_t all_fields = seg->n_fields >= 32 ? 0xFFFFFFFFu : (1u << seg->n_fields) - 1u;
-    bool ok = use_packed && seg->dev.bm && seg->ctx->bitmap_inv > 0 && seg->ctx->bt_cover_inv > 0 && !T.phrase && !T.ph_leaf && !T.quorum && !T.order &&
+    bool ok = use_packed && seg->dev.bm && seg->ctx->bitmap_inv > 0 && seg->ctx->bt_cover_inv > 0 && !T.gen && !T.phrase && !T.ph_leaf && !T.quorum && !T.order &&
               !T.termpos && !T.notnear && q.n_filters == 0 && n <= MAX_PROX_TERMS && seg->total_docs < (1ull << 32) && T.nodes.size() <= 16;
     uint64_t cover_docs = 0;
     for (int k : cover) cover_docs += (uint64_t)T.kws[k].docs;
@@ -742,6 +1040,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       pass_index = n_queries + (uint32_t)extra.size() - 1;
       P->item_first = (uint32_t)items.size();
     }
+    if (T.gen) P->item_first = (uint32_t)items_bm.size(), P->n_items = 0;
     // keyword order of this pass: driver, then required keywords by ascending docs, then the rest
     IntVec order;
     const int drv = cover[p];
@@ -763,7 +1062,20 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     P->n_terms = (uint32_t)n;
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
     P->req_mask = P->excl_mask = 0;
-    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0) | (T.order ? TF_ORDER : 0) | (T.notnear ? TF_NOTNEAR : 0);
+    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0) | (T.order ? TF_ORDER : 0) | (T.notnear ? TF_NOTNEAR : 0) | (T.gen ? TF_GEN : 0);
+    if (T.gen) { // the evaluator's program, keyword slots as this pass orders them
+      GenProg gp = G.prog;
+      for (uint32_t i = 0; i < gp.n_nodes; ++i) {
+        GenNode& g = gp.nodes[i];
+        if (g.kind == GN_TERM) g.kid[0] = (uint8_t)slot[g.kid[0]];
+        if (g.kind == GN_MULTIAND || g.kind == GN_QUORUM)
+          for (int k = 0; k < g.n_kids; ++k) g.kid[k] = (uint8_t)slot[g.kid[k]];
+        if (g.kind == GN_PHRASE || g.kind == GN_PROX)
+          for (int k = 0; k < g.n_words; ++k) g.aux[k] = (uint8_t)slot[g.aux[k]];
+      }
+      P->gen_prog = (uint32_t)gen_progs.size();
+      gen_progs.push_back(gp);
+    }
     P->nn_a = T.notnear ? (uint32_t)slot[T.nn_a] : 0u, P->nn_b = T.notnear ? (uint32_t)slot[T.nn_b] : 0u, P->nn_dist = (uint32_t)T.nn_dist;
     P->px_dist = (uint32_t)T.px_dist;
     P->qr_mask = P->qr_thr = P->qr_n = 0;
@@ -823,10 +1135,15 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
         it.query = pass_index;
         it.blk_begin = (uint32_t)b;
         it.blk_end = (uint32_t)std::min<uint64_t>(nb0, b + bpi);
-        items.push_back(it);
+        if (T.gen) { // its own launch (the scan instance that hands over a reference per keyword), behind the block items
+          it.kind = 2;
+          items_bm.push_back(it);
+          ++P->n_items;
+        } else
+          items.push_back(it);
       }
     }
-    P->n_items = (uint32_t)items.size() - P->item_first;
+    if (!T.gen) P->n_items = (uint32_t)items.size() - P->item_first;
   }
   return MRK_OK;
 }

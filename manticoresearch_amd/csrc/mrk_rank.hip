@@ -9,6 +9,7 @@
 // (no PHRASE / BEFORE node, no position modifier) runs the lean hit_rank_plain.
 #include "mrk_khits.h"
 #include "mrk_kprune.h"
+#include "mrk_keval.h"
 
 namespace mrk {
 
@@ -26,11 +27,14 @@ struct __align__(16) RkSmem {
   uint32_t pre[MQ_SHARDS + 1]; // chunks in the shards before shard s (filled prefixes laid end to end)
 };
 
-template <bool FAT>
+// MODE 0: lean (hit_rank_plain / hit_rank_prox), 1: FAT (hit_pass with the word state machines), 2: GEN (gen_eval)
+template <int MODE>
 __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
+  constexpr bool FAT = MODE == 1, GEN = MODE == 2;
+  constexpr int NP = GEN ? MQ_GEN_PLANES : MQ_PLANES; // planes of a queue entry
   __shared__ RkSmem s;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const MatchQueue MQ = a.mq[FAT ? 1 : 0];
+  const MatchQueue MQ = a.mq[MODE];
   RkWaveLds& L = s.w[wave];
   if (!tid) s.hist_lock = 0;
   static_assert(MQ_SHARDS == 64, "one shard per lane of the prefix sum");
@@ -117,6 +121,16 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
   HC.ap0 = HC.ap1 = HC.ap2 = HC.ap3 = 0, HC.px_dist = 0;
   HC.nn_a = HC.nn_b = HC.nn_dist = 0;
 
+  GenAlloc GA;
+  GA.lane = nullptr, GA.cap = 0, GA.used = 0, GA.spill = nullptr, GA.spill_cap = 0, GA.spill_used = nullptr, GA.failed = false;
+  if (GEN) {
+    const uint32_t gl = blockIdx.x * WG + tid;
+    GA.lane = a.gen.lane_arena + (uint64_t)(gl < a.gen.n_lanes ? gl : 0u) * a.gen.lane_hits;
+    GA.cap = gl < a.gen.n_lanes ? a.gen.lane_hits : 0u;
+    GA.spill = a.gen.spill, GA.spill_cap = a.gen.spill_cap, GA.spill_used = a.gen.spill_used;
+  }
+  uint32_t qc_gen_prog = 0;
+
   // virtual -> physical chunk: the shard whose prefix range holds it (uniform binary search over 65 LDS words)
   auto chunk_of = [&](uint32_t vc) -> uint32_t {
     uint32_t lo = 0, hi = MQ_SHARDS; // pre[lo] <= vc < pre[hi]
@@ -136,35 +150,35 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
   // the chunk after the one being ranked is already on its way (header + the 7 planes): one memory round trip less in
   // every chunk's chain of dependent loads
   uint32_t it = 0, vc = vchunk(0);
-  uint32_t nx_hdr = 0, nx[MQ_PLANES];
+  uint32_t nx_hdr = 0, nx[NP];
 #pragma unroll
-  for (int i = 0; i < MQ_PLANES; ++i) nx[i] = 0;
-  constexpr bool PREFETCH = !FAT; // (the PHRASE & co instance would drop from 3 to 2 waves per SIMD for the 8 registers)
+  for (int i = 0; i < NP; ++i) nx[i] = 0;
+  constexpr bool PREFETCH = MODE == 0; // (the PHRASE & co instance would drop from 3 to 2 waves per SIMD for the 8 registers)
   if (PREFETCH && vc < n_chunks) {
     const uint32_t c = chunk_of(vc);
     nx_hdr = MQ.hdr[c];
-    const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+    const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (NP * 64) + lane;
 #pragma unroll
-    for (int i = 0; i < MQ_PLANES; ++i) nx[i] = d[64 * i];
+    for (int i = 0; i < NP; ++i) nx[i] = d[64 * i];
   }
   for (; vc < n_chunks; vc = vchunk(++it)) {
     if (!PREFETCH) {
       const uint32_t c = chunk_of(vc);
       nx_hdr = MQ.hdr[c];
-      const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+      const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (NP * 64) + lane;
 #pragma unroll
-      for (int i = 0; i < MQ_PLANES; ++i) nx[i] = d[64 * i];
+      for (int i = 0; i < NP; ++i) nx[i] = d[64 * i];
     }
     const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx_hdr);
-    uint32_t cur[MQ_PLANES];
+    uint32_t cur[NP];
 #pragma unroll
-    for (int i = 0; i < MQ_PLANES; ++i) cur[i] = nx[i];
+    for (int i = 0; i < NP; ++i) cur[i] = nx[i];
     if (PREFETCH && vchunk(it + 1) < n_chunks) {
       const uint32_t c = chunk_of(vchunk(it + 1));
       nx_hdr = MQ.hdr[c];
-      const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+      const uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (NP * 64) + lane;
 #pragma unroll
-      for (int i = 0; i < MQ_PLANES; ++i) nx[i] = d[64 * i];
+      for (int i = 0; i < NP; ++i) nx[i] = d[64 * i];
     }
     const uint32_t n = hdr >> 24, pass = hdr & 0xFFFFFFu;
     if (pass != cur_pass) {
@@ -178,6 +192,7 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
       qc_nterms = U(Q->n_terms), qc_ranker = U(Q->ranker), qc_flags = U(Q->tree_flags), qc_index_weight = U(Q->index_weight);
       qc_nw = U(Q->n_weights < 8u ? Q->n_weights : 8u);
       qc_max_qpos = U(Q->max_qpos), qc_n_qwords = U(Q->n_qwords);
+      qc_gen_prog = GEN ? U(Q->gen_prog) : 0u;
 #pragma unroll
       for (int t = 0; t < MAX_PROX_TERMS; ++t) {
         HC.tb[t] = U(Q->t[t].blk_first), HC.tq[t] = U(Q->t[t].qpos), HC.tm[t] = U(Q->t[t].queried32);
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
     const bool phrase = FAT && (flags & TF_PHRASE) != 0;
     const bool ph_leaf = FAT && (flags & TF_PHRASE_LEAF) != 0;
     const bool prox_ranker = (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY)
-                                 ? nterms > 1
+                                 ? (GEN || nterms > 1) // (a generic-path tree is never a single keyword)
                                  : (ranker == MRK_RANK_WORDCOUNT || ranker == MRK_RANK_MATCHANY || ranker == MRK_RANK_FIELDMASK ||
                                     ranker == MRK_RANK_SPH04);
     HC.flags = a.q_flags + cur_oq;
@@ -239,13 +254,25 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
                            !(HC.multi_and && nterms == 3 && (HC.tm[0] & HC.tm[1] & HC.tm[2]) != 0xFFFFFFFFu);
 
     const bool valid = lane < n;
-    const uint32_t rowid = cur[0], fa = cur[2];
-    const float tfidf = __uint_as_float(cur[1]);
-    const uint32_t r0 = cur[3], r1 = cur[4], r2 = cur[5], r3 = cur[6];
+    const uint32_t rowid = cur[0], fa = GEN ? 0u : cur[2];
+    float tfidf = GEN ? 0.0f : __uint_as_float(cur[1]);
+    const uint32_t r0 = GEN ? 0u : cur[3], r1 = GEN ? 0u : cur[4], r2 = GEN ? 0u : cur[5], r3 = GEN ? 0u : cur[6];
     bool is_live = valid;
     uint32_t fields = fa & 0xffu;
     int rk = 0;
-    if (valid) {
+    if (GEN) {
+      if (valid) {
+        uint32_t refs[MRK_MAX_AND_TERMS];
+#pragma unroll
+        for (int t = 0; t < MRK_MAX_AND_TERMS; ++t) refs[t] = cur[NP - MRK_MAX_AND_TERMS + t];
+        is_live = gen_eval(a.seg, a.queries + cur_pass, a.gen.progs + qc_gen_prog, refs, rowid, GA, prox_ranker, HC.dupes, L.fw, nw, a.q_flags + cur_oq, tfidf,
+                           fields, rk);
+        if (GA.failed) {
+          atomicOr(a.q_flags + cur_oq, QF_ARENA);
+          GA.failed = false;
+        }
+      }
+    } else if (valid) {
       const uint32_t all_slots = (1u << (nterms < (uint32_t)MAX_PROX_TERMS ? nterms : (uint32_t)MAX_PROX_TERMS)) - 1u;
       const uint32_t smask = (fa >> 8) & all_slots;
       if (FAT) {
@@ -311,10 +338,12 @@ void launch_rank(const ScanArgs& a, int which, void* stream) {
   // persistent grid: enough workgroups to fill every CU at the kernel's occupancy; late ones find the cursor past the
   // count and leave at once
   const dim3 grid(256 * 8), block(WG);
-  if (which)
-    hipLaunchKernelGGL(rank_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+  if (which == 2)
+    hipLaunchKernelGGL(rank_kernel<2>, dim3(GEN_GRID), block, 0, (hipStream_t)stream, a);
+  else if (which)
+    hipLaunchKernelGGL(rank_kernel<1>, grid, block, 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(rank_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(rank_kernel<0>, grid, block, 0, (hipStream_t)stream, a);
 }
 
 } // namespace mrk

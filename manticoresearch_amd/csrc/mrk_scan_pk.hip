@@ -29,11 +29,11 @@ namespace mrk {
 constexpr int CBUF = MRK_CBUF; // candidates a wave collects before it publishes them
 constexpr int MQCAP = 128;     // matched docs a wave queues for the hit pass (processed 64 at a time)
 
-template <bool PROX, bool TREE>
+template <bool PROX, bool TREE, int NREF = MAX_PROX_TERMS>
 struct __align__(16) PkWaveLds {
   uint64_t cbuf[CBUF];  // candidates not yet published to the query's global list
   // proximity rankers: where each matched doc sits in the other terms' blocks (block<<7 | slot, bit 31 = lone hit)
-  uint32_t href[PROX ? MAX_PROX_TERMS - 1 : 1][PROX ? DEVBLK : 1];
+  uint32_t href[PROX ? NREF - 1 : 1][PROX ? DEVBLK : 1];
   uint32_t tj_rowid[DEVBLK];
   uint32_t tj_attr[64];
   // boolean trees: what each keyword contributes to each doc of the driver block (tfidf term, field bits)
@@ -42,7 +42,7 @@ struct __align__(16) PkWaveLds {
   uint32_t mq_row[PROX ? MQCAP : 1];
   float mq_acc[PROX ? MQCAP : 1];
   uint32_t mq_fa[PROX ? MQCAP : 1];
-  uint32_t mq_ref[PROX ? MAX_PROX_TERMS : 1][PROX ? MQCAP : 1];
+  uint32_t mq_ref[PROX ? NREF : 1][PROX ? MQCAP : 1];
   float kv[TREE ? MRK_MAX_AND_TERMS : 1][TREE ? DEVBLK : 4];
   uint8_t kf[TREE ? MRK_MAX_AND_TERMS : 1][TREE ? DEVBLK : 16];
   union {
@@ -52,19 +52,22 @@ struct __align__(16) PkWaveLds {
 };
 static_assert(NBINS * 4 <= MAPCAP, "hist must fit the map area");
 
-template <bool PROX, bool TREE>
+template <bool PROX, bool TREE, int NREF = MAX_PROX_TERMS>
 struct __align__(16) PkSmem {
-  PkWaveLds<PROX, TREE> w[WAVES];
+  PkWaveLds<PROX, TREE, NREF> w[WAVES];
   uint32_t rank[256];
   float tfidf[1][256]; // really [n_terms][256]: the tail lives in dynamic LDS right behind this struct
 };
 
 // EXT: the batch holds queries with position modifiers, a BEFORE node or attribute filters; batches without them run the
 // leaner instance (the extra code costs the three-keyword proximity mixes ~7 % even when it never executes)
-template <bool PROX, bool TREE, bool EXT = false>
+// NREF: keyword slots whose packed-array references travel with a match (more than MAX_PROX_TERMS: the instance that
+// feeds the generic evaluator's queue -- candidates, not matches, with one reference per keyword)
+template <bool PROX, bool TREE, bool EXT = false, int NREF = MAX_PROX_TERMS>
 __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
+  constexpr bool GEN = NREF > MAX_PROX_TERMS;
   extern __shared__ __align__(16) uint8_t smem_raw[];
-  PkSmem<PROX, TREE>& s = *reinterpret_cast<PkSmem<PROX, TREE>*>(smem_raw);
+  PkSmem<PROX, TREE, NREF>& s = *reinterpret_cast<PkSmem<PROX, TREE, NREF>*>(smem_raw);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= a.n_items) return;
   const DevItem item = a.items[blockIdx.x];
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
                                         ? nterms > 1
                                         : (ranker == MRK_RANK_WORDCOUNT || ranker == MRK_RANK_MATCHANY ||
                                            ranker == MRK_RANK_FIELDMASK || ranker == MRK_RANK_SPH04));
-  PkWaveLds<PROX, TREE>& L = s.w[wave];
+  PkWaveLds<PROX, TREE, NREF>& L = s.w[wave];
   const uint32_t oq = Q->out_q; // logical query: several passes (driver keywords) may feed one result
   const uint32_t req_mask = TREE ? Q->req_mask : 0u, excl_mask = TREE ? Q->excl_mask : 0u;
   const uint32_t n_nodes = TREE ? Q->n_nodes : 0u;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   const uint32_t ph_mask = ph_leaf ? Q->ph_mask : 0u;                         // its words' keyword slots
   const uint32_t ph_n = !PROX ? 0u : phrase ? nterms : (uint32_t)__popc(ph_mask);
   const uint32_t ph_span = !PROX || ph_n < 2 ? 0u : Q->ph_atoms[ph_n - 1] - Q->ph_atoms[0];
-  const bool need_hits = PROX && (prox_ranker || phrase); // matches go through the hit pass before they are weighed
+  const bool need_hits = PROX && (prox_ranker || phrase || GEN); // matches go through the hit pass before they are weighed
   const bool multi_and = (!TREE || (Q->tree_flags & TF_MULTIAND) != 0) && !phrase;
   // PHRASE: query positions of its words in phrase order (FSMphrase_c::m_dAtomPos, searchnode.cpp:3884-3899)
   const uint32_t ap0 = PROX ? Q->ph_atoms[0] : 0u, ap1 = PROX ? Q->ph_atoms[1] : 0u, ap2 = PROX ? Q->ph_atoms[2] : 0u,
@@ -233,16 +236,21 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   auto flush_matches = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
     if (!PROX) return;
     wave_lds_fence();
-    const MatchQueue& MQ = a.mq[fat_q ? 1 : 0];
+    const MatchQueue& MQ = a.mq[GEN ? 2 : fat_q ? 1 : 0];
     const uint32_t c = mq_take(MQ, mqw);
     if (c != 0xFFFFFFFFu) {
-      uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+      uint32_t* __restrict__ d = MQ.data + (uint64_t)c * ((GEN ? MQ_GEN_PLANES : MQ_PLANES) * 64) + lane;
       const uint32_t e = from + lane; // (entries past n are stale slots; the header's count masks them)
       d[0] = L.mq_row[e];
-      d[64] = __float_as_uint(L.mq_acc[e]);
-      d[128] = L.mq_fa[e];
+      if (GEN) {
 #pragma unroll
-      for (int t = 0; t < MAX_PROX_TERMS; ++t) d[192 + 64 * t] = L.mq_ref[t][e];
+        for (int t = 0; t < NREF; ++t) d[64 + 64 * t] = L.mq_ref[t][e];
+      } else {
+        d[64] = __float_as_uint(L.mq_acc[e]);
+        d[128] = L.mq_fa[e];
+#pragma unroll
+        for (int t = 0; t < MAX_PROX_TERMS; ++t) d[192 + 64 * t] = L.mq_ref[t][e];
+      }
       if (lane == 0) MQ.hdr[c] = item.query | (n << 24);
     } else if (lane == 0)
       atomicOr(a.q_flags + oq, QF_OVERFLOW); // the host reruns the query alone with a queue sized for all its driver docs
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
                 acc[r] = acc[r] + tvx;
                 fld[r] |= fq;
               }
-              if (PROX && j < (uint32_t)MAX_PROX_TERMS)
+              if (PROX && j < (uint32_t)NREF)
                 L.href[j - 1][lane + 64 * r] = ((inline_hits && tfq == 1u) ? 0x80000000u : 0u) | rk[r];
             }
           }
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
                     acc[r] = acc[r] + tvx;
                     fld[r] |= fj[r];
                   }
-                  if (PROX && j < (uint32_t)MAX_PROX_TERMS)
+                  if (PROX && j < (uint32_t)NREF)
                     L.href[j - 1][lane + 64 * r] = ((inline_hits && tfj[r] == 1u) ? 0x80000000u : 0u) | (kj << 7) | pos[r];
                 }
               }
@@ -786,7 +794,8 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
               L.mq_fa[pos] = (fld[r] & 0xffu) | ((TREE ? act[r] & 0xffu : 0xffu) << 8) | ((notnear && ((pres[r] >> HC.nn_b) & 1u)) ? 1u << 16 : 0u);
               L.mq_ref[0][pos] = ((inline_hits && ((cur0.attr >> (8 * r)) & 0xffu) == 1u) ? 0x80000000u : 0u) | (b << 7) | (lane + 64 * r);
 #pragma unroll
-              for (int t = 1; t < MAX_PROX_TERMS; ++t) L.mq_ref[t][pos] = L.href[t - 1][lane + 64 * r];
+              for (int t = 1; t < NREF; ++t) // (the generic evaluator is told which keywords the doc does not hold)
+                L.mq_ref[t][pos] = (GEN && !((pres[r] >> t) & 1u)) ? 0xFFFFFFFFu : L.href[t - 1][lane + 64 * r];
             }
             mqn += (uint32_t)__popcll(bal);
             if (mqn >= 64u) {
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
     }
   }
   if (PROX && mqn) flush_matches(0u, mqn);
-  if (PROX) mq_close(a.mq[fat_q ? 1 : 0], mqw, item.query);
+  if (PROX) mq_close(a.mq[GEN ? 2 : fat_q ? 1 : 0], mqw, item.query);
 
   // ---- wave epilogue
   if (cn) publish();
@@ -872,17 +881,19 @@ __global__ __launch_bounds__(WG) void select_kernel(SelectArgs a) {
   if (tid == 0) a.out_cnt[q] = m;
 }
 
-template <bool PROX, bool TREE, bool EXT = false>
+template <bool PROX, bool TREE, bool EXT = false, int NREF = MAX_PROX_TERMS>
 static void launch_pk(const ScanArgs& a, size_t tail, hipStream_t st) {
-  hipLaunchKernelGGL((scan_pk_kernel<PROX, TREE, EXT>), dim3(a.n_items), dim3(WG), sizeof(PkSmem<PROX, TREE>) + tail, st, a);
+  hipLaunchKernelGGL((scan_pk_kernel<PROX, TREE, EXT, NREF>), dim3(a.n_items), dim3(WG), sizeof(PkSmem<PROX, TREE, NREF>) + tail, st, a);
 }
 
-void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, bool ext, void* stream) {
+void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree, bool ext, void* stream, bool gen) {
   if (!a.n_items) return;
   if (max_terms < 1) max_terms = 1;
   const size_t tail = (size_t)(max_terms - 1) * 256 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (ext) // filters alone may come with a plain AND: the EXT instance is the full tree + hit-stream kernel
+  if (gen) // candidates of the generic evaluator: the tree kernel without the in-scan hit passes, a reference per keyword
+    launch_pk<true, true, true, MRK_MAX_AND_TERMS>(a, tail, st);
+  else if (ext) // filters alone may come with a plain AND: the EXT instance is the full tree + hit-stream kernel
     launch_pk<true, true, true>(a, tail, st);
   else if (tree)
     prox ? launch_pk<true, true>(a, tail, st) : launch_pk<false, true>(a, tail, st);
