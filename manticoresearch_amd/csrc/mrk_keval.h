@@ -193,13 +193,17 @@ __device__ inline bool gen_eval(const DevSegment& seg, const DevQuery* __restric
         if (!out) break;
         gen_merge(out, R.n, L.p, L.n, Rr.p, Rr.n, N.npl, N.npr);
         R.p = out;
-        if (N.flags & 1u) { // m_bQPosReverse: hits at one position in DESCENDING query position (CmpAndHitReverse_fn :2618-2624)
-          for (uint32_t i = 1; i < R.n; ++i)
-            for (uint32_t j = i; j > 0 && out[j - 1].hitpos == out[j].hitpos && out[j - 1].qpos < out[j].qpos; --j) {
-              const GenHit x = out[j];
+        if (N.flags & 1u) { // m_bQPosReverse: the hits sorted again, by position and DESCENDING query position (CmpAndHitReverse_fn
+          // :2618-2624).  A sort, not a fix-up of ties: a PROXIMITY operand may hand over hits out of position order
+          for (uint32_t i = 1; i < R.n; ++i) {
+            const GenHit x = out[i];
+            uint32_t j = i;
+            while (j > 0 && (out[j - 1].hitpos > x.hitpos || (out[j - 1].hitpos == x.hitpos && out[j - 1].qpos < x.qpos))) {
               out[j] = out[j - 1];
-              out[j - 1] = x;
+              --j;
             }
+            if (j != i) out[j] = x;
+          }
         }
         break;
       }

@@ -1008,6 +1008,11 @@ def test_generic_evaluator_vs_oracle(orc, dev):
                     want = to_orc(orc, q).run(oi)
                 except Exception:
                     continue  # a shape the oracle itself does not restate
+                def n_kws(x):
+                    return 1 if x.word is not None else sum(n_kws(k) for k in x.children)
+
+                if g.status == -2 and n_kws(q.root) > 8:  # the one limit these shapes can reach: eight keywords per query
+                    continue
                 ok = g.status == 0 and g.total_found == want.total_found and len(g.rowid) == len(want.rowid) and (g.rowid == want.rowid).all() and \
                     (g.weight == want.weight).all()
                 if not ok:  # say which docs differ (every match, by rowid) before failing
