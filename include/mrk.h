@@ -72,7 +72,7 @@ enum { MRK_OP_TERM = 0, MRK_OP_AND = 1, MRK_OP_OR = 2, MRK_OP_MAYBE = 3, MRK_OP_
        MRK_OP_PROXIMITY = 6, /* '"a b c"~N': opt = N */
        MRK_OP_BEFORE = 8, /* 'a << b << c' (ExtOrder_c): the children occur in this order inside one field */
        MRK_OP_QUORUM = 7, /* '"a b c"/N': opt = N (ExtQuorum_c; N = 1 / N >= words as the reference rewrites them) */
-       MRK_OP_NEAR = 9,   /* 'a NEAR/N b' (ExtNWay_T<FSMmultinear_c>): opt = N; the device takes two plain keywords */
+       MRK_OP_NEAR = 9,   /* 'a NEAR/N b' (ExtNWay_T<FSMmultinear_c>): opt = N; operands: keywords, phrases, nested NEARs; 3+ operands at the query root only */
        MRK_OP_NOTNEAR = 10 /* 'a NOTNEAR/N b' (ExtNotNear_c): opt = N */ };
 
 enum { MRK_HITFMT_PLAIN = 0, MRK_HITFMT_INLINE = 1 }; /* ESphHitFormat */
@@ -203,6 +203,11 @@ void mrk_ctx_destroy(mrk_ctx* ctx);
    block by block; default 32, 0 = never; read at submit);
    "mq_max_chunks" (cap of a batch's match queue -- matched docs of hit-ranked queries on their way to the ranking kernel -- in
    chunks of 64 docs / 1792 bytes, default 2^20; queries that outgrow it are rerun one by one by mrk_batch_wait);
+   "gen_lane_hits" / "gen_spill_mb" (the generic per-doc evaluator -- query shapes the specialised hit passes do not take: more
+   than four keywords under a hit ranker, phrases of five and more words, BEFORE / NEAR / NOTNEAR over phrases, groups and
+   quorums, several such nodes -- keeps each node's hit list of the doc at hand in HBM: 16-byte hits per evaluator lane
+   (default 256 x 131072 lanes = 512 MB) and a shared area for longer lists (default 1024 MB); allocated with the first
+   batch that holds such a query; a query that outgrows them fails with MRK_E_UNSUPPORTED, it is never truncated);
    returns MRK_E_INVAL for unknown keys */
 int mrk_ctx_set(mrk_ctx* ctx, const char* key, int64_t value);
 

@@ -107,6 +107,7 @@ constexpr uint32_t TF_PHRASE_LEAF = 8; // one PHRASE below other operators: ph_m
 constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[] = atom positions in phrase order
 constexpr uint32_t TF_FAT = TF_PHRASE | TF_PHRASE_LEAF | TF_TERMPOS | TF_ORDER | TF_NOTNEAR; // final ranking needs the full hit pass (rank_kernel<true>)
 constexpr uint32_t TF_GEN = 1024;   // answered by the generic per-doc evaluator (mrk_keval.h): matches go to queue 2 with one reference per keyword
+constexpr uint32_t TF_GEN_NEARN = 2048; // ... whose root is a NEAR over three and more operands: its folded hits' query position needs the probe launch
 constexpr int PHRASE_STATES = 8;    // live FSMphrase_c states per doc (>= phrase span + 1)
 constexpr int TREE_STACK = 4;       // evaluation stack depth of the tree program
 constexpr int MAX_PASSES = 8; // driver keywords per query (size of the tree's candidate cover)
@@ -231,6 +232,10 @@ struct GenArgs {
   GenHit* spill;       // lists that do not fit the lane's slice; handed out by atomicAdd, released with the launch
   unsigned long long spill_cap;
   unsigned long long* spill_used;
+  // NEAR over 3+ operands (FSMmultinear_c::m_uFirstQpos is never reset): per logical query, for each query position v < 64 the
+  // first rowid whose evaluation inserted an operand hit with that position; phase 1 = the probe launch that fills it
+  uint32_t* near_tab;
+  uint32_t phase, pad2;
 };
 
 struct ScanArgs {

@@ -154,6 +154,7 @@ struct mrk_batch {
   DevBuf<mrk::GenProg> d_gen_progs;
   DevBuf<mrk::GenHit> d_gen_lane, d_gen_spill;
   DevBuf<unsigned long long> d_gen_used;
+  DevBuf<uint32_t> d_gen_near; // GenArgs::near_tab
   std::vector<mrk::GenProg> gen_progs;
   bool last_fat = false;
   // decoded results
@@ -716,7 +717,7 @@ static void mrk_batch_destroy_impl(mrk_batch* b) {
   b->d_decl.release();
   for (int i = 0; i < 3; ++i) b->d_mq_data[i].release(), b->d_mq_hdr[i].release();
   b->d_mq_count.release();
-  b->d_gen_progs.release(), b->d_gen_lane.release(), b->d_gen_spill.release(), b->d_gen_used.release();
+  b->d_gen_progs.release(), b->d_gen_lane.release(), b->d_gen_spill.release(), b->d_gen_used.release(), b->d_gen_near.release();
   if (b->retry) mrk_batch_destroy_impl(b->retry);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
@@ -810,7 +811,7 @@ static int bind_match_queues(mrk_batch* b, const uint64_t chunks[3], mrk::ScanAr
 }
 
 // the generic evaluator's memory: allocated the first time a batch holds such a query, kept with the batch
-static int bind_gen(mrk_batch* b, mrk_batch* owner_of_progs, mrk::ScanArgs& sa, hipStream_t st) {
+static int bind_gen(mrk_batch* b, mrk_batch* owner_of_progs, mrk::ScanArgs& sa, hipStream_t st, uint32_t n_queries, bool nearn) {
   const uint32_t n_lanes = (uint32_t)mrk::GEN_GRID * mrk::WG, lane_hits = (uint32_t)b->ctx->gen_lane_hits;
   const size_t spill = (size_t)b->ctx->gen_spill_mb * (1u << 20) / sizeof(mrk::GenHit);
   int rc;
@@ -822,6 +823,24 @@ static int bind_gen(mrk_batch* b, mrk_batch* owner_of_progs, mrk::ScanArgs& sa, 
   sa.gen.spill = b->d_gen_spill.p;
   sa.gen.spill_cap = spill;
   sa.gen.spill_used = b->d_gen_used.p;
+  sa.gen.near_tab = nullptr, sa.gen.phase = 0;
+  if (nearn) {
+    if ((rc = b->d_gen_near.reserve((size_t)n_queries * 64))) return rc;
+    HIP_TRY(hipMemsetAsync(b->d_gen_near.p, 0xFF, (size_t)n_queries * 64 * 4, st));
+    sa.gen.near_tab = b->d_gen_near.p;
+  }
+  return MRK_OK;
+}
+
+// the generic evaluator over queue 2; queries with a NEAR over 3+ operands at the root need the probe launch first
+static int launch_gen_rank(mrk::ScanArgs& sa, bool nearn, hipStream_t st) {
+  if (nearn) {
+    sa.gen.phase = 1;
+    launch_rank(sa, 2, st);
+    HIP_TRY(hipMemsetAsync(sa.gen.spill_used, 0, sizeof(unsigned long long), st)); // the probe's lists are gone
+    sa.gen.phase = 0;
+  }
+  launch_rank(sa, 2, st);
   return MRK_OK;
 }
 
@@ -965,12 +984,14 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   sa.q_flags = b->d_q_flags.p;
   sa.q_tau_bin = b->d_q_tau_bin.p;
   sa.cand = b->d_cand.p;
+  bool any_nearn = false;
   if ((rc = bind_match_queues(b, mq_chunks, sa))) return rc;
   if (mq_chunks[0] || mq_chunks[1] || mq_chunks[2]) HIP_TRY(hipMemsetAsync(b->d_mq_count.p, 0, 3 * mrk::MQ_SHARDS * 4, st));
   if (!b->gen_progs.empty()) {
     if ((rc = b->d_gen_progs.reserve(b->gen_progs.size()))) return rc;
     HIP_TRY(hipMemcpyAsync(b->d_gen_progs.p, b->gen_progs.data(), b->gen_progs.size() * sizeof(mrk::GenProg), hipMemcpyHostToDevice, st)); // (pageable: the vector lives until the next submit)
-    if ((rc = bind_gen(b, b, sa, st))) return rc;
+    for (uint32_t i = 0; i < n; ++i) any_nearn = any_nearn || (b->h_queries.p[i].tree_flags & mrk::TF_GEN_NEARN) != 0;
+    if ((rc = bind_gen(b, b, sa, st, n, any_nearn))) return rc;
   }
   lap("h2d+memset");
   HIP_TRY(hipEventRecord(b->ev_scan0, st));
@@ -991,7 +1012,7 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
     // the queued matches of hit-ranked queries: hit pass + state rankers (mrk_rank.hip), behind the scans on the same stream
     if (mq_chunks[0]) launch_rank(sa, 0, st);
     if (mq_chunks[1]) launch_rank(sa, 1, st);
-    if (mq_chunks[2]) launch_rank(sa, 2, st);
+    if (mq_chunks[2] && (rc = launch_gen_rank(sa, any_nearn, st))) return rc;
     if (n_items_kind[0]) {
       ScanArgs sb = sa;
       sb.items = b->d_items.p + n_items_pk;
@@ -1151,7 +1172,8 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
       if (chunks[i] > (1ull << 25)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: match queue for the rerun too large", qi);
     if ((rc = bind_match_queues(r, chunks, sa))) return rc;
     if (chunks[0] || chunks[1] || chunks[2]) HIP_TRY(hipMemsetAsync(r->d_mq_count.p, 0, 3 * mrk::MQ_SHARDS * 4, st));
-    if (n_gen && (rc = bind_gen(r, b, sa, st))) return rc; // (the programs are the submit's, still on the device)
+    const bool nearn = (passes[0].tree_flags & TF_GEN_NEARN) != 0;
+    if (n_gen && (rc = bind_gen(r, b, sa, st, 1, nearn))) return rc; // (the programs are the submit's, still on the device)
     launch_scan_pk(sa, b->last_max_terms, b->last_prox, b->last_tree, b->last_ext, st);
     if (n_gen) {
       ScanArgs sg = sa;
@@ -1167,7 +1189,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
     }
     if (chunks[0]) launch_rank(sa, 0, st);
     if (chunks[1]) launch_rank(sa, 1, st);
-    if (chunks[2]) launch_rank(sa, 2, st);
+    if (chunks[2] && (rc = launch_gen_rank(sa, nearn, st))) return rc;
   }
   if (n_bm) {
     ScanArgs sb = sa;

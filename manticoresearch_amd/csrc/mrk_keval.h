@@ -121,7 +121,7 @@ __device__ inline void gen_merge(GenHit* out, uint32_t& n_out, const GenHit* L, 
 // Returns false when the root does not hold the doc; else tfidf / fields of the root and, for the state rankers, rk.
 __device__ inline bool gen_eval(const DevSegment& seg, const DevQuery* __restrict__ Q, const GenProg* __restrict__ P, const uint32_t* refs, uint32_t row,
                                 GenAlloc& A, bool state_ranker, bool dupes, const int32_t* fw, uint32_t nw, uint32_t* qflags, float& tfidf_out,
-                                uint32_t& fields_out, int& rk_out) {
+                                uint32_t& fields_out, int& rk_out, uint32_t near_fq_in = 65535u, uint32_t* near_m_out = nullptr) {
   GenRes res[GEN_MAX_NODES];
   A.used = 0;
   const uint32_t nn = P->n_nodes;
@@ -379,7 +379,123 @@ __device__ inline bool gen_eval(const DevSegment& seg, const DevQuery* __restric
         R.p = out, R.n = n, R.ok = true, R.tfidf = I.tfidf, R.fields = 1u << (ffield & 31u);
         break;
       }
-      case GN_NEAR: {
+      case GN_NEAR:
+        if (N.n_words > 2) {
+          // ExtNWay_T<FSMmultinear_c>, three and more operands (HitFSM :4096-4288, the ring branches): m_dNpos = the operand
+          // numbers gathered so far (sorted), m_dRing = their hits in arrival order; a complete chain resets.  m_uFirstQpos is
+          // never reset in the reference -- it is the least query position any EARLIER doc of the node inserted -- so it
+          // comes in from outside (near_fq_in: the probe launch found it) and this doc's own least goes out (near_m_out).
+          const GenRes& I = res[N.kid[0]];
+          if (!I.ok) break;
+          GenHit* out = A.take(I.n);
+          if (!out) break;
+          constexpr int NR = 16;
+          const uint32_t k = N.n_words, dist = (uint32_t)N.opt;
+          uint32_t last_p = 0, last_ml = 0, first_hit = 0, weight = 0, first_qpos = near_fq_in, m_ins = 65535u, n = 0, ffield = 0;
+          uint32_t np[NR], nnp = 0, iring = 0;
+          GenHit ring[MRK_MAX_AND_TERMS];
+          for (uint32_t i = 0; i < k && i < (uint32_t)MRK_MAX_AND_TERMS; ++i) ring[i] = gen_hit(0, 0, 0, 0, 0, 0);
+          auto tail = [&]() -> uint32_t { return (iring + nnp - 1u) % k; };
+          auto find = [&](uint32_t v) -> int {
+            for (uint32_t i = 0; i < nnp; ++i)
+              if (np[i] == v) return (int)i;
+            return -1;
+          };
+          auto insert = [&](uint32_t at, uint32_t v) -> bool {
+            if (nnp >= (uint32_t)NR) return false;
+            for (uint32_t i = nnp; i > at; --i) np[i] = np[i - 1];
+            np[at] = v;
+            ++nnp;
+            return true;
+          };
+          auto seen_q = [&](uint32_t q) {
+            if (q < first_qpos) first_qpos = q;
+            if (q < m_ins) m_ins = q;
+          };
+          bool bad = false;
+          for (uint32_t hi = 0; hi < I.n && !bad; ++hi) {
+            const GenHit h = I.p[hi];
+            const uint32_t hpf = gen_pwf(h.hitpos), npos = h.nodepos, qpos = h.qpos;
+            if (last_p == hpf) { // a dupe hit (an OR operand, 'a NEAR/2 a NEAR/2 a'): the leftmost operand of the dupes takes the ring slot
+              if (npos < ring[tail()].nodepos && find(npos) < 0) {
+                const int at = find(ring[tail()].nodepos);
+                if (at >= 0) np[at] = npos;
+                for (uint32_t i = 1; i < nnp; ++i)
+                  for (uint32_t j = i; j > 0 && np[j - 1] > np[j]; --j) {
+                    const uint32_t x = np[j];
+                    np[j] = np[j - 1];
+                    np[j - 1] = x;
+                  }
+                ring[tail()].nodepos = (uint16_t)npos, ring[tail()].qpos = (uint16_t)qpos;
+              }
+              continue; // (the pre-last roll-back only exists for two operands)
+            }
+            if (last_p == 0 || last_p + last_ml + dist <= hpf) { // probably a new chain
+              first_hit = last_p = hpf;
+              last_ml = h.matchlen;
+              weight = h.weight;
+              nnp = 1, np[0] = npos;
+              ring[tail()] = h;
+              continue;
+            }
+            if (npos < np[0]) {
+              seen_q(qpos);
+              bad = !insert(0, npos);
+            } else if (npos > np[nnp - 1]) {
+              seen_q(qpos);
+              bad = !insert(nnp, npos);
+            } else if (npos != np[0] && npos != np[nnp - 1]) {
+              int end = (int)nnp, start = 0;
+              bool drop = false;
+              while (end - start > 1) {
+                const int mid = (start + end) / 2;
+                if (npos == np[mid]) {
+                  const GenHit rh = ring[iring];
+                  if (npos == rh.nodepos) { // the last addition is the same operand as the first: shift
+                    weight -= rh.weight;
+                    first_hit = gen_pwf(rh.hitpos);
+                    if (++iring == k) iring = 0;
+                  } else if (npos == ring[tail()].nodepos)
+                    weight -= ring[tail()].weight;
+                  else {
+                    drop = true;
+                    break;
+                  }
+                }
+                if (npos < np[mid])
+                  end = mid;
+                else
+                  start = mid;
+              }
+              if (drop) continue;
+              bad = !insert((uint32_t)end, npos);
+              seen_q(qpos);
+            } else if (npos == ring[iring].nodepos) { // the same operand as the head: shift
+              weight -= ring[iring].weight;
+              first_hit = gen_pwf(ring[iring].hitpos);
+              if (++iring == k) iring = 0;
+            } else if (npos == ring[tail()].nodepos) // ... as the tail: the tail moves onto it
+              weight -= ring[tail()].weight;
+            else
+              continue;
+            if (bad) break;
+            weight += h.weight;
+            last_ml = h.matchlen;
+            ring[tail()] = h;
+            if (k == nnp) { // the whole chain: emit it (no overlapping in generic chains)
+              if (!n) ffield = h.hitpos >> 24;
+              out[n++] = gen_hit(first_hit, first_qpos < qpos ? first_qpos : qpos, 0, nnp, hpf - first_hit + last_ml, weight);
+              last_p = 0;
+              continue;
+            }
+            last_p = hpf;
+          }
+          if (bad) atomicOr(qflags, QF_FSM);
+          if (near_m_out) *near_m_out = m_ins;
+          if (!n) break;
+          R.p = out, R.n = n, R.ok = true, R.tfidf = I.tfidf, R.fields = 1u << (ffield & 31u);
+          break;
+        } else {
         // ExtNWay_T<FSMmultinear_c> for TWO operands of any kind (HitFSM :4096-4288, the twofer branches): the operands' AND
         // chain (kid 0) carries each hit's operand number in nodepos; chains may overlap, so a complete one shifts, not resets
         const GenRes& I = res[N.kid[0]];
@@ -439,8 +555,8 @@ __device__ inline bool gen_eval(const DevSegment& seg, const DevQuery* __restric
         (void)last_sl, (void)prelast_sl;
         if (!n) break;
         R.p = out, R.n = n, R.ok = true, R.tfidf = I.tfidf, R.fields = 1u << (ffield & 31u);
+        }
         break;
-      }
       case GN_QUORUM: {
         // ExtQuorum_c over plain keywords (kid[] = keyword slots in query-position order): at least `opt` of them hold the doc;
         // tfidf adds up in the order m_dChildren has at this rowid (a keyword whose doclist ran dry has left by RemoveFast);

@@ -84,6 +84,7 @@ struct PlanTree {
   int nn_a = 0, nn_b = 0, nn_dist = 0;
   int q_kw0 = 0, q_n = 0, q_thr = 0;
   IntVec atoms;                 // its words' query positions, phrase order
+  bool gen_nearn = false;       // ... with a NEAR over three and more operands at its root
   bool gen = false;             // planned for the generic per-doc evaluator: nodes = the doc-level superset tree, the real tree is a GenProg
 };
 
@@ -454,26 +455,29 @@ static int build_gen(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pla
       return G.add(g, G.plan[inner], INT_MAX, G.atom[nodes_q[0]]);
     }
     case MRK_OP_NEAR: { // CreateMultiNode<ExtMultinear_c>: operands of any kind; two of them on the device (see mrk_keval.h)
-      if (n.n_children != 2)
-        return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: NEAR over %d operands (device path: two; the reference's folded hit of a longer chain "
-                              "carries a query position that depends on the docs evaluated before)", qi, n.n_children), -1;
+      // three and more operands: the folded hit's query position depends on the docs the node evaluated before (m_uFirstQpos
+      // is never reset), which a probe launch reconstructs -- for a node every doc of which reaches the evaluator: the root
+      if (n.n_children > 2 && (depth != 0 || n.n_children > MRK_MAX_AND_TERMS))
+        return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: NEAR over %d operands below another operator (device path: two there, up to %d at the root)", qi,
+                              n.n_children, MRK_MAX_AND_TERMS), -1;
+      if (n.n_children > 2) T.gen_nearn = true;
       if (n.opt <= 0 || n.opt > (1 << 20)) return err = mrk_fail(MRK_E_INVAL, "query %u: NEAR distance %d", qi, n.opt), -1;
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < n.n_children; ++i) {
         const int cop = q.nodes[kids[i]].op;
         if (cop != MRK_OP_TERM && cop != MRK_OP_PHRASE && cop != MRK_OP_PROXIMITY && cop != MRK_OP_NEAR)
           return err = mrk_fail(MRK_E_UNSUPPORTED, "query %u: NEAR over AND / OR groups (the reference's answer for them is not understood: parity unpinned)", qi), -1;
       }
       sph_isort(ord, key);
-      IntVec nodes_q(2);
+      IntVec nodes_q(n.n_children);
       int inner = -1;
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < n.n_children; ++i) {
         const int c = build_gen(seg, q, kids[ord[i]], T, G, qi, depth + 1, err);
         if (c < 0) return -1;
         nodes_q[ord[i]] = c;
         nway_step(inner, c, ord, i);
       }
       GenNode g{};
-      g.kind = GN_NEAR, g.n_kids = 1, g.kid[0] = (uint8_t)inner, g.opt = n.opt;
+      g.kind = GN_NEAR, g.n_kids = 1, g.kid[0] = (uint8_t)inner, g.opt = n.opt, g.n_words = (uint8_t)n.n_children;
       return G.add(g, G.plan[inner], INT_MAX, G.atom[nodes_q[0]]);
     }
     case MRK_OP_QUORUM: { // :1638-1686
@@ -702,6 +706,12 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     }
 
     prox = false; // a state ranker reads the hit streams
+    if (gen && T.gen_nearn) {
+      int mq = 0;
+      for (const PlanKw& k : T.kws) mq = std::max(mq, k.atom_pos);
+      if (q.n_filters > 0 || seg->dev.dead || mq >= 64)
+        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NEAR over 3+ operands next to filters / dead rows / query positions past 63 (every doc of the node must reach the evaluator)", qi);
+    }
     if (gen && single_word) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: a single keyword is not a case for the generic evaluator", qi);
     if (gen) {
       if (!use_packed || !seg->dev.pk_hit || seg->total_docs >= (1ull << 31)) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: the generic evaluator runs on the packed path, < 2^31 docs per segment", qi);
@@ -1062,7 +1072,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     P->n_terms = (uint32_t)n;
     for (int i = 0; i < n; ++i) fill_term(seg, T.kws[order[i]], P->t[i]);
     P->req_mask = P->excl_mask = 0;
-    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0) | (T.order ? TF_ORDER : 0) | (T.notnear ? TF_NOTNEAR : 0) | (T.gen ? TF_GEN : 0);
+    P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0) | (T.order ? TF_ORDER : 0) | (T.notnear ? TF_NOTNEAR : 0) | (T.gen ? TF_GEN : 0) | (T.gen_nearn ? TF_GEN_NEARN : 0);
     if (T.gen) { // the evaluator's program, keyword slots as this pass orders them
       GenProg gp = G.prog;
       for (uint32_t i = 0; i < gp.n_nodes; ++i) {

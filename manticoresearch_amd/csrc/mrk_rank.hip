@@ -265,8 +265,24 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
         uint32_t refs[MRK_MAX_AND_TERMS];
 #pragma unroll
         for (int t = 0; t < MRK_MAX_AND_TERMS; ++t) refs[t] = cur[NP - MRK_MAX_AND_TERMS + t];
-        is_live = gen_eval(a.seg, a.queries + cur_pass, a.gen.progs + qc_gen_prog, refs, rowid, GA, prox_ranker, HC.dupes, L.fw, nw, a.q_flags + cur_oq, tfidf,
-                           fields, rk);
+        const bool nearn = (flags & TF_GEN_NEARN) != 0, probe = a.gen.phase == 1;
+        uint32_t fq = 65535u, m_ins = 65535u;
+        uint32_t* __restrict__ tab = a.gen.near_tab + (uint64_t)cur_oq * 64;
+        if (nearn && !probe) // the least query position an earlier doc inserted (the table is final: the probe launch ran before)
+          for (uint32_t v = 0; v < 64; ++v)
+            if (tab[v] < rowid) {
+              fq = v;
+              break;
+            }
+        if (probe && !nearn)
+          is_live = false;
+        else
+          is_live = gen_eval(a.seg, a.queries + cur_pass, a.gen.progs + qc_gen_prog, refs, rowid, GA, prox_ranker, HC.dupes, L.fw, nw, a.q_flags + cur_oq, tfidf,
+                             fields, rk, fq, &m_ins);
+        if (probe) {
+          if (nearn && m_ins < 64u) atomicMin(tab + m_ins, rowid);
+          is_live = false;
+        }
         if (GA.failed) {
           atomicOr(a.q_flags + cur_oq, QF_ARENA);
           GA.failed = false;
