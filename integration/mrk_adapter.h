@@ -99,7 +99,9 @@ inline int MrkOpOf ( XQOperator_e eOp )
 		case SPH_QUERY_PHRASE:		return MRK_OP_PHRASE;
 		case SPH_QUERY_PROXIMITY:	return MRK_OP_PROXIMITY;
 		case SPH_QUERY_QUORUM:		return MRK_OP_QUORUM;
-		default:					return -1;	// NOT, NEAR, NOTNEAR, SENTENCE, PARAGRAPH, NULL, SCAN
+		case SPH_QUERY_NEAR:		return MRK_OP_NEAR;
+		case SPH_QUERY_NOTNEAR:		return MRK_OP_NOTNEAR;
+		default:					return -1;	// NOT, SENTENCE, PARAGRAPH, NULL, SCAN
 	}
 }
 
