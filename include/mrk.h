@@ -131,7 +131,7 @@ enum { MRK_TERMPOS_NONE = 0, MRK_TERMPOS_START = 1, MRK_TERMPOS_END = 2, MRK_TER
    already resolved to the attribute's locator.  All filters of a query must pass (Filter_And); rejected rows never reach
    the ranker or the sorter and are not counted (ExtRanker_c::GetMatches -> CSphIndex_VLN::EarlyReject,
    sphinxsearch.cpp:1055-1064, sphinx.cpp:11903-11917). */
-enum { MRK_FILTER_VALUES = 0, MRK_FILTER_RANGE = 1 }; /* SPH_FILTER_VALUES, SPH_FILTER_RANGE */
+enum { MRK_FILTER_VALUES = 0, MRK_FILTER_RANGE = 1, MRK_FILTER_FLOATRANGE = 2 }; /* SPH_FILTER_VALUES, SPH_FILTER_RANGE, SPH_FILTER_FLOATRANGE */
 #define MRK_MAX_FILTERS 2
 #define MRK_MAX_FILTER_VALUES 8
 typedef struct {
@@ -142,6 +142,9 @@ typedef struct {
   int64_t min_value, max_value; /* RANGE (SphAttr_t is signed 64-bit) */
   const int64_t* values;        /* VALUES: ascending (IFilter_Values::SetValues), <= MRK_MAX_FILTER_VALUES on the device */
   int32_t n_values;
+  /* FLOATRANGE over a 32-bit float attribute (Filter_FloatRange, sphinxfilter.cpp:275-300): the row's dword read as a float
+     (sphDW2F) against [fmin, fmax] with m_bHasEqualMin / Max; the reference's float filter has no open-sided form */
+  float fmin, fmax;
 } mrk_filter;
 
 /* CSphQuery fields that reach the ranker + the query tree */
@@ -162,6 +165,12 @@ typedef struct {
   int32_t cutoff;               /* CSphQuery::m_iCutoff; only 0 supported on device */
   const mrk_filter* filters;    /* CSphQuery::m_dFilters resolved against the schema; needs mrk_segment_set_attrs */
   int32_t n_filters;            /* <= MRK_MAX_FILTERS on the device */
+  /* CSphQueryContext::m_pWeightFilter: filters on the match weight ('WHERE weight() >= N'; Filter_WeightValues /
+     Filter_WeightRange, sphinxfilter.cpp:304-320), applied after index_weight and before the sorter (MatchExtended,
+     sphinx.cpp:12220-12227); matches they drop are not counted.  kind VALUES / RANGE, exclude, has_equal_min / max;
+     the locator fields are ignored.  All must pass. */
+  const mrk_filter* weight_filters;
+  int32_t n_weight_filters;     /* <= MRK_MAX_FILTERS on the device */
 } mrk_query;
 
 typedef struct {

@@ -46,7 +46,8 @@ class Filter(C.Structure):
     """mrk_filter (include/mrk.h)"""
     _fields_ = [("kind", C.c_int32), ("bit_offset", C.c_int32), ("bit_count", C.c_int32), ("exclude", C.c_int32),
                 ("has_equal_min", C.c_int32), ("has_equal_max", C.c_int32), ("open_left", C.c_int32), ("open_right", C.c_int32),
-                ("min_value", C.c_int64), ("max_value", C.c_int64), ("values", C.POINTER(C.c_int64)), ("n_values", C.c_int32)]
+                ("min_value", C.c_int64), ("max_value", C.c_int64), ("values", C.POINTER(C.c_int64)), ("n_values", C.c_int32),
+                ("fmin", C.c_float), ("fmax", C.c_float)]
 
 
 class Query(C.Structure):
@@ -55,7 +56,7 @@ class Query(C.Structure):
                 ("field_weights", C.POINTER(C.c_int32)), ("n_weights", C.c_int32), ("index_weight", C.c_int32),
                 ("plain_idf", C.c_int32), ("normalized_tfidf", C.c_int32), ("total_docs_override", C.c_int64),
                 ("local_docs", C.POINTER(C.c_int64)), ("cutoff", C.c_int32), ("filters", C.POINTER(Filter)),
-                ("n_filters", C.c_int32)]
+                ("n_filters", C.c_int32), ("weight_filters", C.POINTER(Filter)), ("n_weight_filters", C.c_int32)]
 
 
 class Result(C.Structure):

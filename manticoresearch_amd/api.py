@@ -266,12 +266,16 @@ class Filter:
     has_equal_max: bool = True
     open_left: bool = False
     open_right: bool = False
+    fmin: Optional[float] = None  # both set => SPH_FILTER_FLOATRANGE over a 32-bit float attribute
+    fmax: Optional[float] = None
 
     def as_dict(self) -> dict:  # the oracle's spelling
         d = dict(bit_offset=self.bit_offset, bit_count=self.bit_count, exclude=self.exclude, has_equal_min=self.has_equal_min,
                  has_equal_max=self.has_equal_max, open_left=self.open_left, open_right=self.open_right, min=self.min, max=self.max)
         if self.values is not None:
             d["values"] = list(self.values)
+        if self.fmin is not None:
+            d["fmin"], d["fmax"] = float(self.fmin), float(self.fmax)
         return d
 
 
@@ -289,6 +293,7 @@ class Query:
     local_docs: Optional[Dict[int, int]] = None  # local_df: term id -> global docs
     cutoff: int = 0
     filters: Optional[Sequence["Filter"]] = None  # CSphQuery::m_dFilters, resolved to attribute locators
+    weight_filters: Optional[Sequence["Filter"]] = None  # filters on the match weight (m_pWeightFilter); locator fields unused
 
 
 class _CQueries:
@@ -337,10 +342,12 @@ class _CQueries:
                 c.local_docs = ld
                 self.keep.append(ld)
             c.cutoff = q.cutoff
-            if q.filters:
-                fl = (_lib.Filter * len(q.filters))()
-                for i, f in enumerate(q.filters):
-                    fl[i].kind = 0 if f.values is not None else 1
+            def fill(fs):
+                fl = (_lib.Filter * len(fs))()
+                for i, f in enumerate(fs):
+                    fl[i].kind = 0 if f.values is not None else 2 if f.fmin is not None else 1
+                    if f.fmin is not None:
+                        fl[i].fmin, fl[i].fmax = float(f.fmin), float(f.fmax)
                     fl[i].bit_offset, fl[i].bit_count, fl[i].exclude = f.bit_offset, f.bit_count, int(f.exclude)
                     fl[i].has_equal_min, fl[i].has_equal_max = int(f.has_equal_min), int(f.has_equal_max)
                     fl[i].open_left, fl[i].open_right = int(f.open_left), int(f.open_right)
@@ -350,7 +357,12 @@ class _CQueries:
                         self.keep.append(vals)
                         fl[i].values, fl[i].n_values = vals, len(f.values)
                 self.keep.append(fl)
-                c.filters, c.n_filters = fl, len(q.filters)
+                return fl
+
+            if q.filters:
+                c.filters, c.n_filters = fill(q.filters), len(q.filters)
+            if q.weight_filters:
+                c.weight_filters, c.n_weight_filters = fill(q.weight_filters), len(q.weight_filters)
             self.keep += [cn, ch]
 
 

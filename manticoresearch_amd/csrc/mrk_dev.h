@@ -75,10 +75,34 @@ __device__ __forceinline__ bool row_passes_filters(const DevSegment& seg, const 
     if ((F.kind & 0xffu) == MRK_FILTER_VALUES) {
       pass = false;
       for (uint32_t k = 0; k < F.n_values; ++k) pass = pass || v == F.values[k];
+    } else if ((F.kind & 0xffu) == MRK_FILTER_FLOATRANGE) { // Filter_FloatRange::Eval (sphinxfilter.cpp:286-289): both bounds, always
+      const float fv = __uint_as_float((uint32_t)v), flo = __uint_as_float((uint32_t)F.lo), fhi = __uint_as_float((uint32_t)F.hi);
+      const bool eq_min = (F.kind >> 9) & 1u, eq_max = (F.kind >> 10) & 1u;
+      pass = (eq_min ? fv >= flo : fv > flo) && (eq_max ? fv <= fhi : fv < fhi);
     } else {
       const bool eq_min = (F.kind >> 9) & 1u, eq_max = (F.kind >> 10) & 1u, open_l = (F.kind >> 11) & 1u, open_r = (F.kind >> 12) & 1u;
       const bool min_ok = eq_min ? v >= F.lo : v > F.lo, max_ok = eq_max ? v <= F.hi : v < F.hi;
       pass = open_l ? max_ok : open_r ? min_ok : (min_ok && max_ok);
+    }
+    if ((F.kind >> 8) & 1u) pass = !pass;
+    ok = ok && pass;
+  }
+  return ok;
+}
+
+// CSphQueryContext::m_pWeightFilter: Filter_WeightValues / Filter_WeightRange over the match weight (sphinxfilter.cpp:304-320)
+__device__ __forceinline__ bool weight_passes_filters(const DevFilter* __restrict__ fl, uint32_t n, int32_t weight) {
+  bool ok = true;
+  const int64_t v = (int64_t)weight;
+  for (uint32_t i = 0; i < n; ++i) {
+    const DevFilter& F = fl[i];
+    bool pass;
+    if ((F.kind & 0xffu) == MRK_FILTER_VALUES) {
+      pass = false;
+      for (uint32_t k = 0; k < F.n_values; ++k) pass = pass || v == F.values[k];
+    } else {
+      const bool eq_min = (F.kind >> 9) & 1u, eq_max = (F.kind >> 10) & 1u;
+      pass = (eq_min ? v >= F.lo : v > F.lo) && (eq_max ? v <= F.hi : v < F.hi);
     }
     if ((F.kind >> 8) & 1u) pass = !pass;
     ok = ok && pass;
@@ -169,6 +193,8 @@ struct DevQuery {
   uint32_t nn_a, nn_b, nn_dist;       // TF_NOTNEAR: keyword slots of the must / not side, the distance
   uint32_t max_qpos, n_qwords;        // ExtRanker_c::m_iMaxQpos (largest query position) / m_iQwords (distinct words)
   uint32_t gen_prog;                  // TF_GEN: index of the pass's GenProg
+  uint32_t n_wfilters;                // filters on the match weight (m_pWeightFilter): all must pass, else the match is not one
+  DevFilter wfilters[MRK_MAX_FILTERS];
   int32_t weights[32];
   DevTerm t[MRK_MAX_AND_TERMS];
 };

@@ -887,7 +887,7 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
       b->h_queries.p[i].n_terms = 0;
     }
     max_terms = std::max(max_terms, b->h_queries.p[i].n_terms);
-    any_ext = any_ext || (b->h_queries.p[i].tree_flags & (mrk::TF_TERMPOS | mrk::TF_ORDER | mrk::TF_PHRASE_LEAF | mrk::TF_NOTNEAR)) != 0 || b->h_queries.p[i].n_filters != 0;
+    any_ext = any_ext || (b->h_queries.p[i].tree_flags & (mrk::TF_TERMPOS | mrk::TF_ORDER | mrk::TF_PHRASE_LEAF | mrk::TF_NOTNEAR)) != 0 || b->h_queries.p[i].n_filters != 0 || b->h_queries.p[i].n_wfilters != 0;
     b->h_list_first.p[i] = b->h_queries.p[i].item_first;
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;

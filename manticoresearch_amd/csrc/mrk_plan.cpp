@@ -803,7 +803,9 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       const mrk_filter& f = q.filters[i];
       DevFilter& d = dq.filters[i];
       memset(&d, 0, sizeof d);
-      if (f.kind != MRK_FILTER_VALUES && f.kind != MRK_FILTER_RANGE) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: filter kind %d not on the device path", qi, f.kind);
+      if (f.kind != MRK_FILTER_VALUES && f.kind != MRK_FILTER_RANGE && f.kind != MRK_FILTER_FLOATRANGE)
+        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: filter kind %d not on the device path", qi, f.kind);
+      if (f.kind == MRK_FILTER_FLOATRANGE && f.bit_count != 32) return mrk_fail(MRK_E_INVAL, "query %u: a float filter needs a 32-bit attribute", qi);
       const bool wide = f.bit_count == 64;
       if (f.bit_offset < 0 || f.bit_count < 1 || (!wide && (f.bit_count > 32 || (f.bit_offset & 31) + f.bit_count > 32)) || (wide && (f.bit_offset & 31)) ||
           (uint64_t)(f.bit_offset + f.bit_count) > (uint64_t)seg->dev.attr_stride * 32)
@@ -814,6 +816,11 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       d.shift = (uint32_t)f.bit_offset & 31u;
       d.bits = (uint32_t)f.bit_count;
       d.lo = f.min_value, d.hi = f.max_value;
+      if (f.kind == MRK_FILTER_FLOATRANGE) { // the bounds travel as their bit patterns
+        uint32_t lo_bits, hi_bits;
+        memcpy(&lo_bits, &f.fmin, 4), memcpy(&hi_bits, &f.fmax, 4);
+        d.lo = lo_bits, d.hi = hi_bits;
+      }
       if (f.kind == MRK_FILTER_VALUES) {
         if (f.n_values < 1 || !f.values) return mrk_fail(MRK_E_INVAL, "query %u: values filter without values", qi);
         if (f.n_values > MRK_MAX_FILTER_VALUES) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d filter values (device path: <= %d)", qi, f.n_values, MRK_MAX_FILTER_VALUES);
@@ -822,6 +829,28 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       }
     }
     dq.n_filters = (uint32_t)q.n_filters;
+  }
+  // filters on the match weight (m_pWeightFilter): evaluated where a match's weight is final
+  dq.n_wfilters = 0;
+  if (q.n_weight_filters < 0 || (q.n_weight_filters > 0 && !q.weight_filters)) return mrk_fail(MRK_E_INVAL, "query %u: bad weight filter list", qi);
+  if (q.n_weight_filters > 0) {
+    if (!use_packed) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: weight filters run on the packed path only", qi);
+    if (q.n_weight_filters > MRK_MAX_FILTERS) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d weight filters (device path: <= %d)", qi, q.n_weight_filters, MRK_MAX_FILTERS);
+    for (int i = 0; i < q.n_weight_filters; ++i) {
+      const mrk_filter& f = q.weight_filters[i];
+      DevFilter& d = dq.wfilters[i];
+      memset(&d, 0, sizeof d);
+      if (f.kind != MRK_FILTER_VALUES && f.kind != MRK_FILTER_RANGE) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: weight filter kind %d", qi, f.kind);
+      d.kind = (uint32_t)f.kind | (f.exclude ? 1u << 8 : 0) | (f.has_equal_min ? 1u << 9 : 0) | (f.has_equal_max ? 1u << 10 : 0);
+      d.lo = f.min_value, d.hi = f.max_value;
+      if (f.kind == MRK_FILTER_VALUES) {
+        if (f.n_values < 1 || !f.values) return mrk_fail(MRK_E_INVAL, "query %u: values filter without values", qi);
+        if (f.n_values > MRK_MAX_FILTER_VALUES) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d filter values (device path: <= %d)", qi, f.n_values, MRK_MAX_FILTER_VALUES);
+        d.n_values = (uint32_t)f.n_values;
+        for (int k = 0; k < f.n_values; ++k) d.values[k] = f.values[k];
+      }
+    }
+    dq.n_wfilters = (uint32_t)q.n_weight_filters;
   }
 
   // IDFs: distinct words in GetQwords traversal order (searchnode.cpp:2029-2055, 3276-3286)
@@ -970,7 +999,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   tree_out = tree_out || !pure_and;
 
   // two dense keywords: the bitmap kernel (mrk_scan_bm.hip) walks 2048-rowid windows instead of blocks
-  if (use_packed && pure_and && !T.phrase && n == 2 && q.n_filters == 0 && (ranker == MRK_RANK_NONE || ranker == MRK_RANK_BM25) && seg->dev.bm &&
+  if (use_packed && pure_and && !T.phrase && n == 2 && q.n_filters == 0 && q.n_weight_filters == 0 && (ranker == MRK_RANK_NONE || ranker == MRK_RANK_BM25) && seg->dev.bm &&
       seg->ctx->bitmap_inv > 0 && seg->terms[T.kws[0].term_id].bm_off != ~0ull && seg->terms[T.kws[1].term_id].bm_off != ~0ull) {
     dq.n_terms = 2;
     for (int i = 0; i < 2; ++i) fill_term(seg, T.kws[i], dq.t[i]);
@@ -997,7 +1026,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   {
     const uint32_t all_fields = seg->n_fields >= 32 ? 0xFFFFFFFFu : (1u << seg->n_fields) - 1u;
     bool ok = use_packed && seg->dev.bm && seg->ctx->bitmap_inv > 0 && seg->ctx->bt_cover_inv > 0 && !T.gen && !T.phrase && !T.ph_leaf && !T.quorum && !T.order &&
-              !T.termpos && !T.notnear && q.n_filters == 0 && n <= MAX_PROX_TERMS && seg->total_docs < (1ull << 32) && T.nodes.size() <= 16;
+              !T.termpos && !T.notnear && q.n_filters == 0 && q.n_weight_filters == 0 && n <= MAX_PROX_TERMS && seg->total_docs < (1ull << 32) && T.nodes.size() <= 16;
     uint64_t cover_docs = 0;
     for (int k : cover) cover_docs += (uint64_t)T.kws[k].docs;
     ok = ok && cover_docs * (uint64_t)seg->ctx->bt_cover_inv >= seg->total_docs;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
     GA.cap = gl < a.gen.n_lanes ? a.gen.lane_hits : 0u;
     GA.spill = a.gen.spill, GA.spill_cap = a.gen.spill_cap, GA.spill_used = a.gen.spill_used;
   }
-  uint32_t qc_gen_prog = 0;
+  uint32_t qc_gen_prog = 0, qc_nwf = 0;
 
   // virtual -> physical chunk: the shard whose prefix range holds it (uniform binary search over 65 LDS words)
   auto chunk_of = [&](uint32_t vc) -> uint32_t {
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
       qc_nw = U(Q->n_weights < 8u ? Q->n_weights : 8u);
       qc_max_qpos = U(Q->max_qpos), qc_n_qwords = U(Q->n_qwords);
       qc_gen_prog = GEN ? U(Q->gen_prog) : 0u;
+      qc_nwf = U(Q->n_wfilters);
 #pragma unroll
       for (int t = 0; t < MAX_PROX_TERMS; ++t) {
         HC.tb[t] = U(Q->t[t].blk_first), HC.tq[t] = U(Q->t[t].qpos), HC.tm[t] = U(Q->t[t].queried32);
@@ -310,9 +311,8 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
     // the match: weight, pruning bin, candidate buffer (emit_match of scan_pk_kernel)
     bool push = false;
     uint64_t key = 0;
+    uint32_t weight = 0;
     if (is_live) {
-      ++total;
-      uint32_t weight;
       if (ranker == MRK_RANK_NONE)
         weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
       else if (prox_ranker) {
@@ -332,6 +332,10 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
         weight = ranker == MRK_RANK_PROXIMITY ? rsum : (uint32_t)bm + rsum * 1000u;
       }
       weight *= qc_index_weight; // MatchExtended, sphinx.cpp:12220
+      if (qc_nwf && !weight_passes_filters((a.queries + cur_pass)->wfilters, qc_nwf, (int32_t)weight)) is_live = false; // m_pWeightFilter (:12223-12227)
+    }
+    if (is_live) {
+      ++total;
       const uint32_t grow = a.seg.rowid_base + rowid;
       if (bin_of(bin_mode, bin_lo, bin_shift, (int32_t)weight, grow) >= tau_bin) {
         push = true;

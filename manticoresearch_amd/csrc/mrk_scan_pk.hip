@@ -188,9 +188,8 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   auto emit_match = [&](bool is_live, uint32_t rowid, float tfidf, uint32_t fields, int rk) {
     bool push = false;
     uint64_t key = 0;
+    uint32_t weight = 0;
     if (is_live) {
-      ++total;
-      uint32_t weight;
       if (ranker == MRK_RANK_NONE)
         weight = 1u; // ExtRanker_None_c, sphinxsearch.cpp:1160
       else if (PROX && prox_ranker) {
@@ -205,6 +204,10 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         weight = (uint32_t)bm + s.rank[fields] * 1000u;
       }
       weight *= index_weight; // MatchExtended, sphinx.cpp:12220
+      if (EXT && Q->n_wfilters && !weight_passes_filters(Q->wfilters, Q->n_wfilters, (int32_t)weight)) is_live = false; // m_pWeightFilter (:12223-12227)
+    }
+    if (is_live) {
+      ++total;
       const uint32_t grow = rowid_base + rowid;
       const uint32_t bin = bin_of(bin_mode, bin_lo, bin_shift, (int32_t)weight, grow);
 #if MRK_EXP != 1 && MRK_EXP != 6 && MRK_EXP != 7

@@ -2438,6 +2438,11 @@ static int filters_pass(const orc_index* idx, const orc_query* q, uint32_t rowid
         else
           hi = mid - 1;
       }
+    } else if (f->kind == ORC_FILTER_FLOATRANGE) { /* Filter_FloatRange::Eval (sphinxfilter.cpp:286-289): sphDW2F of the dword, both bounds */
+      float fv;
+      const uint32_t bits = (uint32_t)v;
+      memcpy(&fv, &bits, 4);
+      pass = (f->has_equal_min ? fv >= f->fmin : fv > f->fmin) && (f->has_equal_max ? fv <= f->fmax : fv < f->fmax);
     } else {
       const int min_ok = f->has_equal_min ? v >= f->min_value : v > f->min_value;
       const int max_ok = f->has_equal_max ? v <= f->max_value : v < f->max_value;
@@ -2586,6 +2591,21 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
     /* MatchExtended (sphinx.cpp:12211-12263): dead rows never reach the sorter (:12213-12217) */
     if (idx->dead_rows && (idx->dead_rows[root->rowid >> 5] >> (root->rowid & 31u)) & 1u) continue;
     weight = (int)((uint32_t)weight * (uint32_t)index_weight);
+    { /* m_pWeightFilter (sphinx.cpp:12223-12227): Filter_WeightValues / Filter_WeightRange (sphinxfilter.cpp:304-320) */
+      int ok = 1;
+      for (int i = 0; i < q->n_weight_filters && ok; i++) {
+        const orc_filter* f = &q->weight_filters[i];
+        const int64_t v = (int64_t)weight;
+        int pass = 0;
+        if (f->kind == ORC_FILTER_VALUES) {
+          for (int k = 0; k < f->n_values; k++) pass = pass || f->values[k] == v;
+        } else
+          pass = (f->has_equal_min ? v >= f->min_value : v > f->min_value) && (f->has_equal_max ? v <= f->max_value : v < f->max_value);
+        if (f->exclude) pass = !pass;
+        ok = pass;
+      }
+      if (!ok) continue;
+    }
     match_t m = {root->rowid, weight};
     mq_push(&mq, &m);
     if (--cutoff == 0) break;

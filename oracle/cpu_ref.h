@@ -109,7 +109,7 @@ typedef struct {
 } orc_index;
 
 /* CSphFilterSettings over an integer attribute (sphinx.h:2461-2496), resolved to the attribute's locator */
-enum { ORC_FILTER_VALUES = 0, ORC_FILTER_RANGE = 1 };
+enum { ORC_FILTER_VALUES = 0, ORC_FILTER_RANGE = 1, ORC_FILTER_FLOATRANGE = 2 };
 typedef struct {
   int kind;
   int bit_offset, bit_count; /* CSphAttrLocator */
@@ -118,6 +118,7 @@ typedef struct {
   int64_t min_value, max_value;
   const int64_t* values; /* ascending */
   int n_values;
+  float fmin, fmax; /* FLOATRANGE */
 } orc_filter;
 
 /* ---- query tree ---- */
@@ -156,6 +157,8 @@ typedef struct {
   int cutoff;          /* 0 = none */
   const orc_filter* filters; /* all must pass (Filter_And) */
   int n_filters;
+  const orc_filter* weight_filters; /* m_pWeightFilter: VALUES / RANGE over the match weight */
+  int n_weight_filters;
 } orc_query;
 
 typedef struct {

@@ -57,7 +57,8 @@ class _Node(C.Structure):
 class _Filter(C.Structure):
     _fields_ = [("kind", C.c_int), ("bit_offset", C.c_int), ("bit_count", C.c_int), ("exclude", C.c_int),
                 ("has_equal_min", C.c_int), ("has_equal_max", C.c_int), ("open_left", C.c_int), ("open_right", C.c_int),
-                ("min_value", C.c_int64), ("max_value", C.c_int64), ("values", C.POINTER(C.c_int64)), ("n_values", C.c_int)]
+                ("min_value", C.c_int64), ("max_value", C.c_int64), ("values", C.POINTER(C.c_int64)), ("n_values", C.c_int),
+                ("fmin", C.c_float), ("fmax", C.c_float)]
 
 
 class _Query(C.Structure):
@@ -65,7 +66,8 @@ class _Query(C.Structure):
                 ("root", C.c_int), ("ranker", C.c_int), ("max_matches", C.c_int),
                 ("field_weights", C.POINTER(C.c_int32)), ("n_weights", C.c_int), ("index_weight", C.c_int),
                 ("plain_idf", C.c_int), ("normalized_tfidf", C.c_int), ("total_docs_override", C.c_int64),
-                ("local_docs", C.POINTER(C.c_int64)), ("cutoff", C.c_int), ("filters", C.POINTER(_Filter)), ("n_filters", C.c_int)]
+                ("local_docs", C.POINTER(C.c_int64)), ("cutoff", C.c_int), ("filters", C.POINTER(_Filter)), ("n_filters", C.c_int),
+                ("weight_filters", C.POINTER(_Filter)), ("n_weight_filters", C.c_int)]
 
 
 class _Result(C.Structure):
@@ -260,7 +262,8 @@ class FlatQuery:
     def __init__(self, root: QNode, ranker: int = RANK_BM25, max_matches: int = 1000,
                  field_weights: Optional[Sequence[int]] = None, index_weight: int = 1,
                  plain_idf: bool = False, normalized_tfidf: bool = True, total_docs_override: int = 0,
-                 local_docs: Optional[dict] = None, cutoff: int = 0, filters: Optional[Sequence[dict]] = None):
+                 local_docs: Optional[dict] = None, cutoff: int = 0, filters: Optional[Sequence[dict]] = None,
+                 weight_filters: Optional[Sequence[dict]] = None):
         nodes: List[QNode] = []
 
         def walk(n: QNode) -> int:
@@ -298,12 +301,14 @@ class FlatQuery:
             self.ld = (C.c_int64 * len(nodes))(*arr)
             q.local_docs = self.ld
         q.cutoff = cutoff
-        if filters:  # dicts with the fields of orc_filter; "values" = ascending ints
-            self.fl = (_Filter * len(filters))()
-            self.fv = []
-            for i, f in enumerate(filters):
-                c = self.fl[i]
-                c.kind = FILTER_VALUES if "values" in f else FILTER_RANGE
+        self.fv = []
+
+        def fill(fs):  # dicts with the fields of orc_filter; "values" = ascending ints, "fmin" / "fmax" = a float range
+            arr = (_Filter * len(fs))()
+            for i, f in enumerate(fs):
+                c = arr[i]
+                c.kind = FILTER_VALUES if "values" in f else 2 if "fmin" in f else FILTER_RANGE  # 2 = ORC_FILTER_FLOATRANGE
+                c.fmin, c.fmax = float(f.get("fmin", 0.0)), float(f.get("fmax", 0.0))
                 c.bit_offset, c.bit_count, c.exclude = f["bit_offset"], f["bit_count"], int(f.get("exclude", False))
                 c.has_equal_min, c.has_equal_max = int(f.get("has_equal_min", True)), int(f.get("has_equal_max", True))
                 c.open_left, c.open_right = int(f.get("open_left", False)), int(f.get("open_right", False))
@@ -312,7 +317,14 @@ class FlatQuery:
                     vals = (C.c_int64 * len(f["values"]))(*sorted(int(v) for v in f["values"]))
                     self.fv.append(vals)
                     c.values, c.n_values = vals, len(f["values"])
+            return arr
+
+        if filters:
+            self.fl = fill(filters)
             q.filters, q.n_filters = self.fl, len(filters)
+        if weight_filters:
+            self.wfl = fill(weight_filters)
+            q.weight_filters, q.n_weight_filters = self.wfl, len(weight_filters)
         self.q = q
         self.K = max_matches
 

@@ -40,7 +40,8 @@ def to_orc(orc, q):
     return orc.FlatQuery(conv(q.root), ranker=q.ranker, max_matches=q.max_matches, field_weights=q.field_weights,
                          index_weight=q.index_weight, plain_idf=q.plain_idf, normalized_tfidf=q.normalized_tfidf,
                          total_docs_override=q.total_docs, local_docs=q.local_docs,
-                         filters=[f.as_dict() for f in q.filters] if q.filters else None)
+                         filters=[f.as_dict() for f in q.filters] if q.filters else None,
+                         weight_filters=[f.as_dict() for f in q.weight_filters] if q.weight_filters else None)
 
 
 def check_batch(orc, dev, hi, queries, rowid_base=0):
@@ -1413,7 +1414,8 @@ def test_before_operator(orc, dev, block, fmt):
 
 # ------------------------------------------------------------------ attribute filters (EarlyReject)
 def test_attribute_filters(orc, dev):
-    """SPH_FILTER_VALUES / SPH_FILTER_RANGE over integer attributes of the row-wise storage (32-bit, 64-bit, bit fields),
+    """SPH_FILTER_VALUES / SPH_FILTER_RANGE over integer attributes of the row-wise storage (32-bit, 64-bit, bit fields) and
+    SPH_FILTER_FLOATRANGE over a float attribute (negative values, infinities, a NaN row: fails every bound),
     include / exclude, open ranges, strict bounds, two filters at once; with trees, phrases, every ranker and dead rows.
     Rejected rows are neither ranked nor counted (sphinxsearch.cpp:1055-1064, sphinx.cpp:11903-11917)."""
     m, ctx, batch = dev
@@ -1426,17 +1428,26 @@ def test_attribute_filters(orc, dev):
     nt = len(probs)
     hi = m.index_from_hits(W, R, H, n_terms=nt, total_docs=n_docs, n_fields=3)
     # rows: [id lo, id hi (64-bit id), gid (32-bit), flags: 3-bit field at bit 4 and 1-bit at bit 9 of dword 3, price (64-bit, signed use)]
-    rows = np.zeros((n_docs, 6), np.uint32)
+    rows = np.zeros((n_docs, 7), np.uint32)  # (dword 6: a float attribute)
     ids = np.arange(n_docs, dtype=np.uint64) * np.uint64(7) + np.uint64(1 << 33)
     rows[:, 0], rows[:, 1] = (ids & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ids >> np.uint64(32)).astype(np.uint32)
     rows[:, 2] = rng.integers(0, 50, n_docs)
     rows[:, 3] = (rng.integers(0, 8, n_docs) << 4) | (rng.integers(0, 2, n_docs) << 9) | (rng.integers(0, 16, n_docs)) | (rng.integers(0, 1 << 20, n_docs) << 10 << 1)
     price = rng.integers(-1000, 100000, n_docs).astype(np.int64)
     rows[:, 4], rows[:, 5] = (price.view(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32), (price.view(np.uint64) >> np.uint64(32)).astype(np.uint32)
+    score = (rng.normal(0.0, 50.0, n_docs)).astype(np.float32)
+    score[::997] = np.float32("inf")
+    score[5::1999] = np.float32("nan")
+    score[3::1013] = np.float32(-0.0)
+    rows[:, 6] = score.view(np.uint32)
     F = m.Filter
 
     def rand_filter():
-        k = int(rng.integers(0, 5))
+        k = int(rng.integers(0, 6))
+        if k == 5:
+            lo = float(np.float32(rng.normal(0.0, 40.0)))
+            return F(192, 32, fmin=lo if rng.random() < 0.9 else float("-inf"), fmax=float(np.float32(lo + abs(rng.normal(0.0, 60.0)))) if rng.random() < 0.9 else float("inf"),
+                     exclude=bool(rng.random() < 0.25), has_equal_min=bool(rng.random() < 0.7), has_equal_max=bool(rng.random() < 0.7))
         excl = bool(rng.random() < 0.25)
         if k == 0:
             return F(64, 32, values=sorted(set(int(v) for v in rng.integers(0, 50, int(rng.integers(1, 9))))), exclude=excl)
@@ -1459,7 +1470,14 @@ def test_attribute_filters(orc, dev):
         root = [kw(m, a, 1), m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), OR(m, kw(m, a, 1), kw(m, b, 2)), m.XQNode.AND(OR(m, kw(m, a, 1), kw(m, b, 2)), kw(m, c, 3)),
                 PHRASE(m, kw(m, a, 1), kw(m, b, 2)), ANDNOT(m, kw(m, a, 1), kw(m, b, 2))][shape]
         fl = [rand_filter() for _ in range(int(rng.integers(1, 3)))]
-        qs.append(m.Query(root, ranker=int(rng.choice(rankers)), max_matches=int(rng.choice([30, 1000])), filters=fl))
+        wf = None
+        if rng.random() < 0.35:  # a filter on the weight itself ('WHERE weight() ...'): m_pWeightFilter
+            lo = int(rng.integers(0, 3000))
+            wf = [F(0, 32, min=lo, max=lo + int(rng.integers(0, 4000)), exclude=bool(rng.random() < 0.3), has_equal_min=bool(rng.random() < 0.7))
+                  if rng.random() < 0.8 else F(0, 32, values=[1, 1500, 1551, 1577, 2500])]
+            if rng.random() < 0.3:
+                fl = None
+        qs.append(m.Query(root, ranker=int(rng.choice(rankers)), max_matches=int(rng.choice([30, 1000])), filters=fl, weight_filters=wf))
     seg = m.Segment(ctx, hi)
     oi = orc_index_of(orc, hi)
     oi.attrs = rows
