@@ -73,7 +73,10 @@ enum { MRK_OP_TERM = 0, MRK_OP_AND = 1, MRK_OP_OR = 2, MRK_OP_MAYBE = 3, MRK_OP_
        MRK_OP_BEFORE = 8, /* 'a << b << c' (ExtOrder_c): the children occur in this order inside one field */
        MRK_OP_QUORUM = 7, /* '"a b c"/N': opt = N (ExtQuorum_c; N = 1 / N >= words as the reference rewrites them) */
        MRK_OP_NEAR = 9,   /* 'a NEAR/N b' (ExtNWay_T<FSMmultinear_c>): opt = N; operands: keywords, phrases, nested NEARs; 3+ operands at the query root only */
-       MRK_OP_NOTNEAR = 10 /* 'a NOTNEAR/N b' (ExtNotNear_c): opt = N */ };
+       MRK_OP_NOTNEAR = 10, /* 'a NOTNEAR/N b' (ExtNotNear_c): opt = N */
+       MRK_OP_SENTENCE = 11, /* 'a SENTENCE b' (ExtUnit_c): both sides inside one sentence of an index_sp = 1 index; the node's term_id = the
+                                dictionary slot of the boundary keyword MAGIC_WORD_SENTENCE "\3sentence" (< 0: the index holds none: plain AND) */
+       MRK_OP_PARAGRAPH = 12 /* 'a PARAGRAPH b': the same over MAGIC_WORD_PARAGRAPH "\3paragraph" */ };
 
 enum { MRK_HITFMT_PLAIN = 0, MRK_HITFMT_INLINE = 1 }; /* ESphHitFormat */
 
@@ -113,7 +116,7 @@ typedef struct {
   int32_t op;          /* MRK_OP_* */
   int32_t n_children;
   int32_t first_child; /* offset into children[] */
-  int32_t term_id;     /* leaf: dictionary slot; < 0 = keyword not in the dictionary */
+  int32_t term_id;     /* leaf: dictionary slot; < 0 = keyword not in the dictionary.  SENTENCE / PARAGRAPH node: the boundary keyword's slot */
   int32_t atom_pos;    /* XQKeyword_t::m_iAtomPos */
   uint32_t field_mask; /* XQLimitSpec_t::m_dFieldMask, low dword */
   float boost;         /* XQKeyword_t::m_fBoost */
@@ -418,11 +421,12 @@ const uint32_t* mrk_host_index_dead_rows(const mrk_host_index* h, uint64_t* n_ro
    The caller side of the path: the extended query syntax (sphParseExtendedQuery: sphinxquery.y:57-125 grammar; the lexer
    XQParser_t::GetToken, sphinxquery.cpp:1201-1553; AddKeyword / AddOp, :1600-1678; FixupNots, :499-562) restated for the
    operators this library evaluates:  a b   a | b   a MAYBE b   -a  !a   ( )   "a b"   "a b"~N   "a b c"/N   "a b c"/0.5
-   a << b   a NEAR/N b   a NOTNEAR/N b   @field  @(f1,f2)  @!field  @!(f1,f2)  @*  @field[N]  @@relaxed   ^a  a$  =a  a^1.5
+   a << b   a NEAR/N b   a NOTNEAR/N b   a SENTENCE b   a PARAGRAPH b   @field  @(f1,f2)  @!field  @!(f1,f2)  @*  @field[N]  @@relaxed   ^a  a$  =a  a^1.5
    and '*' inside a phrase.  The result is the flat mrk_node[] + children[] form mrk_query takes (post-order, root last):
    query positions (atom_pos) in textual order, field limits as masks, NOT folded into ANDNOT, one-word phrases folded to
-   their word, fractional quorum thresholds resolved against the word count.  SENTENCE / PARAGRAPH / ZONE / ZONESPAN are
-   not recognised (their capitals read as keywords).
+   their word, fractional quorum thresholds resolved against the word count.  'a SENTENCE b' / 'a PARAGRAPH b' come back as
+   MRK_OP_SENTENCE / _PARAGRAPH nodes whose keyword text (mrk_parsed_keyword) is the boundary word "\3sentence" /
+   "\3paragraph" for the dictionary lookup.  ZONE / ZONESPAN are not recognised (their capitals read as keywords).
    Tokenizing is ASCII [A-Za-z0-9_] + bytes >= 0x80, lower-casing ASCII only -- a host with a charset_table, morphology,
    stopwords or wordforms runs its own tokenizer / dictionary over the keywords' text; what this entry point fixes is the
    grammar.  Words shorter than min_word_len (code points) are dropped and keep their position (overshort_step = 1).

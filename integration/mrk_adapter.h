@@ -101,7 +101,9 @@ inline int MrkOpOf ( XQOperator_e eOp )
 		case SPH_QUERY_QUORUM:		return MRK_OP_QUORUM;
 		case SPH_QUERY_NEAR:		return MRK_OP_NEAR;
 		case SPH_QUERY_NOTNEAR:		return MRK_OP_NOTNEAR;
-		default:					return -1;	// NOT, SENTENCE, PARAGRAPH, NULL, SCAN
+		case SPH_QUERY_SENTENCE:	return MRK_OP_SENTENCE;
+		case SPH_QUERY_PARAGRAPH:	return MRK_OP_PARAGRAPH;
+		default:					return -1;	// NOT, NULL, SCAN
 	}
 }
 
@@ -170,6 +172,14 @@ public:
 		tNode.n_children = dKids.GetLength();
 		tNode.first_child = m_tOut.m_dChildren.GetLength();
 		tNode.term_id = -1;
+		if ( iOp==MRK_OP_SENTENCE || iOp==MRK_OP_PARAGRAPH )
+		{
+			// the boundary keyword ExtUnit_c's ctor looks up (searchnode.cpp:4987-4989): MAGIC_WORD_SENTENCE / MAGIC_WORD_PARAGRAPH
+			XQKeyword_t tDot;
+			tDot.m_sWord = iOp==MRK_OP_SENTENCE ? MAGIC_WORD_SENTENCE : MAGIC_WORD_PARAGRAPH;
+			CSphString sDot;
+			tNode.term_id = MrkLookupTerm ( m_tIndex, m_tSetup, tDot, sDot );
+		}
 		tNode.field_mask = uMask;
 		tNode.boost = 1.0f;
 		tNode.opt = pNode->m_iOpArg;

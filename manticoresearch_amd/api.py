@@ -30,6 +30,7 @@ SPH_QUERY_QUORUM = 7     # '"a b c"/N': XQNode.opt = N
 SPH_QUERY_BEFORE = 8     # 'a << b << c' (ExtOrder_c)
 SPH_QUERY_NEAR = 9       # 'a NEAR/N b' (ExtNWay_T<FSMmultinear_c>): XQNode.opt = N
 SPH_QUERY_NOTNEAR = 10   # 'a NOTNEAR/N b' (ExtNotNear_c): XQNode.opt = N
+SPH_QUERY_SENTENCE, SPH_QUERY_PARAGRAPH = 11, 12  # 'a SENTENCE b' / 'a PARAGRAPH b' (ExtUnit_c): XQNode.unit_term = the index_sp boundary keyword
 SPH_HIT_FORMAT_PLAIN, SPH_HIT_FORMAT_INLINE = 0, 1
 ALL_FIELDS = 0xFFFFFFFF
 
@@ -198,6 +199,7 @@ class XQNode:
     field_mask: int = ALL_FIELDS   # m_dSpec.m_dFieldMask (low dword)
     opt: int = 0                   # m_iOpArg
     field_max_pos: int = 0         # m_dSpec.m_iFieldMaxPos: '@field[N] word'
+    unit_term: int = -1            # SENTENCE / PARAGRAPH: dictionary slot of MAGIC_WORD_SENTENCE / _PARAGRAPH (< 0: the index holds none)
 
     @staticmethod
     def keyword(term_id: int, atom_pos: int, field_mask: int = ALL_FIELDS, boost: float = 1.0, field_start: bool = False,
@@ -246,6 +248,9 @@ def parse_query(text: str, field_names: Sequence[str] = (), min_word_len: int = 
                 x.word.text = w
             else:
                 x = XQNode(m.op, [built[kids[m.first_child + j]] for j in range(m.n_children)], None, m.field_mask, m.opt)
+                if m.op in (SPH_QUERY_SENTENCE, SPH_QUERY_PARAGRAPH):
+                    w = L.mrk_parsed_keyword(pq, i).decode("utf-8")  # the boundary keyword's text
+                    x.unit_term = m.term_id if not callable(lookup) else int(lookup(w))
             built.append(x)
         return built[root]
     finally:
@@ -324,7 +329,7 @@ class _CQueries:
                     cn[i].term_id, cn[i].atom_pos, cn[i].boost = n.word.term_id, n.word.atom_pos, n.word.boost
                     cn[i].term_pos, cn[i].field_max_pos = n.term_pos(), n.field_max_pos
                 else:
-                    cn[i].term_id, cn[i].boost = -1, 1.0
+                    cn[i].term_id, cn[i].boost = n.unit_term, 1.0
             ch = (C.c_int32 * max(1, len(flat)))(*flat)
             c = self.arr[qi]
             c.nodes, c.n_nodes, c.children, c.root = cn, len(nodes), ch, 0
@@ -566,6 +571,6 @@ def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool =
 
 __all__ = ["SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
-           "parse_query", "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE", "SPH_QUERY_NEAR", "SPH_QUERY_NOTNEAR",
+           "parse_query", "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE", "SPH_QUERY_NEAR", "SPH_QUERY_NOTNEAR", "SPH_QUERY_SENTENCE", "SPH_QUERY_PARAGRAPH",
            "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Filter", "Matches", "Context",
            "Segment", "Batch", "prepare", "idf", "MrkError", "validate_index", "pair_stats"]

@@ -230,7 +230,7 @@ struct MatchQueue {
 constexpr int GEN_MAX_NODES = 24;
 constexpr int MQ_GEN_PLANES = 1 + MRK_MAX_AND_TERMS; // queue 2: rowid + one packed-array reference per keyword slot
 constexpr uint32_t GN_TERM = 0, GN_MULTIAND = 1, GN_AND = 2, GN_OR = 3, GN_MAYBE = 4, GN_ANDNOT = 5, GN_PHRASE = 6, GN_PROX = 7, GN_NEAR = 8, GN_QUORUM = 9,
-                   GN_ORDER = 10, GN_NOTNEAR = 11;
+                   GN_ORDER = 10, GN_NOTNEAR = 11, GN_UNIT = 12;
 struct GenNode {
   uint8_t kind;     // GN_*
   uint8_t n_kids;
@@ -238,7 +238,7 @@ struct GenNode {
   uint8_t n_words;  // PHRASE / PROX: words
   uint16_t npl, npr; // AND: node positions its sides' hits are relabelled with (0 = keep)
   uint8_t kid[8];   // child node indices; TERM: [0] = keyword slot; MULTIAND / QUORUM: keyword slots; PHRASE / PROX / NEAR: [0] = the operands' AND chain
-  uint8_t aux[8];   // MULTIAND: node position per keyword; PHRASE / PROX: the words' keyword slots in phrase order
+  uint8_t aux[8];   // MULTIAND: node position per keyword; PHRASE / PROX: the words' keyword slots in phrase order; UNIT: [0] = the boundary keyword's slot (0xFF: none)
   int32_t opt;      // distance / threshold
   uint32_t pad;
 };

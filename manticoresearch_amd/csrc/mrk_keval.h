@@ -253,6 +253,53 @@ __device__ inline bool gen_eval(const DevSegment& seg, const DevQuery* __restric
         R.ok = n != 0;
         break;
       }
+      case GN_UNIT: {
+        // ExtUnit_c, SENTENCE / PARAGRAPH (searchnode.cpp:4983-5310): both arguments hold the doc; where it also holds boundary hits
+        // ("dots", the index_sp keyword, limited to the node's fields), only hit pairs no dot separates match and the hits of
+        // every matching unit are copied (FilterHits :5082-5166); positions compare raw, as Hitpos_t does
+        const GenRes &L = res[N.kid[0]], &Rr = res[N.kid[1]];
+        if (!(L.ok && Rr.ok)) break;
+        GenRes D;
+        D.p = nullptr, D.n = 0, D.ok = false;
+        if (N.aux[0] != 0xFFu) gen_term(seg, Q->t[N.aux[0]], refs[N.aux[0]], row, A, D);
+        if (A.failed) break;
+        GenHit* out = A.take(L.n + Rr.n);
+        if (!out) break;
+        const uint32_t nd = D.ok ? D.n : 0u;
+        uint32_t i1 = 0, i2 = 0, id = 0, n = 0, end = nd ? 0u : 0xFFFFFFFFu;
+        for (;;) {
+          if (end) { // in a matched unit: copy hits up to the next dot
+            const bool v1 = i1 < L.n && L.p[i1].hitpos < end, v2 = i2 < Rr.n && Rr.p[i2].hitpos < end;
+            if (!v1 && !v2) {
+              end = 0;
+              if (i1 < L.n && i2 < Rr.n) continue;
+              break;
+            }
+            out[n++] = (v1 && (!v2 || gen_hit_less(L.p[i1], Rr.p[i2]))) ? L.p[i1++] : Rr.p[i2++];
+          } else {
+            if (i1 >= L.n || i2 >= Rr.n) break;
+            const uint32_t a = L.p[i1].hitpos, b = Rr.p[i2].hitpos, umin = a < b ? a : b, umax = a < b ? b : a;
+            while (id < nd && D.p[id].hitpos <= umin) ++id;
+            if (id >= nd) { // no dot past the pair's start: a match, copy to the doc's end
+              end = 0xFFFFFFFFu;
+              continue;
+            }
+            const uint32_t dp = D.p[id].hitpos;
+            if (dp < umax) { // "A dot B": both sides move past this dot
+              while (i1 < L.n && L.p[i1].hitpos <= dp) ++i1;
+              if (i1 >= L.n) break;
+              while (i2 < Rr.n && Rr.p[i2].hitpos <= dp) ++i2;
+              if (i2 >= Rr.n) break;
+              continue;
+            }
+            while (id < nd && D.p[id].hitpos <= umax) ++id;
+            end = id >= nd ? 0xFFFFFFFFu : D.p[id].hitpos;
+          }
+        }
+        if (!n) break;
+        R.p = out, R.n = n, R.ok = true, R.fields = L.fields | Rr.fields, R.tfidf = L.tfidf + Rr.tfidf;
+        break;
+      }
       case GN_PHRASE: {
         // ExtNWay_T<FSMphrase_c>: the words' AND chain (kid 0) through the phrase state machine (HitFSM :3901-3947)
         const GenRes& I = res[N.kid[0]];

@@ -60,6 +60,7 @@ struct PlanKw { // one keyword occurrence of the query tree
   int atom_pos;
   int tp_kind, tp_max; // MRK_TERMPOS_*
   bool weighted_first; // first node of its word in GetQwords order gets the IDF, later dupes get 0
+  bool hidden = false; // the boundary keyword of a SENTENCE / PARAGRAPH node: read for its hits, not a query word (bNotWeighted, no IDF, no query position)
 };
 
 struct PlanNode { // binary eval-tree node, post-order
@@ -562,6 +563,33 @@ static int build_gen(const mrk_segment* seg, const mrk_query& q, int32_t ni, Pla
       }
       return cur;
     }
+    case MRK_OP_SENTENCE:
+    case MRK_OP_PARAGRAPH: { // generic create (:1785-1803): pCur = new ExtUnit_c ( pCur, pNext, fields, setup, MAGIC_WORD_... )
+      int cur = -1;
+      for (int i = 0; i < n.n_children; ++i) {
+        const int c = build_gen(seg, q, kids[i], T, G, qi, depth + 1, err);
+        if (c < 0) return -1;
+        cur = cur < 0 ? c : twofer(GN_UNIT, PN_AND, cur, c);
+        if (G.prog.nodes[cur].kind == GN_UNIT && cur != c) G.prog.nodes[cur].aux[0] = 0xFF;
+      }
+      if (n.term_id >= 0 && (uint32_t)n.term_id < seg->terms.size() && seg->terms[n.term_id].docs) {
+        // the boundary keyword: one slot, located for every candidate (MAYBE: a doc without boundaries is a plain AND)
+        PlanKw k{};
+        k.term_id = n.term_id, k.node = ni, k.docs = (int)seg->terms[n.term_id].docs, k.boost = 1.0f, k.queried32 = n.field_mask, k.hidden = true;
+        T.kws.push_back(k);
+        PlanNode pn;
+        pn.op = PN_TERM;
+        pn.kw = (int)T.kws.size() - 1;
+        T.nodes.push_back(pn);
+        const int dot_plan = (int)T.nodes.size() - 1;
+        for (uint32_t g = 0; g < G.prog.n_nodes; ++g)
+          if (G.prog.nodes[g].kind == GN_UNIT && G.prog.nodes[g].aux[0] == 0xFF && G.prog.nodes[g].aux[1] == 0) G.prog.nodes[g].aux[0] = (uint8_t)pn.kw, G.prog.nodes[g].aux[1] = 1;
+        G.plan[cur] = pjoin(PN_MAYBE, G.plan[cur], dot_plan);
+      } else
+        for (uint32_t g = 0; g < G.prog.n_nodes; ++g)
+          if (G.prog.nodes[g].kind == GN_UNIT && G.prog.nodes[g].aux[0] == 0xFF) G.prog.nodes[g].aux[1] = 1; // (settled: no boundary keyword)
+      return cur;
+    }
     case MRK_OP_OR:
     case MRK_OP_MAYBE:
     case MRK_OP_ANDNOT:
@@ -856,12 +884,18 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   // IDFs: distinct words in GetQwords traversal order (searchnode.cpp:2029-2055, 3276-3286)
   IntVec words;
   for (int i = 0; i < n; ++i) {
+    if (T.kws[i].hidden) { // read for its hits only
+      T.kws[i].weighted_first = false;
+      continue;
+    }
     bool seen = false;
     for (int w : words) seen |= T.kws[i].term_id >= 0 && T.kws[w].term_id == T.kws[i].term_id; // words missing from the dictionary are distinct words
     T.kws[i].weighted_first = !seen;
     if (!seen) words.push_back(i);
   }
-  const bool got_dupes = (int)words.size() != n; // HasQwordDupes: proximity rankers switch to their HANDLE_DUPES update
+  int n_visible = 0;
+  for (const PlanKw& k : T.kws) n_visible += k.hidden ? 0 : 1;
+  const bool got_dupes = (int)words.size() != n_visible; // HasQwordDupes: proximity rankers switch to their HANDLE_DUPES update
   const int64_t total_docs = q.total_docs_override > 0 ? q.total_docs_override : (int64_t)seg->total_docs;
   for (int w : words) {
     PlanKw& t = T.kws[w];
@@ -873,7 +907,8 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   dq.ranker = ranker;
   dq.n_qwords = (uint32_t)words.size(); // ExtRanker_c::m_iQwords (sphinxsearch.cpp:730-731)
   dq.max_qpos = 0;                      // ... m_iMaxQpos = GetQwords() (:4294-4296, 4372)
-  for (const PlanKw& k : T.kws) dq.max_qpos = std::max<uint32_t>(dq.max_qpos, (uint32_t)std::max(k.atom_pos, 0));
+  for (const PlanKw& k : T.kws)
+    if (!k.hidden) dq.max_qpos = std::max<uint32_t>(dq.max_qpos, (uint32_t)std::max(k.atom_pos, 0));
   dq.k = (uint32_t)q.max_matches;
   dq.n_weights = seg->n_fields;
   dq.index_weight = (uint32_t)(q.index_weight ? q.index_weight : 1);
@@ -1111,6 +1146,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
           for (int k = 0; k < g.n_kids; ++k) g.kid[k] = (uint8_t)slot[g.kid[k]];
         if (g.kind == GN_PHRASE || g.kind == GN_PROX)
           for (int k = 0; k < g.n_words; ++k) g.aux[k] = (uint8_t)slot[g.aux[k]];
+        if (g.kind == GN_UNIT && g.aux[0] != 0xFF) g.aux[0] = (uint8_t)slot[g.aux[0]];
       }
       P->gen_prog = (uint32_t)gen_progs.size();
       gen_progs.push_back(gp);

@@ -5,7 +5,7 @@
 // path evaluates:
 //
 //   keywords (implicit AND)   a | b   a MAYBE b   -a / !a   ( ... )   "a b c"   "a b"~N   "a b c"/N   a << b   a NEAR/N b
-//   a NOTNEAR/N b   @field  @(f1,f2)  @!field  @!(f1,f2)  @*  @field[N]   ^a   a$   =a   a^1.5   * inside a phrase
+//   a SENTENCE b   a PARAGRAPH b   a NOTNEAR/N b   @field  @(f1,f2)  @!field  @!(f1,f2)  @*  @field[N]   ^a   a$   =a   a^1.5   * inside a phrase
 //
 // Precedence as in the grammar: NOTNEAR binds atoms; '|' and MAYBE bind atoms into an or-list; '-' / '!' negate an or-list;
 // '<<' and NEAR/N chain or-lists left to right (equal operator + argument extend the node: AddOp); juxtaposition is AND.
@@ -38,7 +38,7 @@ struct mrk_parsed_query {
 
 namespace {
 
-enum Tok { T_END, T_WORD, T_OR, T_NOT, T_MAYBE, T_LP, T_RP, T_QUOTE, T_BEFORE, T_NEAR, T_NOTNEAR, T_FIELD, T_TILDE, T_SLASH, T_STAR };
+enum Tok { T_END, T_WORD, T_OR, T_NOT, T_MAYBE, T_LP, T_RP, T_QUOTE, T_BEFORE, T_NEAR, T_NOTNEAR, T_FIELD, T_TILDE, T_SLASH, T_STAR, T_SENTENCE, T_PARAGRAPH };
 
 struct Token {
   Tok t = T_END;
@@ -165,6 +165,12 @@ struct Parser {
       if (!strncmp(p, "NEAR/", 5) && isdigit((unsigned char)p[5])) {
         t.t = T_NEAR;
         t.ival = (int)strtol(p + 5, (char**)&p, 10);
+        cur = t;
+        return true;
+      }
+      if ((!strncmp(p, "SENTENCE", 8) && !wordch((unsigned char)p[8])) || (!strncmp(p, "PARAGRAPH", 9) && !wordch((unsigned char)p[9]))) {
+        t.t = *p == 'S' ? T_SENTENCE : T_PARAGRAPH; // (capitals only; not a query position: sphinxquery.cpp:1284-1300)
+        p += *p == 'S' ? 8 : 9;
         cur = t;
         return true;
       }
@@ -349,6 +355,17 @@ struct Parser {
 
   bool atom_(int& out) {
     if (!primary(out)) return false;
+    // sentence: sp_item SENTENCE sp_item | sentence SENTENCE sp_item (sphinxquery.y:117-124); sp_item = a keyword or a plain phrase
+    while (cur.t == T_SENTENCE || cur.t == T_PARAGRAPH) {
+      const int op = cur.t == T_SENTENCE ? MRK_OP_SENTENCE : MRK_OP_PARAGRAPH;
+      auto sp_item = [&](int x) { return x >= 0 && (N[x].op == MRK_OP_TERM || N[x].op == MRK_OP_PHRASE) && N[x].opt == 0; };
+      if (out >= 0 && !sp_item(out) && N[out].op != op) return fail("SENTENCE / PARAGRAPH take keywords and phrases");
+      if (!next()) return false;
+      int r;
+      if (!primary(r)) return false;
+      if (r >= 0 && !sp_item(r)) return fail("SENTENCE / PARAGRAPH take keywords and phrases");
+      out = add_op(op, out, r);
+    }
     while (cur.t == T_NOTNEAR) { // atom TOK_NOTNEAR atom, left-associative
       const int dist = cur.ival;
       if (!next()) return false;
@@ -495,7 +512,7 @@ int emit(const Parser& P, int ni, mrk_parsed_query& out) {
     for (int k : kids) out.children.push_back(k);
   }
   out.nodes.push_back(m);
-  out.words.push_back(n.op == MRK_OP_TERM ? n.word : std::string());
+  out.words.push_back(n.op == MRK_OP_TERM ? n.word : n.op == MRK_OP_SENTENCE ? std::string("\3sentence") : n.op == MRK_OP_PARAGRAPH ? std::string("\3paragraph") : std::string());
   return (int)out.nodes.size() - 1;
 }
 
@@ -535,6 +552,6 @@ extern "C" const char* mrk_parsed_keyword(const mrk_parsed_query* q, int32_t nod
 extern "C" int mrk_parsed_resolve(mrk_parsed_query* q, const mrk_host_index* h) {
   if (!q || !h) return mrk_fail(MRK_E_INVAL, "mrk_parsed_resolve: NULL argument");
   for (size_t i = 0; i < q->nodes.size(); ++i)
-    if (q->nodes[i].op == MRK_OP_TERM) q->nodes[i].term_id = mrk_host_index_find_word(h, q->words[i].c_str(), (int32_t)q->words[i].size());
+    if (q->nodes[i].op == MRK_OP_TERM || q->nodes[i].op == MRK_OP_SENTENCE || q->nodes[i].op == MRK_OP_PARAGRAPH) q->nodes[i].term_id = mrk_host_index_find_word(h, q->words[i].c_str(), (int32_t)q->words[i].size());
   return MRK_OK;
 }

@@ -629,7 +629,7 @@ static void hv_push(hitvec* v, const hit_t* h) {
   v->p[v->n++] = *h;
 }
 
-enum { EN_TERM, EN_MULTIAND, EN_AND, EN_OR, EN_MAYBE, EN_ANDNOT, EN_PHRASE, EN_QUORUM, EN_ORDER, EN_NOTNEAR };
+enum { EN_TERM, EN_MULTIAND, EN_AND, EN_OR, EN_MAYBE, EN_ANDNOT, EN_PHRASE, EN_QUORUM, EN_ORDER, EN_NOTNEAR, EN_UNIT };
 
 typedef struct {
   qword qw;
@@ -706,6 +706,10 @@ struct enode {
   int nr_iring;
   /* NOTNEAR (ExtNotNear_c): l = must, r = not */
   int nn_dist;
+  /* UNIT (ExtUnit_c, SENTENCE / PARAGRAPH): l, r = the arguments, dot = the boundary keyword's term (NULL: none in the index) */
+  enode* dot;
+  int dot_ok;
+  hitvec dot_hits;
   /* common */
   int atom; /* ExtNode_i::GetAtomPos */
   int64_t* p_fetched_docs;
@@ -1419,6 +1423,95 @@ static int notnear_next(enode* e) {
   }
 }
 
+
+/* ---- ExtUnit_c, the SENTENCE / PARAGRAPH operators (searchnode.cpp:4983-5310): AND of the two arguments; where the doc
+   also holds boundary hits ("dots"), only the hit pairs no dot separates match, and the hits of every matching unit are
+   copied (FilterHits :5082-5166).  Positions compare raw (field, end flag, position), as the reference's Hitpos_t does. ---- */
+static int unit_filter(enode* e) {
+  const hitvec *L = &e->tmp, *R = &e->tmp2, *D = &e->dot_hits;
+  int i1 = 0, i2 = 0, id = 0, registered = 0;
+  uint32_t end = D->n ? 0 : UINT_MAX; /* no dots in the doc: copy all hits */
+  for (;;) {
+    if (end) { /* in a matched unit: copy hits until the next dot */
+      const int v1 = i1 < L->n && L->p[i1].hitpos < end, v2 = i2 < R->n && R->p[i2].hitpos < end;
+      if (!v1 && !v2) {
+        end = 0;
+        if (i1 < L->n && i2 < R->n) continue; /* perhaps more units in this doc */
+        break;
+      }
+      registered = 1;
+      if (v1 && (!v2 || hit_less(&L->p[i1], &R->p[i2])))
+        hv_push(&e->myhits, &L->p[i1++]);
+      else
+        hv_push(&e->myhits, &R->p[i2++]);
+    } else { /* the next hit pair */
+      if (i1 >= L->n || i2 >= R->n) break; /* (the reference asserts both; an argument without hits matches nothing) */
+      const uint32_t a = L->p[i1].hitpos, b = R->p[i2].hitpos, umin = a < b ? a : b, umax = a < b ? b : a;
+      while (id < D->n && D->p[id].hitpos <= umin) id++; /* SkipHitsLtePos ( pDotHit, uMin ) */
+      if (id >= D->n) {
+        end = UINT_MAX; /* no more dots past the pair's start: match, copy to the doc's end */
+        continue;
+      }
+      if (D->p[id].hitpos < umax) { /* "A dot B": rewind both sides past this dot */
+        const uint32_t dp = D->p[id].hitpos;
+        while (i1 < L->n && L->p[i1].hitpos <= dp) i1++;
+        if (i1 >= L->n) break;
+        while (i2 < R->n && R->p[i2].hitpos <= dp) i2++;
+        if (i2 >= R->n) break;
+        continue;
+      }
+      while (id < D->n && D->p[id].hitpos <= umax) id++;
+      end = id >= D->n ? UINT_MAX : D->p[id].hitpos;
+    }
+  }
+  return registered;
+}
+
+static int unit_next(enode* e) {
+  if (!e->started) {
+    e->started = 1;
+    e->l_ok = en_next(e->l);
+    if (!e->l_ok) return 0;
+    en_hint(e->r, e->l->rowid);
+    e->r_ok = en_next(e->r);
+    e->dot_ok = e->dot ? en_next(e->dot) : 0;
+  } else {
+    if (!e->l_ok || !e->r_ok) return 0;
+    e->l_ok = en_next(e->l);
+    e->r_ok = e->l_ok ? en_next(e->r) : 0;
+  }
+  while (e->l_ok && e->r_ok) {
+    if (e->l->rowid < e->r->rowid) {
+      en_hint(e->l, e->r->rowid);
+      e->l_ok = en_next(e->l);
+      continue;
+    }
+    if (e->l->rowid > e->r->rowid) {
+      en_hint(e->r, e->l->rowid);
+      e->r_ok = en_next(e->r);
+      continue;
+    }
+    const uint32_t rowid = e->l->rowid;
+    while (e->dot_ok && e->dot->rowid < rowid) {
+      en_hint(e->dot, rowid);
+      e->dot_ok = en_next(e->dot);
+    }
+    e->tmp.n = e->tmp2.n = e->dot_hits.n = e->myhits.n = 0;
+    en_hits(e->l, &e->tmp);
+    en_hits(e->r, &e->tmp2);
+    if (e->dot_ok && e->dot->rowid == rowid) en_hits(e->dot, &e->dot_hits);
+    if (unit_filter(e)) {
+      e->rowid = rowid;
+      e->fields = e->l->fields | e->r->fields;
+      e->tfidf = e->l->tfidf + e->r->tfidf;
+      return 1;
+    }
+    e->l_ok = en_next(e->l);
+    e->r_ok = e->l_ok ? en_next(e->r) : 0;
+  }
+  return 0;
+}
+
 static int phrase_next(enode* e) { /* ExtNWay_T::GetDocsChunk :3806-3848 */
   for (;;) {
     if (!en_next(e->inner)) return 0;
@@ -1629,6 +1722,7 @@ static int en_next(enode* e) {
     case EN_QUORUM: ok = quorum_next(e); break;
     case EN_ORDER: ok = order_next(e); break;
     case EN_NOTNEAR: ok = notnear_next(e); break;
+    case EN_UNIT: ok = unit_next(e); break;
     default: ok = phrase_next(e); break;
   }
   if (!ok) e->rowid = ORC_INVALID_ROWID;
@@ -1646,6 +1740,7 @@ static void en_hits(enode* e, hitvec* out) {
     case EN_QUORUM:
     case EN_ORDER:
     case EN_NOTNEAR:
+    case EN_UNIT:
       for (int i = 0; i < e->myhits.n; i++) hv_push(out, &e->myhits.p[i]);
       break;
     default: phrase_hits(e, out); break;
@@ -1680,6 +1775,8 @@ static void en_free(enode* e) {
   en_free(e->l);
   en_free(e->r);
   en_free(e->inner);
+  en_free(e->dot);
+  free(e->dot_hits.p);
   free(e->atom_pos);
   free(e->qpos_delta);
   free(e->states);
@@ -2063,6 +2160,27 @@ static enode* build_node(build_ctx* bc, int ni) {
       if (cur_ex) cur_ex->qpos_reverse = 1;
       e->inner = cur;
       return e;
+    }
+    case ORC_OP_SENTENCE:
+    case ORC_OP_PARAGRAPH: { /* generic create :1785-1803: pCur = new ExtUnit_c ( pCur, pNext, fields, setup, MAGIC_WORD_... ); its boundary term is
+                                created with the node's field mask and bNotWeighted (:4987-4989): not a query word, no IDF */
+      enode* cur = NULL;
+      for (int i = 0; i < qn->n_children; i++) {
+        enode* nx = build_node(bc, q->children[qn->first_child + i]);
+        if (!nx) continue;
+        if (!cur) {
+          cur = nx;
+          continue;
+        }
+        cur = build_twofer(bc, EN_UNIT, cur, nx);
+        if (qn->term_id >= 0) {
+          orc_node w;
+          memset(&w, 0, sizeof w);
+          w.op = ORC_OP_TERM, w.term_id = qn->term_id, w.field_mask = qn->field_mask, w.boost = 1.0f;
+          cur->dot = build_term(bc, &w);
+        }
+      }
+      return cur;
     }
     case ORC_OP_NOTNEAR: { /* generic create :1785-1803: pCur = new ExtNotNear_c ( pCur, pNext, .., m_iOpArg ) */
       if (qn->opt <= 0) {

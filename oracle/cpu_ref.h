@@ -58,7 +58,9 @@ enum {
   ORC_OP_QUORUM = 7,
   ORC_OP_BEFORE = 8, /* 'a << b << c' (ExtOrder_c) */
   ORC_OP_NEAR = 9,    /* 'a NEAR/N b NEAR/N c' (ExtNWay_T<FSMmultinear_c>): opt = N */
-  ORC_OP_NOTNEAR = 10 /* 'a NOTNEAR/N b' (ExtNotNear_c): opt = N */
+  ORC_OP_NOTNEAR = 10, /* 'a NOTNEAR/N b' (ExtNotNear_c): opt = N */
+  ORC_OP_SENTENCE = 11, /* 'a SENTENCE b' (ExtUnit_c over the index_sp boundary keyword): the node's term_id = that keyword's slot (< 0: none indexed) */
+  ORC_OP_PARAGRAPH = 12
 };
 
 /* ---- VLB codec (src/sphinxstd.h:5545-5567, src/fileio.cpp:31-45) ---- */

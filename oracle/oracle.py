@@ -19,6 +19,7 @@ RANK_PROXIMITY_BM25, RANK_BM25, RANK_NONE, RANK_WORDCOUNT, RANK_PROXIMITY = 0, 1
 RANK_MATCHANY, RANK_FIELDMASK, RANK_SPH04 = 5, 6, 7
 OP_TERM, OP_AND, OP_OR, OP_MAYBE, OP_ANDNOT, OP_PHRASE, OP_PROXIMITY, OP_QUORUM, OP_BEFORE = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OP_NEAR, OP_NOTNEAR = 9, 10  # 'a NEAR/N b', 'a NOTNEAR/N b': opt = N
+OP_SENTENCE, OP_PARAGRAPH = 11, 12  # 'a SENTENCE b', 'a PARAGRAPH b': the node's term_id = the boundary keyword (index_sp), < 0 = none
 ALL_FIELDS = 0xFFFFFFFF
 
 
@@ -242,8 +243,8 @@ def term(term_id: int, atom_pos: int, field_mask: int = ALL_FIELDS, boost: float
     return QNode(OP_TERM, [], term_id, atom_pos, field_mask, boost, term_pos=term_pos, field_max_pos=field_max_pos)
 
 
-def op(kind: int, *children: QNode, field_mask: int = ALL_FIELDS, opt: int = 0) -> QNode:
-    return QNode(kind, list(children), field_mask=field_mask, opt=opt)
+def op(kind: int, *children: QNode, field_mask: int = ALL_FIELDS, opt: int = 0, unit_term: int = -1) -> QNode:
+    return QNode(kind, list(children), term_id=unit_term, field_mask=field_mask, opt=opt)
 
 
 @dataclass

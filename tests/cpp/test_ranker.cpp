@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
   const int n = tParent.Flatten(out.data());
   for (int i = 0; i < n; ++i) printf("%d %u %d\n", out[i].m_iTag, out[i].m_tRowID, out[i].m_iWeight);
   // an unsupported query shape must fail loudly, reference-style (nullptr + error string)
-  nodes[0].op = 11; // an operator beyond MRK_OP_NOTNEAR (SENTENCE, PARAGRAPH, ...)
+  nodes[0].op = 13; // an operator beyond MRK_OP_PARAGRAPH (ZONE limits, NULL, ...)
   mrk::GpuRanker* pBad = mrk::GpuRanker::Create(batch, seg[0], q, sError);
   printf("unknown_op %s\n", pBad ? "accepted" : "rejected");
   delete pBad;

@@ -409,6 +409,47 @@ for name, query, ids in [
 ]:
     G["cases"].append({"name": "349 " + name, "corpus": "test_349", "query": query, "ranker": "proximity_bm25", "expect_ids": ids})
 
+
+# test_133: SENTENCE / PARAGRAPH (ExtUnit_c) over an index_sp = 1, html_strip = 1 index.  Rows 1-6, 100, 101 as the test inserts them
+# (the SQL's '&lt;p&gt;' is '<p>' by the time the stripper sees it); the index holds 17 docs in all (model.bin's BM25 parts fit
+# N = 17: 598 for two keywords of 4 docs each) -- the other nine (zone / entity rows) share no keyword with these queries and stand
+# here as filler text.  The boundary keywords are indexed like words ("unit": their dictionary text).
+SENT, PARA = "\x03sentence", "\x03paragraph"
+G["corpora"]["test_133"] = {
+    "source": "test/test_133/test.xml (index test: rows 1-6, 100, 101 + nine rows that hold none of the queried words) + model.bin",
+    "min_word_len": 1, "index_sp": True,
+    "ids": [1, 2, 3, 4, 5, 6, 100, 101, 200, 201, 211, 202, 300, 301, 310, 311, 400],
+    "docs_spec": [{"count": 1, "fields": [t]} for t in [
+        "One and one and one. And two. And three, all separate.",
+        "And then we'll have him, one two three! Kidnap the Sandy Clawz...",
+        "One two something. But not three.",
+        "Two says hello to one more three.",
+        {"runs": [["A ram zam zam. ", 171], ["Zam ram!", 1]]},
+        "A ram zam zam, a ram zam zam, guli guli guli guli ram zam zam.",
+        "Quick brown fox<p>jumps over a lazy dog.",
+        "In paragraph, yes. Not in sentence, no."]] +
+    [{"count": 9, "fields": ["the walrus said of shoes and ships and sealing wax"]}]}
+
+
+def UNIT(kind, *kids):
+    n = OP(kind, *kids)
+    n["unit"] = SENT if kind == "sentence" else PARA
+    return n
+
+
+for name, query, exp in [
+    ("one SENTENCE two", UNIT("sentence", T("one", 1), T("two", 2)), [[2, 2598], [3, 2598], [4, 1598]]),
+    ("one SENTENCE two three", OP("and", UNIT("sentence", T("one", 1), T("two", 2)), T("three", 3)), [[2, 3598], [3, 2598], [4, 2598]]),
+    ("one SENTENCE two SENTENCE three", UNIT("sentence", T("one", 1), T("two", 2), T("three", 3)), [[2, 3598], [4, 2598]]),
+    ('"one two" SENTENCE three', UNIT("sentence", OP("phrase", T("one", 1), T("two", 2)), T("three", 3)), [[2, 2598]]),
+    ("zam SENTENCE ram", UNIT("sentence", T("zam", 1), T("ram", 2)), [[5, 2857], [6, 1778]]),
+    ("fox PARAGRAPH dog", UNIT("paragraph", T("fox", 1), T("dog", 2)), []),
+    ("sentence SENTENCE paragraph", UNIT("sentence", T("sentence", 1), T("paragraph", 2)), []),
+    ("sentence PARAGRAPH paragraph", UNIT("paragraph", T("sentence", 1), T("paragraph", 2)), [[101, 1722]]),
+    ("one SENTENCE three", UNIT("sentence", T("one", 1), T("three", 2)), [[2, 1598], [4, 1598]]),
+]:
+    G["cases"].append({"name": "133 " + name, "corpus": "test_133", "query": query, "ranker": "proximity_bm25", "expect": exp, "total_found": len(exp)})
+
 for _name, _c in G["corpora"].items():  # a corpus given as "like another one, with row 21 replaced"
     if "like" in _c:
         spec = [dict(r) for r in G["corpora"][_c.pop("like")]["docs_spec"]]

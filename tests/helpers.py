@@ -28,16 +28,72 @@ def tokenize(text: str, min_word_len: int = 1) -> List[Tuple[str, int]]:
     return out
 
 
-def make_hits(docs: Sequence[Sequence[str]], min_word_len: int = 1):
+MAGIC_SENTENCE, MAGIC_PARAGRAPH = "\x03sentence", "\x03paragraph"  # MAGIC_WORD_SENTENCE / _PARAGRAPH (sphinx.cpp:163-164)
+
+
+def tokenize_sp(text: str, min_word_len: int = 1) -> List[Tuple[str, int]]:
+    """index_sp = 1 (+ html_strip for '<p>'): the tokenizer of `tokenize` for ASCII text, plus the boundary tokens.  A sentence
+    boundary ('?', '!', or a '.' that CSphTokenizerBase::CodepointArbitrationI, sphinx.cpp:4575-4655, does not take for an
+    in-word dot, an in-phrase dot or a middle name / salutation) takes the next position and is indexed as the keyword
+    MAGIC_SENTENCE there; a paragraph boundary ('<p>') as both MAGIC_SENTENCE and MAGIC_PARAGRAPH at one position
+    (CSphSource_Document::BuildZoneHits, sphinx.cpp:22231-22245)."""
+    out: List[Tuple[str, int]] = []
+    pos, i, n = 0, 0, len(text)
+    accum = ""  # the word right before the current character (m_sAccum), "" after a separator
+
+    def word(c):
+        return c.isascii() and (c.isalnum() or c == "_")
+
+    while i < n:
+        c = text[i]
+        if text.startswith("<p>", i):
+            pos += 1
+            out += [(MAGIC_SENTENCE, pos), (MAGIC_PARAGRAPH, pos)]
+            i, accum = i + 3, ""
+            continue
+        if word(c):
+            j = i
+            while j < n and word(text[j]):
+                j += 1
+            accum = text[i:j]
+            pos += 1
+            if len(accum) >= min_word_len:
+                out.append((accum.lower(), pos))
+            i = j
+            continue
+        boundary = c in "?!"
+        if c == ".":
+            nx, nx2, nx3 = (text[i + 1:i + 2] or "\0"), (text[i + 2:i + 3] or "\0"), (text[i + 3:i + 4] or "\0")
+            inword = word(nx) or nx == "-" or ord(nx) >= 0x80 or nx == ","
+            inphrase = nx in " \t\r\n" and (("a" <= nx2 <= "z") or (nx2 == "(" and "a" <= nx3 <= "z"))
+            middle = False
+            if len(accum) == 1:
+                middle = accum.isupper()
+            elif len(accum) == 2 and accum[0].isupper():
+                middle = (not accum[1].isupper()) or accum in ("MR", "MS", "DR")
+            elif len(accum) == 3:
+                middle = accum.lower() in ("mrs", "drs")
+            boundary = not (inword or inphrase or middle)
+        if boundary:
+            pos += 1
+            out.append((MAGIC_SENTENCE, pos))
+        accum = ""
+        i += 1
+    return out
+
+
+def make_hits(docs: Sequence[Sequence[str]], min_word_len: int = 1, index_sp: bool = False):
     """docs[rowid] = [field0 text, field1 text, ...] -> (wordid, rowid, hitpos) arrays sorted
-    by (wordid, rowid, hitpos), plus the vocabulary {token: term_id} (wordid = term_id + 1)."""
+    by (wordid, rowid, hitpos), plus the vocabulary {token: term_id} (wordid = term_id + 1).
+    The field-end marker goes on every hit at the field's last position (sphinx.cpp:22533-22548)."""
     vocab: Dict[str, int] = {}
     raw = []
     for rowid, fields in enumerate(docs):
         for f, text in enumerate(fields):
-            toks = tokenize(text, min_word_len)
+            toks = tokenize_sp(text, min_word_len) if index_sp else tokenize(text, min_word_len)
+            last = toks[-1][1] if toks else 0
             for i, (t, pos) in enumerate(toks):
-                raw.append((t, rowid, f, pos, i == len(toks) - 1))
+                raw.append((t, rowid, f, pos, pos == last))
     for t in sorted({r[0] for r in raw}):
         vocab[t] = len(vocab)
     hits = sorted((vocab[t] + 1, rowid, (f << 24) | pos, end) for t, rowid, f, pos, end in raw)
@@ -47,8 +103,8 @@ def make_hits(docs: Sequence[Sequence[str]], min_word_len: int = 1):
     return wordid, rowid, hitpos, vocab
 
 
-def mini_index(orc, docs, min_word_len: int = 1, skiplist_block_size: int = 128, inline_hits: int = 1):
-    wordid, rowid, hitpos, vocab = make_hits(docs, min_word_len)
+def mini_index(orc, docs, min_word_len: int = 1, skiplist_block_size: int = 128, inline_hits: int = 1, index_sp: bool = False):
+    wordid, rowid, hitpos, vocab = make_hits(docs, min_word_len, index_sp)
     n_fields = max(len(d) for d in docs)
     idx = orc.build_index(wordid, rowid, hitpos, total_docs=len(docs), skiplist_block_size=skiplist_block_size,
                           inline_hits=inline_hits, n_fields=n_fields, n_terms=len(vocab))

@@ -35,7 +35,7 @@ def to_orc(orc, q):
     def conv(n):
         if n.word is not None:
             return orc.term(n.word.term_id, n.word.atom_pos, n.field_mask, n.word.boost, term_pos=n.term_pos(), field_max_pos=n.field_max_pos)
-        return orc.op(n.op, *[conv(c) for c in n.children], field_mask=n.field_mask, opt=n.opt)
+        return orc.op(n.op, *[conv(c) for c in n.children], field_mask=n.field_mask, opt=n.opt, unit_term=n.unit_term)
 
     return orc.FlatQuery(conv(q.root), ranker=q.ranker, max_matches=q.max_matches, field_weights=q.field_weights,
                          index_weight=q.index_weight, plain_idf=q.plain_idf, normalized_tfidf=q.normalized_tfidf,
@@ -218,7 +218,7 @@ def test_unsupported_shapes_fail_loudly(dev):
     hi = m.synth_index(1000, [0.5, 0.5], seed=1)
     seg = m.Segment(ctx, hi)
     # an operator the device path does not know (SENTENCE / PARAGRAPH ...: op codes beyond NOTNEAR)
-    q_or = m.Query(m.XQNode(11, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
+    q_or = m.Query(m.XQNode(13, [kw(m, 0, 1), kw(m, 1, 2)]), ranker=m.SPH_RANK_BM25)
     q_big = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25, max_matches=5000)
     q_ok = m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_BM25)
     r = batch.search(seg, [q_or, q_ok, q_big])
@@ -845,7 +845,7 @@ def test_golden_vectors_on_device(dev, from_text):
                "wordcount": m.SPH_RANK_WORDCOUNT, "sph04": m.SPH_RANK_SPH04, "fieldmask": m.SPH_RANK_FIELDMASK}
     ops = {"and": m.SPH_QUERY_AND, "or": m.SPH_QUERY_OR, "andnot": m.SPH_QUERY_ANDNOT, "phrase": m.SPH_QUERY_PHRASE,
            "proximity": m.SPH_QUERY_PROXIMITY, "quorum": m.SPH_QUERY_QUORUM, "before": m.SPH_QUERY_BEFORE, "near": m.SPH_QUERY_NEAR,
-           "notnear": m.SPH_QUERY_NOTNEAR}
+           "notnear": m.SPH_QUERY_NOTNEAR, "sentence": m.SPH_QUERY_SENTENCE, "paragraph": m.SPH_QUERY_PARAGRAPH}
 
     def near_beyond_device(q):
         """the NEAR shape the device declines by design: more than two operands below another operator (none in the fixture)"""
@@ -856,13 +856,13 @@ def test_golden_vectors_on_device(dev, from_text):
             tp = q.get("tp")
             return m.XQNode.keyword(v.get(q["word"], -1), q["pos"], q["mask"], field_start=tp in ("start", "startend"),  # -1: not in the dictionary
                                     field_end=tp in ("end", "startend"), field_max_pos=q.get("max_pos", 0) if tp == "limit" else 0)
-        return m.XQNode(ops[q["op"]], [tree(v, k) for k in q["kids"]], None, q["mask"], q.get("opt", 0))
+        return m.XQNode(ops[q["op"]], [tree(v, k) for k in q["kids"]], None, q["mask"], q.get("opt", 0), unit_term=v.get(q["unit"], -1) if "unit" in q else -1)
 
     n_ok = 0
     n_near_declined = 0
     declined = []
     for name, corpus in GOLDEN["corpora"].items():
-        W, R, H, v = make_hits(corpus["docs"], corpus["min_word_len"])
+        W, R, H, v = make_hits(corpus["docs"], corpus["min_word_len"], bool(corpus.get("index_sp")))
         nf = max(len(d) for d in corpus["docs"])
         seg = m.Segment(ctx, m.index_from_hits(W, R, H, n_terms=len(v), total_docs=len(corpus["docs"]), n_fields=nf))
         cases = [c for c in GOLDEN["cases"] if c["corpus"] == name]
@@ -965,7 +965,7 @@ def test_generic_evaluator_vs_oracle(orc, dev):
                 return m.XQNode(m.SPH_QUERY_AND, [term(), term()])
 
             shape = rng.choice(["and_many", "long_phrase", "long_prox", "two_phrases", "before_ops", "near_phrases", "notnear_ops", "quorum_in_tree",
-                                "big_quorum", "nested_near", "before_quorum", "mix", "near_many"])
+                                "big_quorum", "nested_near", "before_quorum", "mix", "near_many", "unit", "unit_in_tree"])
             if shape == "and_many":
                 root = m.XQNode(m.SPH_QUERY_AND, [term() for _ in range(int(rng.integers(5, 8)))])
             elif shape == "long_phrase":
@@ -983,6 +983,13 @@ def test_generic_evaluator_vs_oracle(orc, dev):
                 root = m.XQNode(m.SPH_QUERY_NEAR, [inner, phrase_like()], opt=int(rng.integers(2, 9)))
             elif shape == "near_many":  # three and more operands at the root: the folded hits' query position depends on the docs before
                 root = m.XQNode(m.SPH_QUERY_NEAR, [phrase_like() if rng.random() < 0.3 else term() for _ in range(int(rng.integers(3, 5)))], opt=int(rng.integers(1, 8)))
+            elif shape in ("unit", "unit_in_tree"):  # SENTENCE / PARAGRAPH: any keyword can play the boundary word ("dot")
+                def sp_item():
+                    return m.XQNode(m.SPH_QUERY_PHRASE, words(2)) if rng.random() < 0.3 else term()
+                root = m.XQNode(int(rng.choice([m.SPH_QUERY_SENTENCE, m.SPH_QUERY_PARAGRAPH])), [sp_item() for _ in range(int(rng.integers(2, 4)))],
+                                field_mask=0xFFFFFFFF if rng.random() < 0.7 else int(rng.integers(1, 8)), unit_term=int(rng.integers(-1, nt + 1)))
+                if shape == "unit_in_tree":
+                    root = m.XQNode(rng.choice([m.SPH_QUERY_AND, m.SPH_QUERY_OR, m.SPH_QUERY_ANDNOT]), [root, term()] if rng.random() < 0.5 else [term(), root])
             elif shape == "notnear_ops":
                 root = m.XQNode(m.SPH_QUERY_NOTNEAR, [operand(), operand()], opt=int(rng.integers(1, 8)))
             elif shape == "quorum_in_tree":

@@ -197,13 +197,13 @@ def _golden_tree(orc, v, q):
         tp = {None: 0, "start": orc.TERMPOS_START, "end": orc.TERMPOS_END, "startend": orc.TERMPOS_STARTEND, "limit": orc.TERMPOS_LIMIT}[q.get("tp")]
         return orc.term(v.get(q["word"], -1), q["pos"], field_mask=q["mask"], term_pos=tp, field_max_pos=q.get("max_pos", 0))  # -1: keyword not in the dictionary
     return orc.op(getattr(orc, "OP_" + q["op"].upper()), *[_golden_tree(orc, v, k) for k in q["kids"]], field_mask=q["mask"],
-                  opt=q.get("opt", 0))
+                  opt=q.get("opt", 0), unit_term=v.get(q["unit"], -1) if "unit" in q else -1)
 
 
 @pytest.mark.parametrize("case", GOLDEN["cases"], ids=[c["name"] for c in GOLDEN["cases"]])
 def test_reference_vectors(orc, case):
     corpus = GOLDEN["corpora"][case["corpus"]]
-    idx, v = mini_index(orc, corpus["docs"], min_word_len=corpus["min_word_len"])
+    idx, v = mini_index(orc, corpus["docs"], min_word_len=corpus["min_word_len"], index_sp=bool(corpus.get("index_sp")))
     kw = {"field_weights": case["field_weights"]} if "field_weights" in case else {}
     if case.get("plain_idf"):
         kw["plain_idf"] = True

@@ -24,7 +24,8 @@ PARSER = json.load(open(os.path.join(HERE, "golden", "query_parser_vectors.json"
 ALL = 0xFFFFFFFF
 OPNAME = {api.SPH_QUERY_AND: "and", api.SPH_QUERY_OR: "or", api.SPH_QUERY_MAYBE: "maybe", api.SPH_QUERY_ANDNOT: "andnot",
           api.SPH_QUERY_PHRASE: "phrase", api.SPH_QUERY_PROXIMITY: "proximity", api.SPH_QUERY_QUORUM: "quorum",
-          api.SPH_QUERY_BEFORE: "before", api.SPH_QUERY_NEAR: "near", api.SPH_QUERY_NOTNEAR: "notnear"}
+          api.SPH_QUERY_BEFORE: "before", api.SPH_QUERY_NEAR: "near", api.SPH_QUERY_NOTNEAR: "notnear", api.SPH_QUERY_SENTENCE: "sentence",
+          api.SPH_QUERY_PARAGRAPH: "paragraph"}
 
 
 # ---------------------------------------------------------------- sphReconstructNode over an XQNode tree
