@@ -1153,7 +1153,10 @@ def test_candidate_overflow_is_rerun(orc, dev):
     hi = m.index_from_hits(W, R, H, n_terms=2, total_docs=n_docs, n_fields=2)
     qs = [m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_BM25, max_matches=1000),
           m.Query(OR(m, kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_BM25, max_matches=10),
-          m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_FIELDMASK, max_matches=100)]
+          m.Query(kw(m, 0, 1), ranker=m.SPH_RANK_FIELDMASK, max_matches=100),
+          # the generic per-doc evaluator's rerun: 'a NOTNEAR/3 "b a"' -- the phrase never occurs, every doc of a stays
+          m.Query(m.XQNode(m.SPH_QUERY_NOTNEAR, [kw(m, 0, 1), m.XQNode(m.SPH_QUERY_PHRASE, [kw(m, 1, 2), kw(m, 0, 3)])], opt=3), ranker=m.SPH_RANK_PROXIMITY_BM25,
+                  max_matches=50)]
     for inv in (64, 0):  # bitmap kernel and block kernel
         ctx.set("bitmap_inv", inv)
         seg = m.Segment(ctx, hi)
@@ -1164,8 +1167,9 @@ def test_candidate_overflow_is_rerun(orc, dev):
                 assert g.total_found == n_docs
                 assert list(g.rowid) == list(range(len(g.rowid))) and len(g.rowid) == q.max_matches  # ties: lowest rowids win
                 assert len(set(int(w) for w in g.weight)) == 1
-            want = to_orc(orc, qs[0]).run(orc_index_of(orc, hi))
-            assert (got[0].weight == want.weight).all() and (got[0].rowid == want.rowid).all()
+            for i in (0, 3):
+                want = to_orc(orc, qs[i]).run(orc_index_of(orc, hi))
+                assert (got[i].weight == want.weight).all() and (got[i].rowid == want.rowid).all()
         finally:
             seg.close()
     ctx.set("bitmap_inv", 64)
