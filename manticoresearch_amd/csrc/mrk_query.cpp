@@ -73,6 +73,7 @@ struct Parser {
   Token cur;
   int atom = 0;
   bool in_phrase = false, relaxed = false;
+  int depth = 0; // open parentheses (bounded: the descent is recursive)
   uint32_t spec_mask = 0xFFFFFFFFu; // the field limit in force
   int spec_max_pos = 0;
 
@@ -392,8 +393,10 @@ struct Parser {
     } else if (cur.t == T_LP) {
       const uint32_t m0 = spec_mask;
       const int p0 = spec_max_pos;
+      if (++depth > 64) return fail("query nests too deep");
       if (!next()) return false;
       if (!expr(out)) return false;
+      --depth;
       if (cur.t != T_RP) return fail("missing closing parenthesis");
       spec_mask = m0, spec_max_pos = p0; // a field limit ends with its parentheses
       if (!next()) return false;

@@ -147,3 +147,46 @@ def test_field_limits_modifiers_and_errors():
     # a callable resolves keywords; unknown words stay < 0
     t = api.parse_query("alpha beta", F, lookup=lambda w: {"alpha": 7}.get(w, -1))
     assert [k.word.term_id for k in t.children] == [7, -1]
+
+
+def test_parser_survives_junk():
+    """Arbitrary text either parses or fails with MRK_E_INVAL and a message -- never a crash, never a hang."""
+    import random
+    rnd = random.Random(1234)
+    alphabet = ["a", "bb", "ccc", " ", " ", "(", ")", "|", "-", "!", '"', "~", "/", "1", "0.5", "<<", "NEAR/2", "NOTNEAR/3", "NEAR/", "MAYBE", "SENTENCE", "PARAGRAPH",
+                "@title", "@(title,body)", "@!", "@*", "@body[3]", "@nosuch", "@@relaxed", "^", "$", "=", "*", "^1.5", "\\", "\xc3\xa9", "\x03", "["]
+    n_ok = 0
+    for _ in range(3000):
+        q = "".join(rnd.choice(alphabet) for _ in range(rnd.randint(1, 24)))
+        try:
+            api.parse_query(q, ["title", "body"], rnd.choice([1, 2]))
+            n_ok += 1
+        except MrkError as e:
+            assert str(e)
+    assert n_ok > 100
+    with pytest.raises(MrkError, match="too deep"):
+        api.parse_query("(" * 200 + "a" + ")" * 200, [])
+    assert api.parse_query("(" * 60 + "a" + ")" * 60, []).word.text == "a"
+
+
+def test_parser_under_sanitizers(tmp_path):
+    """The parser alone (it is plain host C++), built with -fsanitize=address,undefined, over 20 000 junk queries."""
+    import random
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "fuzz_parser")
+    subprocess.check_call(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I" + os.path.join(root, "manticoresearch_amd", "csrc"), os.path.join(HERE, "cpp", "fuzz_parser.cpp"),
+                           os.path.join(root, "manticoresearch_amd", "csrc", "mrk_query.cpp"), "-o", exe])
+    rnd = random.Random(99)
+    alphabet = ["a", "bb", "ccc", " ", " ", "(", ")", "|", "-", "!", '"', "~", "/", "1", "0.5", "<<", "NEAR/2", "NOTNEAR/3", "NEAR/", "MAYBE", "SENTENCE",
+                "PARAGRAPH", "@title", "@(title,body)", "@!", "@*", "@body[3]", "@nosuch", "@@relaxed", "^", "$", "=", "*", "^1.5", "\\", "\xc3\xa9", "\x03",
+                "[", "99999999999999999999", "~99999999999", "/0", "@(", "@(title,", "@title["]
+    text = "\n".join("".join(rnd.choice(alphabet) for _ in range(rnd.randint(1, 40))) for _ in range(20000)) + "\n"
+    out = subprocess.run([exe], input=text.encode("utf-8"), capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
+    ok, bad = (int(x) for x in out.stdout.split()[1::2])
+    assert ok + bad == 20000 and ok > 200
