@@ -74,11 +74,12 @@ __device__ __forceinline__ float term_tfidf(uint32_t tf, float idf) {
   return q * idf;
 }
 
-// bitonic sort of c[0..CAND) descending, all WG threads
-__device__ void sort_cand_desc(uint64_t* c) {
-  for (uint32_t k = 2; k <= (uint32_t)CAND; k <<= 1) {
+// bitonic sort of c[0..len) descending, all WG threads; len = a power of two <= CAND (entries past the keys are zeros: a
+// short list sorts a short network -- 15 stages for 32 keys instead of the 66 of the full buffer)
+__device__ void sort_cand_desc(uint64_t* c, uint32_t len = (uint32_t)CAND) {
+  for (uint32_t k = 2; k <= len; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = threadIdx.x; t < (uint32_t)CAND / 2; t += WG) {
+      for (uint32_t t = threadIdx.x; t < len / 2; t += WG) {
         const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)); // lower index of the pair
         const uint32_t p = i | j;
         const uint64_t x = c[i], y = c[p];
@@ -144,9 +145,12 @@ template <typename S>
 __device__ uint32_t compact_cand(S& s, uint32_t k, uint64_t* gtau) {
   __syncthreads();
   const uint32_t n = s.cand_n;
-  for (uint32_t i = n + threadIdx.x; i < (uint32_t)CAND; i += WG) s.cand[i] = 0;
+  uint32_t len = 64; // the smallest power of two that holds the keys
+  while (len < n) len <<= 1;
+  if (len > (uint32_t)CAND) len = (uint32_t)CAND;
+  for (uint32_t i = n + threadIdx.x; i < len; i += WG) s.cand[i] = 0;
   __syncthreads();
-  sort_cand_desc(s.cand);
+  sort_cand_desc(s.cand, len);
   const uint32_t keep = n < k ? n : k;
   if (threadIdx.x == 0) {
     s.cand_n = keep;
