@@ -417,6 +417,18 @@ const uint32_t* mrk_host_index_attr_rows(const mrk_host_index* h, uint32_t* stri
 /* .spm bitmap (bit rowid & 31 of word rowid >> 5), as mrk_segment_set_dead_rows takes it; NULL = no map */
 const uint32_t* mrk_host_index_dead_rows(const mrk_host_index* h, uint64_t* n_rows);
 
+/* ---- RT index RAM chunk (host only) ---------------------------------------------------------------------------------------
+   path_prefix + ".meta" / ".ram" as RtIndex_c::SaveMeta / SaveRamChunk write them (sphinxrt.cpp:3560-3640, 4034-4103; meta
+   v.14-18).  Each RAM segment (RtSegment_t: its own dictionary, doclists and hitlists in the RT codecs, sphinxrt.cpp:390-640,
+   rows, dead-row map) comes back as a mrk_host_index in the disk format -- decoded and re-emitted, so that an RT segment is
+   one more mrk_segment for mrk_topk_merge; rowids are segment-local as in the reference.  Stepped over: stored fields (the docstore); not read: the
+   blob pool; declined: hitless words.  mrk_rt_ram_take hands segment i to the caller (free it with mrk_host_index_free). */
+typedef struct mrk_rt_ram mrk_rt_ram;
+int mrk_rt_ram_open(const char* path_prefix, mrk_rt_ram** out);
+uint32_t mrk_rt_ram_segments(const mrk_rt_ram* rt);
+int mrk_rt_ram_take(mrk_rt_ram* rt, uint32_t i, mrk_host_index** out);
+void mrk_rt_ram_free(mrk_rt_ram* rt);
+
 /* ---- query text -> tree (host only) ------------------------------------------------------------------------------------
    The caller side of the path: the extended query syntax (sphParseExtendedQuery: sphinxquery.y:57-125 grammar; the lexer
    XQParser_t::GetToken, sphinxquery.cpp:1201-1553; AddKeyword / AddOp, :1600-1678; FixupNots, :499-562) restated for the

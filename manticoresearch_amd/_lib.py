@@ -146,6 +146,10 @@ SYMBOLS = [
     ("mrk_host_index_dead_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("mrk_host_index_attr", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(AttrInfo)]),
     ("mrk_host_index_attr_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("mrk_rt_ram_open", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    ("mrk_rt_ram_segments", C.c_uint32, [C.c_void_p]),
+    ("mrk_rt_ram_take", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mrk_rt_ram_free", None, [C.c_void_p]),
     ("mrk_query_parse", C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("mrk_parsed_free", None, [C.c_void_p]),
     ("mrk_parsed_n_nodes", C.c_int32, [C.c_void_p]),

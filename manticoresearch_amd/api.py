@@ -101,6 +101,29 @@ def open_index(path_prefix: str) -> HostIndex:
     L = lib()
     h = C.c_void_p()
     check(L.mrk_index_open(os.fsencode(path_prefix), C.byref(h)))
+    return _wrap_file_index(h)
+
+
+def open_rt_ram(path_prefix: str) -> List[HostIndex]:
+    """Read an RT index's RAM chunk (<prefix>.meta + <prefix>.ram, RtIndex_c::SaveMeta / SaveRamChunk): one HostIndex per
+    RAM segment, each with the fields open_index() gives (info, fields, words, attrs, attr_rows, dead rows, find_word):
+    the segment's postings decoded from the RT codecs and re-emitted in the disk format (include/mrk.h, mrk_rt_ram_open)."""
+    L = lib()
+    rt = C.c_void_p()
+    check(L.mrk_rt_ram_open(os.fsencode(path_prefix), C.byref(rt)))
+    try:
+        out = []
+        for i in range(L.mrk_rt_ram_segments(rt)):
+            h = C.c_void_p()
+            check(L.mrk_rt_ram_take(rt, i, C.byref(h)))
+            out.append(_wrap_file_index(h))
+        return out
+    finally:
+        L.mrk_rt_ram_free(rt)
+
+
+def _wrap_file_index(h) -> HostIndex:
+    L = lib()
     info = _lib.IndexInfo()
     check(L.mrk_host_index_info(h, C.byref(info)))
     hi = _take_host_index(h, int(info.total_docs), int(info.skiplist_block_size), int(info.hit_format), int(info.n_fields))
@@ -569,7 +592,7 @@ def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool =
     return float(lib().mrk_idf(term_docs, total_docs, int(plain), int(normalized), n_qwords, boost))
 
 
-__all__ = ["SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
+__all__ = ["open_rt_ram", "SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
            "parse_query", "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE", "SPH_QUERY_NEAR", "SPH_QUERY_NOTNEAR", "SPH_QUERY_SENTENCE", "SPH_QUERY_PARAGRAPH",
            "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Filter", "Matches", "Context",

@@ -143,20 +143,16 @@ bool schema_column(Reader& r, uint32_t version, mrk_host_index::Attr* out = null
   return payload;
 }
 
-int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_index* h, uint64_t& cp_offset) {
-  Reader r(sph.data(), sph.size());
+// ReadSchema (sphinx.cpp:8722-8781): full-text fields, then attributes
+int read_schema(Reader& r, const char* name, mrk_host_index* h) {
   mrk_index_info& I = h->info;
-  if (r.dword() != SPH_MAGIC) return mrk_fail(MRK_E_FORMAT, "%s: not an index header (magic)", name);
-  I.version = r.dword();
-  if (I.version < MIN_VERSION || I.version > MAX_VERSION)
-    return mrk_fail(MRK_E_FORMAT, "%s is v.%u, this reader covers v.%u..%u", name, I.version, MIN_VERSION, MAX_VERSION);
   // schema: full-text fields, then attributes
   I.n_fields = r.dword();
   if (I.n_fields > 256) return mrk_fail(MRK_E_FORMAT, "%s: %u fields", name, I.n_fields);
   for (uint32_t i = 0; i < I.n_fields && !r.bad; ++i) {
     if (I.version >= 57) { // ReadSchemaField
       h->fields.push_back(r.str());
-      r.dword(); // field flags
+      if (r.dword() & 1u) h->stored_fields = true; // field flags: FIELD_STORED
       if (r.byte()) h->payload_fields |= i < 64 ? 1ull << i : 1ull << 63; // payload
     } else {
       const size_t at = r.at;
@@ -173,15 +169,13 @@ int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_ind
     schema_column(r, I.version, &a);
     h->attrs.push_back(a);
   }
-  // dictionary header
-  cp_offset = r.offset();
-  I.n_checkpoints = r.dword();
-  r.byte();  // infix codepoint bytes
-  r.dword(); // infix blocks offset
-  r.dword(); // infix blocks words size
-  // index stats
-  I.total_docs = r.dword();
-  I.total_bytes = r.offset();
+  return MRK_OK;
+}
+
+// LoadIndexSettings + CSphTokenizerSettings::Load + CSphDictSettings::Load, in the order both the .sph header and an RT
+// index's .meta hold them
+void read_settings(Reader& r, mrk_host_index* h) {
+  mrk_index_info& I = h->info;
   // LoadIndexSettings
   I.min_prefix_len = r.dword();
   I.min_infix_len = r.dword();
@@ -242,6 +236,26 @@ int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_ind
   I.word_dict = r.byte() != 0;
   r.byte(); // stopwords unstemmed
   r.str();  // morphology fingerprint
+}
+
+int parse_header(const std::vector<uint8_t>& sph, const char* name, mrk_host_index* h, uint64_t& cp_offset) {
+  Reader r(sph.data(), sph.size());
+  mrk_index_info& I = h->info;
+  if (r.dword() != SPH_MAGIC) return mrk_fail(MRK_E_FORMAT, "%s: not an index header (magic)", name);
+  I.version = r.dword();
+  if (I.version < MIN_VERSION || I.version > MAX_VERSION)
+    return mrk_fail(MRK_E_FORMAT, "%s is v.%u, this reader covers v.%u..%u", name, I.version, MIN_VERSION, MAX_VERSION);
+  if (int rc = read_schema(r, name, h)) return rc;
+  // dictionary header
+  cp_offset = r.offset();
+  I.n_checkpoints = r.dword();
+  r.byte();  // infix codepoint bytes
+  r.dword(); // infix blocks offset
+  r.dword(); // infix blocks words size
+  // index stats
+  I.total_docs = r.dword();
+  I.total_bytes = r.offset();
+  read_settings(r, h);
   h->docinfo_rows = r.offset(); // m_iDocinfo: rows in .spa
   r.offset();                   // m_iDocinfoIndex
   r.offset();                   // m_iMinMaxIndex: where the min-max index starts in .spa, in dwords
@@ -487,3 +501,232 @@ extern "C" const uint32_t* mrk_host_index_dead_rows(const mrk_host_index* h, uin
   if (n_rows) *n_rows = h->info.total_docs;
   return h->dead.data();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RT index RAM chunk: <prefix>.meta (RtIndex_c::SaveMeta / LoadMeta, sphinxrt.cpp:3560-3640, 3732-3868) + <prefix>.ram
+// (SaveRamChunk / LoadRamChunk, :4034-4225).  Every RAM segment holds its own small dictionary, doclists and hitlists in
+// the RT codecs (RtWordReader_t / RtDocReader_t / RtHitReader_t, :390-640: little-endian-first varints, keywords front-
+// coded against the previous one, deltas restarted every m_iWordsCheckpoint words); each segment is decoded into hits and
+// re-emitted in the disk format the device path takes -- an RT segment becomes one more mrk_host_index / mrk_segment.
+struct mrk_rt_ram {
+  std::vector<mrk_host_index*> seg;
+  ~mrk_rt_ram() {
+    for (mrk_host_index* h : seg) delete h;
+  }
+};
+
+namespace {
+
+struct RtBytes { // UnzipT (sphinxrt.cpp:141-157) over a bounded byte range
+  const uint8_t* p;
+  size_t n, at = 0;
+  bool bad = false;
+  uint64_t zip() {
+    uint64_t v = 0;
+    for (int off = 0;; off += 7) {
+      if (at >= n || off > 63) {
+        bad = true;
+        return 0;
+      }
+      const uint8_t b = p[at++];
+      v += (uint64_t)(b & 0x7Fu) << off;
+      if (!(b & 0x80u)) return v;
+    }
+  }
+};
+
+int rt_vector(Reader& r, size_t elem, const char* what, const char* name, std::vector<uint8_t>& out) { // LoadVector (:3997-4010)
+  const uint32_t cnt = r.dword();
+  if (r.bad || (uint64_t)cnt * elem > r.n - r.at) return mrk_fail(MRK_E_FORMAT, "%s: %s vector of %u entries past the file", name, what, cnt);
+  out.assign(r.p + r.at, r.p + r.at + (size_t)cnt * elem);
+  r.at += (size_t)cnt * elem;
+  return MRK_OK;
+}
+
+int rt_open(const char* path_prefix, mrk_rt_ram* rt) {
+  const std::string base(path_prefix), mname = base + ".meta", rname = base + ".ram";
+  std::vector<uint8_t> meta, ram;
+  if (!read_file(mname, meta) || !read_file(rname, ram)) return MRK_E_FORMAT;
+  mrk_host_index proto; // what the .meta says, copied into every segment
+  proto.from_files = true;
+  Reader m(meta.data(), meta.size());
+  if (m.dword() != 0x54525053u) return mrk_fail(MRK_E_FORMAT, "%s: not an RT meta file (magic)", mname.c_str()); // 'SPRT'
+  const uint32_t meta_ver = m.dword();
+  if (meta_ver < 14 || meta_ver > 18) return mrk_fail(MRK_E_FORMAT, "%s is meta v.%u, this reader covers v.14..18", mname.c_str(), meta_ver);
+  m.dword();  // total documents
+  m.offset(); // total bytes
+  m.offset(); // TID
+  proto.info.version = m.dword(); // the settings' version = the disk format version they were saved with
+  if (proto.info.version < MIN_VERSION || proto.info.version > MAX_VERSION)
+    return mrk_fail(MRK_E_FORMAT, "%s: settings of index format v.%u, this reader covers v.%u..%u", mname.c_str(), proto.info.version, MIN_VERSION, MAX_VERSION);
+  if (int rc = read_schema(m, mname.c_str(), &proto)) return rc;
+  read_settings(m, &proto);
+  const uint32_t words_checkpoint = m.dword();
+  if (m.bad) return mrk_fail(MRK_E_FORMAT, "%s: failed to parse (unexpected eof)", mname.c_str());
+  if (words_checkpoint < 2 || words_checkpoint > (1u << 20)) return mrk_fail(MRK_E_FORMAT, "%s: words checkpoint %u", mname.c_str(), words_checkpoint);
+  if (proto.info.hitless != 0) return mrk_fail(MRK_E_UNSUPPORTED, "%s: hitless index (hitless_words) is not on the device path", path_prefix);
+  if (proto.payload_fields) return mrk_fail(MRK_E_UNSUPPORTED, "%s: payload fields are not on the device path", path_prefix);
+  if (proto.info.n_fields > 32) return mrk_fail(MRK_E_UNSUPPORTED, "%s: %u fields (RT doclists carry a 32-bit field mask)", path_prefix, proto.info.n_fields);
+  const bool word_dict = proto.info.word_dict != 0;
+
+  Reader r(ram.data(), ram.size());
+  r.dword();
+  const uint32_t n_seg = r.dword();
+  if (r.bad || n_seg > (1u << 16)) return mrk_fail(MRK_E_FORMAT, "%s: %u segments", rname.c_str(), n_seg);
+  for (uint32_t si = 0; si < n_seg; ++si) {
+    const uint32_t rows = r.dword();
+    r.dword(); // alive rows
+    r.dword();
+    std::vector<uint8_t> words, kwcp, docs, hits, rowdata, blobs, infix;
+    int rc;
+    if ((rc = rt_vector(r, 1, "ram-words", rname.c_str(), words))) return rc;
+    if (word_dict && (rc = rt_vector(r, 1, "ram-checkpoints", rname.c_str(), kwcp))) return rc;
+    const uint32_t n_cp = r.dword();
+    if (r.bad || (uint64_t)n_cp * 16 > r.n - r.at) return mrk_fail(MRK_E_FORMAT, "%s: %u word checkpoints past the file", rname.c_str(), n_cp);
+    r.at += (size_t)n_cp * 16; // (offset, keyword offset | word id) pairs: a lookup aid, the words are walked in full here
+    if ((rc = rt_vector(r, 1, "ram-doclist", rname.c_str(), docs)) || (rc = rt_vector(r, 1, "ram-hitlist", rname.c_str(), hits)) ||
+        (rc = rt_vector(r, 4, "ram-attributes", rname.c_str(), rowdata)))
+      return rc;
+    std::vector<uint32_t> dead((rows + 31) / 32, 0u); // DeadRowMap_Ram_c::Load (killlist.cpp:120-129)
+    if (!r.need(dead.size() * 4)) return mrk_fail(MRK_E_FORMAT, "%s: dead-row map of %u rows past the file", rname.c_str(), rows);
+    if (!dead.empty()) memcpy(dead.data(), r.p + r.at, dead.size() * 4);
+    r.at += dead.size() * 4;
+    if ((rc = rt_vector(r, 1, "ram-blobs", rname.c_str(), blobs))) return rc;
+    if (meta_ver >= 15 && proto.stored_fields) { // DocstoreRT_c::Load (docstore.cpp:1685-1699): the stored fields' text, stepped over
+      const uint64_t nd = r.zint();
+      for (uint64_t i = 0; i < nd && !r.bad; ++i) {
+        const uint64_t len = r.zint();
+        if (!r.need((size_t)len)) break;
+        r.at += (size_t)len;
+      }
+      if (r.bad) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: docstore runs past the file", rname.c_str(), si);
+    }
+    if ((rc = rt_vector(r, 8, "ram-infixes", rname.c_str(), infix))) return rc;
+
+    // ---- walk the segment's dictionary: RtWordReader_t::UnzipWord (:528-575)
+    std::vector<uint64_t> W;
+    std::vector<uint32_t> Rw, H;
+    std::vector<char> wtext;
+    std::vector<uint32_t> woff;
+    std::vector<uint64_t> wordids;
+    RtBytes wr{words.data(), words.size()};
+    uint8_t packed[260];
+    packed[0] = 0;
+    uint64_t wordid = 0, doc_off = 0;
+    uint32_t n_in_cp = 0, term = 0;
+    while (wr.at < wr.n) {
+      if (++n_in_cp == words_checkpoint) doc_off = 0, n_in_cp = 1, wordid = word_dict ? wordid : 0;
+      if (word_dict) {
+        uint32_t match, delta;
+        const uint8_t pk = wr.p[wr.at++];
+        if (pk & 0x80u)
+          delta = ((pk >> 4) & 7u) + 1u, match = pk & 15u;
+        else {
+          delta = pk & 127u;
+          if (wr.at >= wr.n) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: truncated keyword", rname.c_str(), si);
+          match = wr.p[wr.at++];
+        }
+        if (match > packed[0] || match + delta > 255u || wr.n - wr.at < delta) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: bad front-coded keyword", rname.c_str(), si);
+        packed[0] = (uint8_t)(match + delta);
+        memcpy(packed + 1 + match, wr.p + wr.at, delta);
+        wr.at += delta;
+        woff.push_back((uint32_t)wtext.size());
+        wtext.insert(wtext.end(), packed + 1, packed + 1 + packed[0]);
+        wtext.push_back(0);
+      } else {
+        wordid += wr.zip();
+        wordids.push_back(wordid);
+      }
+      const uint64_t n_docs = wr.zip(), n_hits = wr.zip();
+      doc_off += wr.zip();
+      if (wr.bad || doc_off > docs.size() || n_docs > docs.size() || n_hits > hits.size() + n_docs)
+        return mrk_fail(MRK_E_FORMAT, "%s: segment %u: dictionary entry %u points past the doclists", rname.c_str(), si, term);
+      // ---- its docs: RtDocReader_t::UnzipDoc (:397-421); rowid deltas start from INVALID_ROWID (~0: the first delta wraps)
+      RtBytes dr{docs.data(), docs.size(), (size_t)doc_off};
+      uint32_t rowid = 0xFFFFFFFFu;
+      for (uint64_t d = 0; d < n_docs; ++d) {
+        rowid += (uint32_t)dr.zip();
+        dr.zip(); // field mask (recomputed from the hits by the writer below)
+        const uint64_t dh = dr.zip();
+        uint32_t hit1 = 0;
+        uint64_t hoff = 0;
+        if (dh == 1) {
+          const uint64_t a = dr.zip(), b = dr.zip();
+          hit1 = (uint32_t)(a + (b << 24));
+        } else
+          hoff = dr.zip();
+        if (dr.bad || rowid >= rows || dh == 0 || (dh != 1 && hoff > hits.size()))
+          return mrk_fail(MRK_E_FORMAT, "%s: segment %u: word %u: bad doclist entry", rname.c_str(), si, term);
+        if (dh == 1) {
+          W.push_back(term + 1), Rw.push_back(rowid), H.push_back(hit1);
+          continue;
+        }
+        RtBytes hr{hits.data(), hits.size(), (size_t)hoff}; // RtHitReader_t::UnzipHit (:612-622)
+        uint32_t last = 0;
+        for (uint64_t k = 0; k < dh; ++k) {
+          last += (uint32_t)hr.zip();
+          if (hr.bad) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: word %u: hitlist runs past the segment", rname.c_str(), si, term);
+          W.push_back(term + 1), Rw.push_back(rowid), H.push_back(last);
+        }
+      }
+      ++term;
+    }
+    // ---- the same postings in the disk format
+    mrk_host_index* h = nullptr;
+    rc = mrk_index_from_hits(W.data(), Rw.data(), H.data(), W.size(), term, proto.info.skiplist_block_size ? proto.info.skiplist_block_size : 128u,
+                             proto.info.hit_format, &h);
+    if (rc != MRK_OK) return rc;
+    rt->seg.push_back(h);
+    h->from_files = true;
+    h->info = proto.info;
+    h->info.total_docs = rows;
+    h->info.n_checkpoints = 0;
+    h->fields = proto.fields;
+    h->attrs = proto.attrs;
+    h->words = wtext;
+    h->word_off = woff;
+    if (!word_dict)
+      for (size_t i = 0; i < h->dict.size() && i < wordids.size(); ++i) h->dict[i].wordid = wordids[i];
+    h->dead = dead;
+    for (uint32_t x = 0; x < rows; ++x) h->info.n_dead += (dead[x >> 5] >> (x & 31u)) & 1u;
+    if (rows && rowdata.size() % ((size_t)rows * 4) == 0) { // CSphRowitem rows, the schema's stride
+      h->attr_stride = (uint32_t)(rowdata.size() / 4 / rows);
+      h->docinfo_rows = rows;
+      h->attr_rows.resize(rowdata.size() / 4);
+      memcpy(h->attr_rows.data(), rowdata.data(), rowdata.size());
+    }
+  }
+  if (r.bad) return mrk_fail(MRK_E_FORMAT, "%s: failed to parse (unexpected eof)", rname.c_str());
+  return MRK_OK;
+}
+
+} // namespace
+
+extern "C" int mrk_rt_ram_open(const char* path_prefix, mrk_rt_ram** out) {
+  if (!path_prefix || !out) return mrk_fail(MRK_E_INVAL, "mrk_rt_ram_open: null argument");
+  *out = nullptr;
+  mrk_rt_ram* rt = new (std::nothrow) mrk_rt_ram();
+  if (!rt) return mrk_fail(MRK_E_NOMEM, "out of memory");
+  int rc;
+  try { // sizes come from untrusted files
+    rc = rt_open(path_prefix, rt);
+  } catch (const std::bad_alloc&) {
+    rc = mrk_fail(MRK_E_NOMEM, "%s: out of memory reading the RAM chunk", path_prefix);
+  } catch (const std::exception& e) {
+    rc = mrk_fail(MRK_E_FORMAT, "%s: %s", path_prefix, e.what());
+  }
+  if (rc != MRK_OK) {
+    delete rt;
+    return rc;
+  }
+  *out = rt;
+  return MRK_OK;
+}
+extern "C" uint32_t mrk_rt_ram_segments(const mrk_rt_ram* rt) { return rt ? (uint32_t)rt->seg.size() : 0u; }
+extern "C" int mrk_rt_ram_take(mrk_rt_ram* rt, uint32_t i, mrk_host_index** out) {
+  if (!rt || !out || i >= rt->seg.size() || !rt->seg[i]) return mrk_fail(MRK_E_INVAL, "mrk_rt_ram_take: no segment %u (or taken already)", i);
+  *out = rt->seg[i];
+  rt->seg[i] = nullptr;
+  return MRK_OK;
+}
+extern "C" void mrk_rt_ram_free(mrk_rt_ram* rt) { delete rt; }

@@ -1229,8 +1229,9 @@ def test_index_files_on_device(orc, dev, tmp_path):
     from test_index_files import IDX, synth, write_index
     m, ctx, batch = dev
     # 1. reference fixtures: one row each, every keyword and keyword pair under every ranker
-    for name in ("t250_plain2", "t233_test", "t233_reload", "t406_index0"):
-        hi = m.open_index(os.path.join(IDX, name))
+    # (+ two RT RAM segments, mrk_rt_ram_open: decoded from the RT codecs and searched like any other segment)
+    for name in ("t250_plain2", "t233_test", "t233_reload", "t406_index0", "rt:t406_index", "rt:t406_idx320"):
+        hi = m.open_rt_ram(os.path.join(IDX, name[3:]))[0] if name.startswith("rt:") else m.open_index(os.path.join(IDX, name))
         qs = []
         ws = list(range(len(hi.words)))
         for rk in (m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_WORDCOUNT, m.SPH_RANK_SPH04, m.SPH_RANK_PROXIMITY):

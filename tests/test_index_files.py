@@ -297,3 +297,74 @@ def test_header_counts_are_bounded_before_they_are_trusted(tmp_path):
         assert time.time() - t0 < 60
         assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - rss0 < 600_000  # KiB: no count was allocated from unchecked
         assert opened > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RT RAM chunks: <prefix>.meta + <prefix>.ram, the files RtIndex_c::SaveMeta / SaveRamChunk wrote
+#   t406_index    test/test_406/data/index.{meta,ram}          meta v17 (stored field: a docstore rides in the segment), RAM row (2 'doc two');
+#                                                              with its disk chunk t406_index0 the table test_406 imports: rows 2, 1 (model.bin)
+#   t406_idx320   test/test_406/data/rel320/idx320.{meta,ram}  written by release 3.2.0; 'select .. where match(@keywords kw1)' -> id 10 (model.bin)
+#   ql_rt         test/ql/data/rt.{meta,ram}                   meta v7: older than the reference itself still loads (LoadMeta: "prior to v.14")
+def test_rt_ram_chunks(orc):
+    import manticoresearch_amd as m
+
+    segs = m.open_rt_ram(os.path.join(IDX, "t406_index"))
+    assert len(segs) == 1
+    hi = segs[0]
+    assert (hi.total_docs, hi.fields, hi.words, hi.info["word_dict"], hi.info["n_dead"]) == (1, ["title"], ["doc", "two"], 1, 0)
+    assert hi.attrs == {"id": (6, 0, 64)} and hi.attr_rows.tolist() == [[2, 0]]
+    oi = orc_index(orc, hi)
+    for w, pos in (("doc", 1), ("two", 2)):
+        t = hi.find_word(w)
+        rows, fields, nhits, _ = oi.decode_doclist(t)
+        assert rows.tolist() == [0] and fields.tolist() == [1] and nhits.tolist() == [1]
+    # the RAM segment answers like a disk chunk: rank both parts of the table and merge (ids from the attribute rows)
+    dk = m.open_index(os.path.join(IDX, "t406_index0"))
+    got = []
+    for part in (hi, dk):
+        r = orc.FlatQuery(orc.term(part.find_word("doc"), 1), ranker=orc.RANK_BM25).run(orc_index(orc, part))
+        got += [int(part.attr_rows[x][0]) for x in r.rowid]
+    assert sorted(got) == [1, 2]  # test_406/model.bin: "select * from test1" -> ids 2, 1
+
+    (old,) = m.open_rt_ram(os.path.join(IDX, "t406_idx320"))
+    assert (old.total_docs, old.fields, old.words, old.info["version"]) == (1, ["title", "keywords"], ["data", "kw1", "of"], 58)
+    assert int(old.attr_rows[0][0]) == 10 and old.attrs["idd"] == (1, 128, 32)
+    q = orc.FlatQuery(orc.term(old.find_word("kw1"), 1, field_mask=1 << old.fields.index("keywords")), ranker=orc.RANK_PROXIMITY_BM25)
+    r = q.run(orc_index(orc, old))
+    assert [int(old.attr_rows[x][0]) for x in r.rowid] == [10]  # model.bin: match('@keywords kw1') -> id 10
+    assert orc.FlatQuery(orc.term(old.find_word("kw1"), 1, field_mask=1 << old.fields.index("title")), ranker=orc.RANK_BM25).run(orc_index(orc, old)).total_found == 0
+
+    with pytest.raises(m.MrkError, match="meta v.7"):
+        m.open_rt_ram(os.path.join(IDX, "ql_rt"))
+    with pytest.raises(m.MrkError):
+        m.open_rt_ram(os.path.join(IDX, "no_such_index"))
+
+
+def test_rt_ram_rejects_damage(tmp_path):
+    """Truncations and bit flips of a RAM chunk end in an error code or in a segment that passes validation, never in a crash."""
+    import manticoresearch_amd as m
+
+    meta = open(os.path.join(IDX, "t406_idx320.meta"), "rb").read()
+    ram = open(os.path.join(IDX, "t406_idx320.ram"), "rb").read()
+    rng = np.random.default_rng(5)
+    n_err = 0
+    for trial in range(400):
+        mb, rb = bytearray(meta), bytearray(ram)
+        target = rb if trial % 4 else mb
+        k = int(rng.integers(0, 3))
+        if k == 0:
+            del target[int(rng.integers(0, len(target))):]
+        elif k == 1:
+            target[int(rng.integers(0, len(target)))] ^= 1 << int(rng.integers(0, 8))
+        else:
+            i = int(rng.integers(0, len(target) - 4))
+            target[i:i + 4] = struct.pack("<I", int(rng.choice([0xFFFFFFFF, 0x7FFFFFFF, 0x40000000, 65536])))
+        p = str(tmp_path / "x")
+        open(p + ".meta", "wb").write(mb)
+        open(p + ".ram", "wb").write(rb)
+        try:
+            for hi in m.open_rt_ram(p):
+                m.validate_index(hi)
+        except m.MrkError:
+            n_err += 1
+    assert n_err > 100
