@@ -148,6 +148,13 @@ typedef struct {
   /* FLOATRANGE over a 32-bit float attribute (Filter_FloatRange, sphinxfilter.cpp:275-300): the row's dword read as a float
      (sphDW2F) against [fmin, fmax] with m_bHasEqualMin / Max; the reference's float filter has no open-sided form */
   float fmin, fmax;
+  /* A multi-value attribute (SPH_ATTR_UINT32SET / INT64SET): mva_bits = 32 / 64 (0 = a plain row attribute).  Its values live,
+     sorted, in the blob pool (mrk_segment_set_blobs) as blob attribute blob_attr_id of the row's n_blob_attrs
+     (CSphAttrLocator::m_iBlobAttrId / m_nBlobAttrs; the row's blob offset is its second attribute, sphGetBlobRowOffset).
+     VALUES: any of the doc's values is in the set (Filter_MVAValues_Any_c) or, mva_all, every one is (.._All_c);
+     RANGE: some value inside [min, max] (MvaEval_RangeAny) or all of them (MvaEval_RangeAll); sphinxfilter.h:160-240,
+     sphinxfilter.cpp:340-383.  A doc without values fails both forms. */
+  int32_t mva_bits, mva_all, blob_attr_id, n_blob_attrs;
 } mrk_filter;
 
 /* CSphQuery fields that reach the ranker + the query tree */
@@ -239,6 +246,12 @@ int mrk_segment_set_dead_rows(mrk_segment* seg, const uint32_t* bitmap, uint64_t
 /* Row-wise attribute storage (.spa: CSphRowitem rows[n_rows][stride], sphinx.cpp GetDocinfoByRowID) copied to HBM for the
    filters of mrk_query; rows = NULL drops it.  Waits for the context's running batches like mrk_segment_set_dead_rows. */
 int mrk_segment_set_attrs(mrk_segment* seg, const uint32_t* rows, uint32_t stride_dwords, uint64_t n_rows);
+/* The blob pool of the attribute storage (.spb file / RtSegment_t::m_dBlobs: per row a blob row = length-size byte, cumulative
+   lengths, data; attribute.cpp:495-513) copied to HBM for MVA filters.  rows / stride / n_rows = the rows given to
+   mrk_segment_set_attrs: every row's blob row is walked here once (offset, header and lengths inside the pool), so that
+   untrusted bytes never become an out-of-bounds device read.  pool = NULL drops it. */
+int mrk_segment_set_blobs(mrk_segment* seg, const uint8_t* pool, uint64_t pool_len, uint32_t n_blob_attrs, const uint32_t* rows,
+                          uint32_t stride_dwords, uint64_t n_rows);
 /* device bytes held, and the reference-format doclist bytes of one term */
 uint64_t mrk_segment_device_bytes(const mrk_segment* seg);
 
@@ -416,6 +429,9 @@ int mrk_host_index_attr(const mrk_host_index* h, uint32_t i, mrk_attr_info* out)
 const uint32_t* mrk_host_index_attr_rows(const mrk_host_index* h, uint32_t* stride_dwords, uint64_t* n_rows);
 /* .spm bitmap (bit rowid & 31 of word rowid >> 5), as mrk_segment_set_dead_rows takes it; NULL = no map */
 const uint32_t* mrk_host_index_dead_rows(const mrk_host_index* h, uint64_t* n_rows);
+/* the blob pool (.spb file as it is / an RT segment's m_dBlobs), NULL = none; n_blob_attrs = the schema's blob-stored attributes
+   (strings, MVAs, JSON: those with bit_count 0, in schema order = their blob attribute ids) */
+const uint8_t* mrk_host_index_blobs(const mrk_host_index* h, uint64_t* len, uint32_t* n_blob_attrs);
 
 /* ---- RT index RAM chunk (host only) ---------------------------------------------------------------------------------------
    path_prefix + ".meta" / ".ram" as RtIndex_c::SaveMeta / SaveRamChunk write them (sphinxrt.cpp:3560-3640, 4034-4103; meta

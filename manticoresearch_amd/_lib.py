@@ -47,7 +47,8 @@ class Filter(C.Structure):
     _fields_ = [("kind", C.c_int32), ("bit_offset", C.c_int32), ("bit_count", C.c_int32), ("exclude", C.c_int32),
                 ("has_equal_min", C.c_int32), ("has_equal_max", C.c_int32), ("open_left", C.c_int32), ("open_right", C.c_int32),
                 ("min_value", C.c_int64), ("max_value", C.c_int64), ("values", C.POINTER(C.c_int64)), ("n_values", C.c_int32),
-                ("fmin", C.c_float), ("fmax", C.c_float)]
+                ("fmin", C.c_float), ("fmax", C.c_float), ("mva_bits", C.c_int32), ("mva_all", C.c_int32), ("blob_attr_id", C.c_int32),
+                ("n_blob_attrs", C.c_int32)]
 
 
 class Query(C.Structure):
@@ -146,6 +147,8 @@ SYMBOLS = [
     ("mrk_host_index_dead_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("mrk_host_index_attr", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(AttrInfo)]),
     ("mrk_host_index_attr_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("mrk_segment_set_blobs", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint64]),
+    ("mrk_host_index_blobs", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     ("mrk_rt_ram_open", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("mrk_rt_ram_segments", C.c_uint32, [C.c_void_p]),
     ("mrk_rt_ram_take", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),

@@ -145,6 +145,10 @@ def _wrap_file_index(h) -> HostIndex:
     hi.attr_rows = None  # the .spa rows for Segment.set_attrs()
     if p:
         hi.attr_rows = np.frombuffer((C.c_uint32 * (arows.value * stride.value)).from_address(p), dtype=np.uint32).reshape(arows.value, stride.value).copy()
+    blen, nblob = C.c_uint64(), C.c_uint32()
+    p = L.mrk_host_index_blobs(h, C.byref(blen), C.byref(nblob))
+    hi.blobs = np.frombuffer((C.c_uint8 * blen.value).from_address(p), dtype=np.uint8).copy() if p else None  # blob pool (strings, MVAs)
+    hi.n_blob_attrs = int(nblob.value)
     nrows = C.c_uint64()
     p = L.mrk_host_index_dead_rows(h, C.byref(nrows))
     hi.dead_bitmap = hi.dead_rows = None
@@ -296,6 +300,10 @@ class Filter:
     open_right: bool = False
     fmin: Optional[float] = None  # both set => SPH_FILTER_FLOATRANGE over a 32-bit float attribute
     fmax: Optional[float] = None
+    mva_bits: int = 0             # 32 / 64: a multi-value attribute in the blob pool (Segment.set_blobs); bit_offset / bit_count unused
+    mva_all: bool = False         # every value of the doc must pass (ALL()) instead of any (ANY())
+    blob_attr_id: int = 0         # CSphAttrLocator::m_iBlobAttrId / m_nBlobAttrs
+    n_blob_attrs: int = 0
 
     def as_dict(self) -> dict:  # the oracle's spelling
         d = dict(bit_offset=self.bit_offset, bit_count=self.bit_count, exclude=self.exclude, has_equal_min=self.has_equal_min,
@@ -304,6 +312,8 @@ class Filter:
             d["values"] = list(self.values)
         if self.fmin is not None:
             d["fmin"], d["fmax"] = float(self.fmin), float(self.fmax)
+        if self.mva_bits:
+            d.update(mva_bits=self.mva_bits, mva_all=self.mva_all, blob_attr_id=self.blob_attr_id, n_blob_attrs=self.n_blob_attrs)
         return d
 
 
@@ -377,6 +387,7 @@ class _CQueries:
                     if f.fmin is not None:
                         fl[i].fmin, fl[i].fmax = float(f.fmin), float(f.fmax)
                     fl[i].bit_offset, fl[i].bit_count, fl[i].exclude = f.bit_offset, f.bit_count, int(f.exclude)
+                    fl[i].mva_bits, fl[i].mva_all, fl[i].blob_attr_id, fl[i].n_blob_attrs = f.mva_bits, int(f.mva_all), f.blob_attr_id, f.n_blob_attrs
                     fl[i].has_equal_min, fl[i].has_equal_max = int(f.has_equal_min), int(f.has_equal_max)
                     fl[i].open_left, fl[i].open_right = int(f.open_left), int(f.open_right)
                     fl[i].min_value, fl[i].max_value = int(f.min), int(f.max)
@@ -496,6 +507,17 @@ class Segment:
         a = np.ascontiguousarray(rows, dtype=np.uint32)
         assert a.ndim == 2
         check(lib().mrk_segment_set_attrs(self._h, a.ctypes.data, a.shape[1], a.shape[0]))
+
+    def set_blobs(self, pool: Optional[np.ndarray], n_blob_attrs: int = 0, rows: Optional[np.ndarray] = None) -> None:
+        """Upload the blob pool (.spb bytes / an RT segment's m_dBlobs) for MVA filters; rows = the attribute rows given to
+        set_attrs (every row's blob row is bounds-checked against the pool here).  None drops it."""
+        if pool is None:
+            check(lib().mrk_segment_set_blobs(self._h, None, 0, 0, None, 0, 0))
+            return
+        b = np.ascontiguousarray(pool, dtype=np.uint8)
+        a = np.ascontiguousarray(rows, dtype=np.uint32)
+        assert a.ndim == 2
+        check(lib().mrk_segment_set_blobs(self._h, b.ctypes.data, b.size, n_blob_attrs, a.ctypes.data, a.shape[1], a.shape[0]))
 
     def set_dead_rows(self, bitmap: Optional[np.ndarray]) -> None:
         """Install the segment's dead-row map (uint32 words, DeadRowMap_c layout); None clears it."""

@@ -47,12 +47,14 @@ struct DevSegment {
   uint32_t n_windows;       // windows per bitmap = ceil(total_docs / 2048)
   const uint32_t* attrs;    // row-wise attributes (.spa rows, attr_stride dwords each) or NULL
   uint32_t attr_stride;
+  const uint8_t* blobs;     // blob pool (.spb / m_dBlobs) for MVA filters or NULL; every row's blob row was bounds-checked at load
 };
 
 struct DevFilter { // mrk_filter with the values inline
   uint32_t kind;                  // MRK_FILTER_* | exclude << 8 | has_equal_min << 9 | has_equal_max << 10 | open_left << 11 | open_right << 12
   uint32_t item, shift, bits;     // dword of the row, bit offset inside it, width (64 = two dwords)
-  uint32_t n_values, pad;
+  uint32_t n_values;
+  uint32_t mva;                   // 0 = a row attribute; else MVA width in bits | all << 8 | blob attribute id << 16 | blob attributes of the row << 24
   int64_t lo, hi;                 // RANGE
   int64_t values[MRK_MAX_FILTER_VALUES];
 };
@@ -64,6 +66,67 @@ __device__ __forceinline__ bool row_passes_filters(const DevSegment& seg, const 
   bool ok = true;
   for (uint32_t i = 0; i < n; ++i) {
     const DevFilter& F = fl[i];
+    if (F.mva) { // a multi-value attribute: sorted values in the row's blob row (attribute.cpp:495-513)
+      const uint32_t w = (F.mva & 0xffu) >> 3, all = (F.mva >> 8) & 1u, id = (F.mva >> 16) & 0xffu, nblob = F.mva >> 24;
+      const uint8_t* __restrict__ br = seg.blobs + ((uint64_t)row[2] | ((uint64_t)row[3] << 32)); // sphGetBlobRowOffset: the 2nd attribute
+      const uint32_t sz = br[0] == 0 ? 1u : br[0] == 1 ? 2u : 4u;
+      auto rd = [](const uint8_t* p, uint32_t nb) {
+        uint64_t x = 0;
+        for (uint32_t i = 0; i < nb; ++i) x |= (uint64_t)p[i] << (8 * i);
+        return x;
+      };
+      const uint64_t l1 = rd(br + 1 + id * sz, sz), l0 = id ? rd(br + 1 + (id - 1) * sz, sz) : 0;
+      const uint8_t* __restrict__ data = br + 1 + nblob * sz + l0;
+      const uint32_t nv = (uint32_t)((l1 - l0) / w);
+      auto val = [&](uint32_t i) -> int64_t { return w == 4 ? (int64_t)(uint32_t)rd(data + 4 * i, 4) : (int64_t)rd(data + 8ull * i, 8); };
+      bool pass = false;
+      const bool eq_min = (F.kind >> 9) & 1u, eq_max = (F.kind >> 10) & 1u;
+      if (nv) {
+        if ((F.kind & 0xffu) == MRK_FILTER_VALUES) {
+          if (!all) { // MvaEval_Any
+            for (uint32_t i = 0; i < nv && !pass; ++i) {
+              const int64_t x = val(i);
+              for (uint32_t k = 0; k < F.n_values; ++k) pass = pass || x == F.values[k];
+            }
+          } else { // MvaEval_All
+            pass = true;
+            for (uint32_t i = 0; i < nv && pass; ++i) {
+              const int64_t x = val(i);
+              bool in = false;
+              for (uint32_t k = 0; k < F.n_values; ++k) in = in || x == F.values[k];
+              pass = in;
+            }
+          }
+        } else if (!all) { // MvaEval_RangeAny (sphinxfilter.h:203-233): binary search for the minimum, then the value at / after it
+          int L = 0, R = (int)nv - 1;
+          bool decided = false;
+          while (L <= R) {
+            const int mid = L + (R - L) / 2;
+            const int64_t x = val((uint32_t)mid);
+            if (F.lo > x)
+              L = mid + 1;
+            else if (F.lo < x)
+              R = mid - 1;
+            else {
+              pass = eq_min || mid + 1 < (int)nv; // (the reference does not test that next value against the maximum)
+              decided = true;
+              break;
+            }
+          }
+          if (!decided && L != (int)nv) {
+            const int64_t x = val((uint32_t)L);
+            pass = eq_max ? x <= F.hi : x < F.hi;
+          }
+        } else { // MvaEval_RangeAll: the least and the largest value inside the range
+          const int64_t a = val(0), b = val(nv - 1);
+          const int64_t lo = w == 4 ? (int64_t)(uint32_t)F.lo : F.lo, hi = w == 4 ? (int64_t)(uint32_t)F.hi : F.hi; // ( (T)m_iMinValue, (T)m_iMaxValue )
+          pass = (eq_min ? a >= lo : a > lo) && (eq_max ? b <= hi : b < hi);
+        }
+      }
+      if ((F.kind >> 8) & 1u) pass = !pass;
+      ok = ok && pass;
+      continue;
+    }
     int64_t v; // sphGetRowAttr (sphinx.h:993-1014)
     if (F.bits == 64)
       v = (int64_t)((uint64_t)row[F.item] | ((uint64_t)row[F.item + 1] << 32));

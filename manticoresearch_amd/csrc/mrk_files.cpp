@@ -429,7 +429,18 @@ static int index_open(const char* path_prefix, mrk_host_index* h) {
       }
     }
   }
+  if (rc == MRK_OK) read_file(base + ".spb", h->blobs, true); // blob pool (strings, MVAs, JSON); absent when the schema has none
   return rc;
+}
+
+extern "C" const uint8_t* mrk_host_index_blobs(const mrk_host_index* h, uint64_t* len, uint32_t* n_blob_attrs) {
+  if (n_blob_attrs) {
+    *n_blob_attrs = 0;
+    if (h)
+      for (const mrk_host_index::Attr& a : h->attrs) *n_blob_attrs += a.bit_count == 0 ? 1u : 0u; // blob-stored: no bits in the row
+  }
+  if (len) *len = h ? h->blobs.size() : 0;
+  return h && !h->blobs.empty() ? h->blobs.data() : nullptr;
 }
 
 extern "C" int mrk_host_index_info(const mrk_host_index* h, mrk_index_info* out) {
@@ -687,6 +698,7 @@ int rt_open(const char* path_prefix, mrk_rt_ram* rt) {
     h->word_off = woff;
     if (!word_dict)
       for (size_t i = 0; i < h->dict.size() && i < wordids.size(); ++i) h->dict[i].wordid = wordids[i];
+    h->blobs = blobs;
     h->dead = dead;
     for (uint32_t x = 0; x < rows; ++x) h->info.n_dead += (dead[x >> 5] >> (x & 31u)) & 1u;
     if (rows && rowdata.size() % ((size_t)rows * 4) == 0) { // CSphRowitem rows, the schema's stride

@@ -298,6 +298,7 @@ static void mrk_segment_destroy_impl(mrk_segment* s) {
   if (s->d_pk_attr1) (void)hipFree(s->d_pk_attr1);
   if (s->d_dead) (void)hipFree(s->d_dead);
   if (s->d_attrs) (void)hipFree(s->d_attrs);
+  if (s->d_blobs) (void)hipFree(s->d_blobs);
   if (s->d_bm) (void)hipFree(s->d_bm);
   if (s->d_bm_dir) (void)hipFree(s->d_bm_dir);
   delete s;
@@ -345,6 +346,46 @@ static int mrk_segment_set_attrs_impl(mrk_segment* s, const uint32_t* rows, uint
   s->attr_rows = rows ? n_rows : 0;
   s->dev.attrs = (const uint32_t*)fresh;
   s->dev.attr_stride = rows ? stride : 0;
+  return MRK_OK;
+}
+
+// The blob pool for MVA filters.  Every row's blob row is walked on the host first (attribute.cpp:495-513: length-size byte,
+// n cumulative lengths, data): what the device later dereferences without a check was inside the pool at load.
+static int mrk_segment_set_blobs_impl(mrk_segment* s, const uint8_t* pool, uint64_t len, uint32_t n_blob, const uint32_t* rows, uint32_t stride, uint64_t n_rows) {
+  if (!s || !s->ctx) return mrk_fail(MRK_E_INVAL, "mrk_segment_set_blobs: NULL segment");
+  if (pool) {
+    if (!rows || stride < 4 || n_rows < s->total_docs) return mrk_fail(MRK_E_INVAL, "mrk_segment_set_blobs: needs the segment's attribute rows (stride >= 4 dwords: id + blob locator)");
+    if (n_blob < 1 || n_blob > 255) return mrk_fail(MRK_E_INVAL, "mrk_segment_set_blobs: %u blob attributes", n_blob);
+    for (uint64_t r = 0; r < s->total_docs; ++r) {
+      const uint32_t* row = rows + r * stride;
+      const uint64_t off = (uint64_t)row[2] | ((uint64_t)row[3] << 32);
+      if (off >= len) return mrk_fail(MRK_E_FORMAT, "row %llu: blob offset %llu past the pool (%llu bytes)", (unsigned long long)r, (unsigned long long)off, (unsigned long long)len);
+      const uint8_t* br = pool + off;
+      if (br[0] > 2) return mrk_fail(MRK_E_FORMAT, "row %llu: blob row type %u", (unsigned long long)r, br[0]);
+      const uint32_t sz = br[0] == 0 ? 1u : br[0] == 1 ? 2u : 4u;
+      const uint64_t head = 1ull + (uint64_t)n_blob * sz;
+      if (len - off < head) return mrk_fail(MRK_E_FORMAT, "row %llu: blob row header past the pool", (unsigned long long)r);
+      uint64_t prev = 0;
+      for (uint32_t a = 0; a < n_blob; ++a) {
+        uint64_t l = 0;
+        for (uint32_t i = 0; i < sz; ++i) l |= (uint64_t)br[1 + a * sz + i] << (8 * i);
+        if (l < prev || l > len - off - head) return mrk_fail(MRK_E_FORMAT, "row %llu: blob attribute %u runs past the pool", (unsigned long long)r, a);
+        prev = l;
+      }
+    }
+  }
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  void* fresh = nullptr;
+  if (pool) {
+    HIP_TRY(hipMalloc(&fresh, (size_t)len + 16));
+    HIP_TRY(hipMemset((char*)fresh + len, 0, 16));
+    HIP_TRY(hipMemcpy(fresh, pool, (size_t)len, hipMemcpyHostToDevice));
+  }
+  if (s->d_blobs) (void)hipFree(s->d_blobs);
+  s->d_blobs = fresh;
+  s->dev.blobs = (const uint8_t*)fresh;
+  s->n_blob_attrs = pool ? n_blob : 0;
   return MRK_OK;
 }
 
@@ -1545,6 +1586,9 @@ extern "C" int mrk_segment_set_dead_rows(mrk_segment* s, const uint32_t* bitmap,
 }
 extern "C" int mrk_segment_set_attrs(mrk_segment* s, const uint32_t* rows, uint32_t stride, uint64_t n_rows) {
   return on_worker(s ? s->ctx : nullptr, [&] { return mrk_segment_set_attrs_impl(s, rows, stride, n_rows); });
+}
+extern "C" int mrk_segment_set_blobs(mrk_segment* s, const uint8_t* pool, uint64_t len, uint32_t n_blob, const uint32_t* rows, uint32_t stride, uint64_t n_rows) {
+  return on_worker(s ? s->ctx : nullptr, [&] { return mrk_segment_set_blobs_impl(s, pool, len, n_blob, rows, stride, n_rows); });
 }
 extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** out) {
   return on_worker(ctx, [&] { return mrk_batch_create_impl(ctx, max_queries, out); });

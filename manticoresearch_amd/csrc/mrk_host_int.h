@@ -70,6 +70,8 @@ struct mrk_segment {
   void* d_pk_attr1 = nullptr;
   void* d_dead = nullptr;
   void* d_attrs = nullptr; // .spa rows (mrk_segment_set_attrs)
+  void* d_blobs = nullptr; // blob pool (mrk_segment_set_blobs)
+  uint32_t n_blob_attrs = 0;
   uint64_t attr_rows = 0;
   void* d_bm = nullptr;
   void* d_bm_dir = nullptr;

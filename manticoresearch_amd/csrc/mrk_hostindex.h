@@ -29,6 +29,7 @@ struct mrk_host_index {
   std::vector<uint32_t> attr_rows;  // .spa: docinfo_rows x attr_stride dwords
   uint32_t attr_stride = 0;
   uint64_t docinfo_rows = 0;
+  std::vector<uint8_t> blobs;       // blob pool: the .spb file as it is / an RT segment's m_dBlobs
   bool stored_fields = false;       // some field is FIELD_STORED (a docstore rides inside RT RAM segments)
   uint64_t payload_fields = 0;      // bit f: schema field f is a payload field (bit 63: some field >= 63)
   ~mrk_host_index() {

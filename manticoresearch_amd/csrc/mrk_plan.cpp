@@ -834,6 +834,24 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       if (f.kind != MRK_FILTER_VALUES && f.kind != MRK_FILTER_RANGE && f.kind != MRK_FILTER_FLOATRANGE)
         return mrk_fail(MRK_E_UNSUPPORTED, "query %u: filter kind %d not on the device path", qi, f.kind);
       if (f.kind == MRK_FILTER_FLOATRANGE && f.bit_count != 32) return mrk_fail(MRK_E_INVAL, "query %u: a float filter needs a 32-bit attribute", qi);
+      if (f.mva_bits) { // a multi-value attribute in the blob pool
+        if (f.mva_bits != 32 && f.mva_bits != 64) return mrk_fail(MRK_E_INVAL, "query %u: MVA width %d", qi, f.mva_bits);
+        if (f.kind == MRK_FILTER_FLOATRANGE) return mrk_fail(MRK_E_INVAL, "query %u: a float range over an MVA", qi);
+        if (!seg->dev.blobs) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: MVA filters need the segment's blob pool (mrk_segment_set_blobs)", qi);
+        if (f.n_blob_attrs < 1 || f.n_blob_attrs > 255 || f.blob_attr_id < 0 || f.blob_attr_id >= f.n_blob_attrs || (uint32_t)f.n_blob_attrs != seg->n_blob_attrs)
+          return mrk_fail(MRK_E_INVAL, "query %u: blob attribute %d of %d (the segment's rows hold %u)", qi, f.blob_attr_id, f.n_blob_attrs, seg->n_blob_attrs);
+        if (seg->dev.attr_stride < 4) return mrk_fail(MRK_E_INVAL, "query %u: rows of %u dwords hold no blob locator", qi, seg->dev.attr_stride);
+        d.kind = (uint32_t)f.kind | (f.exclude ? 1u << 8 : 0) | (f.has_equal_min ? 1u << 9 : 0) | (f.has_equal_max ? 1u << 10 : 0);
+        d.mva = (uint32_t)f.mva_bits | (f.mva_all ? 1u << 8 : 0) | ((uint32_t)f.blob_attr_id << 16) | ((uint32_t)f.n_blob_attrs << 24);
+        d.lo = f.min_value, d.hi = f.max_value;
+        if (f.kind == MRK_FILTER_VALUES) {
+          if (f.n_values < 1 || !f.values) return mrk_fail(MRK_E_INVAL, "query %u: values filter without values", qi);
+          if (f.n_values > MRK_MAX_FILTER_VALUES) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: %d filter values (device path: <= %d)", qi, f.n_values, MRK_MAX_FILTER_VALUES);
+          d.n_values = (uint32_t)f.n_values;
+          for (int k = 0; k < f.n_values; ++k) d.values[k] = f.values[k];
+        }
+        continue;
+      }
       const bool wide = f.bit_count == 64;
       if (f.bit_offset < 0 || f.bit_count < 1 || (!wide && (f.bit_count > 32 || (f.bit_offset & 31) + f.bit_count > 32)) || (wide && (f.bit_offset & 31)) ||
           (uint64_t)(f.bit_offset + f.bit_count) > (uint64_t)seg->dev.attr_stride * 32)

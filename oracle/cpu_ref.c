@@ -2533,6 +2533,61 @@ static int filters_pass(const orc_index* idx, const orc_query* q, uint32_t rowid
   const uint32_t* row = idx->attrs + (size_t)rowid * (size_t)idx->attr_stride;
   for (int i = 0; i < q->n_filters; i++) {
     const orc_filter* f = &q->filters[i];
+    if (f->mva_bits) { /* Filter_MVAValues_Any_c / _All_c / Filter_MVARange_Any_c / _All_c (sphinxfilter.cpp:340-383) */
+      int pass = 0;
+      if (idx->blobs) {
+        const uint8_t* br = idx->blobs + ((uint64_t)row[2] | ((uint64_t)row[3] << 32)); /* sphGetBlobRowOffset */
+        const int sz = br[0] == 0 ? 1 : br[0] == 1 ? 2 : 4;                              /* GetBlobAttr, attribute.cpp:495-513 */
+        uint64_t l1 = 0, l0 = 0;
+        memcpy(&l1, br + 1 + f->blob_attr_id * sz, (size_t)sz);
+        if (f->blob_attr_id) memcpy(&l0, br + 1 + (f->blob_attr_id - 1) * sz, (size_t)sz);
+        const uint8_t* data = br + 1 + f->n_blob_attrs * sz + l0;
+        const int w = f->mva_bits / 8, nv = (int)((l1 - l0) / (uint64_t)w);
+#define MVA_AT(i_) (w == 4 ? (int64_t)({ uint32_t t_; memcpy(&t_, data + 4 * (size_t)(i_), 4); t_; }) : ({ int64_t t_; memcpy(&t_, data + 8 * (size_t)(i_), 8); t_; }))
+        if (nv > 0) {
+          if (f->kind == ORC_FILTER_VALUES && !f->mva_all) { /* MvaEval_Any (sphinxfilter.h:160-184) */
+            for (int a = 0; a < nv && !pass; a++)
+              for (int k = 0; k < f->n_values; k++)
+                if (MVA_AT(a) == f->values[k]) pass = 1;
+          } else if (f->kind == ORC_FILTER_VALUES) { /* MvaEval_All (:187-201) */
+            pass = 1;
+            for (int a = 0; a < nv && pass; a++) {
+              int in = 0;
+              for (int k = 0; k < f->n_values; k++)
+                if (MVA_AT(a) == f->values[k]) in = 1;
+              pass = in;
+            }
+          } else if (!f->mva_all) { /* MvaEval_RangeAny (:203-233) */
+            int L = 0, R = nv - 1, decided = 0;
+            while (L <= R) {
+              const int mid = L + (R - L) / 2;
+              const int64_t x = MVA_AT(mid);
+              if (f->min_value > x)
+                L = mid + 1;
+              else if (f->min_value < x)
+                R = mid - 1;
+              else {
+                pass = f->has_equal_min || mid + 1 < nv;
+                decided = 1;
+                break;
+              }
+            }
+            if (!decided && L != nv) {
+              const int64_t x = MVA_AT(L);
+              pass = f->has_equal_max ? x <= f->max_value : x < f->max_value;
+            }
+          } else { /* MvaEval_RangeAll (:244-253): ( *L, *R, (T)m_iMinValue, (T)m_iMaxValue ) */
+            const int64_t a = MVA_AT(0), b = MVA_AT(nv - 1);
+            const int64_t lo = w == 4 ? (int64_t)(uint32_t)f->min_value : f->min_value, hi = w == 4 ? (int64_t)(uint32_t)f->max_value : f->max_value;
+            pass = (f->has_equal_min ? a >= lo : a > lo) && (f->has_equal_max ? b <= hi : b < hi);
+          }
+        }
+#undef MVA_AT
+      }
+      if (f->exclude) pass = !pass;
+      if (!pass) return 0;
+      continue;
+    }
     const int item = f->bit_offset >> 5;
     int64_t v;
     if (f->bit_count == 32)

@@ -108,6 +108,7 @@ typedef struct {
   const uint32_t* dead_rows; /* DeadRowMap_c bitmap (killlist.h:22-46) or NULL */
   const uint32_t* attrs;     /* row-wise attribute storage (.spa): CSphRowitem rows[total_docs][attr_stride], or NULL */
   int attr_stride;
+  const uint8_t* blobs;      /* blob pool (.spb / m_dBlobs) for MVA filters, or NULL */
 } orc_index;
 
 /* CSphFilterSettings over an integer attribute (sphinx.h:2461-2496), resolved to the attribute's locator */
@@ -121,6 +122,7 @@ typedef struct {
   const int64_t* values; /* ascending */
   int n_values;
   float fmin, fmax; /* FLOATRANGE */
+  int mva_bits, mva_all, blob_attr_id, n_blob_attrs; /* an MVA in the blob pool: 32 / 64 bits wide, ANY / ALL form */
 } orc_filter;
 
 /* ---- query tree ---- */

@@ -46,7 +46,7 @@ class _Index(C.Structure):
     _fields_ = [("spd", C.c_void_p), ("spd_len", C.c_size_t), ("spp", C.c_void_p), ("spp_len", C.c_size_t),
                 ("spe", C.c_void_p), ("spe_len", C.c_size_t), ("dict", C.c_void_p), ("n_terms", C.c_uint32),
                 ("total_docs", C.c_int64), ("skiplist_block_size", C.c_int), ("inline_hits", C.c_int),
-                ("n_fields", C.c_int), ("dead_rows", C.c_void_p), ("attrs", C.c_void_p), ("attr_stride", C.c_int)]
+                ("n_fields", C.c_int), ("dead_rows", C.c_void_p), ("attrs", C.c_void_p), ("attr_stride", C.c_int), ("blobs", C.c_void_p)]
 
 
 class _Node(C.Structure):
@@ -59,7 +59,8 @@ class _Filter(C.Structure):
     _fields_ = [("kind", C.c_int), ("bit_offset", C.c_int), ("bit_count", C.c_int), ("exclude", C.c_int),
                 ("has_equal_min", C.c_int), ("has_equal_max", C.c_int), ("open_left", C.c_int), ("open_right", C.c_int),
                 ("min_value", C.c_int64), ("max_value", C.c_int64), ("values", C.POINTER(C.c_int64)), ("n_values", C.c_int),
-                ("fmin", C.c_float), ("fmax", C.c_float)]
+                ("fmin", C.c_float), ("fmax", C.c_float), ("mva_bits", C.c_int), ("mva_all", C.c_int), ("blob_attr_id", C.c_int),
+                ("n_blob_attrs", C.c_int)]
 
 
 class _Query(C.Structure):
@@ -137,6 +138,7 @@ class Index:
     n_fields: int = 2
     dead_rows: Optional[np.ndarray] = None  # uint32 bitmap, DeadRowMap_c layout
     attrs: Optional[np.ndarray] = None      # uint32 [total_docs, stride]: the .spa rows
+    blobs: Optional[np.ndarray] = None      # uint8: the blob pool (MVA filters)
 
     def c_struct(self) -> _Index:
         s = _Index()
@@ -151,6 +153,7 @@ class Index:
         s.dead_rows = self.dead_rows.ctypes.data if self.dead_rows is not None else None
         s.attrs = self.attrs.ctypes.data if self.attrs is not None else None
         s.attr_stride = int(self.attrs.shape[1]) if self.attrs is not None else 0
+        s.blobs = self.blobs.ctypes.data if self.blobs is not None else None
         return s
 
     def decode_doclist(self, term_id: int):
@@ -310,6 +313,8 @@ class FlatQuery:
                 c = arr[i]
                 c.kind = FILTER_VALUES if "values" in f else 2 if "fmin" in f else FILTER_RANGE  # 2 = ORC_FILTER_FLOATRANGE
                 c.fmin, c.fmax = float(f.get("fmin", 0.0)), float(f.get("fmax", 0.0))
+                c.mva_bits, c.mva_all = int(f.get("mva_bits", 0)), int(f.get("mva_all", False))
+                c.blob_attr_id, c.n_blob_attrs = int(f.get("blob_attr_id", 0)), int(f.get("n_blob_attrs", 0))
                 c.bit_offset, c.bit_count, c.exclude = f["bit_offset"], f["bit_count"], int(f.get("exclude", False))
                 c.has_equal_min, c.has_equal_max = int(f.get("has_equal_min", True)), int(f.get("has_equal_max", True))
                 c.open_left, c.open_right = int(f.get("open_left", False)), int(f.get("open_right", False))

@@ -134,3 +134,26 @@ def synth_postings(rng: np.random.Generator, n_docs: int, probs: Sequence[float]
     if not W:
         return np.zeros(0, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint32)
     return np.concatenate(W), np.concatenate(R), np.concatenate(H)
+
+
+def build_blob_pool(rows_values, header: int = 8):
+    """The attribute blob pool as BlobRowBuilder writes it (attribute.cpp:22-46, 495-513): per row a blob row = one byte for the
+    width of the length fields (0 / 1 / 2 = 1 / 2 / 4 bytes, by the row's total data size), the blob attributes' CUMULATIVE
+    lengths, then their bytes back to back.  rows_values[r] = [bytes of blob attribute 0, bytes of attribute 1, ...]
+    (an MVA = its sorted values as little-endian 32- / 64-bit integers).  -> (pool uint8 array, per-row offsets)."""
+    pool = bytearray(header)  # a .spb file starts with the used size
+    offs = []
+    for vals in rows_values:
+        total = sum(len(v) for v in vals)
+        kind = 0 if total < 256 else 1 if total < 65536 else 2
+        sz = (1, 2, 4)[kind]
+        offs.append(len(pool))
+        pool.append(kind)
+        acc = 0
+        for v in vals:
+            acc += len(v)
+            pool += acc.to_bytes(sz, "little")
+        for v in vals:
+            pool += bytes(v)
+    pool[:8] = len(pool).to_bytes(8, "little")[:header] if header else b""
+    return np.frombuffer(bytes(pool), np.uint8).copy(), offs

@@ -1424,6 +1424,69 @@ def test_before_operator(orc, dev, block, fmt):
         seg.close()
 
 
+# ------------------------------------------------------------------ MVA filters over the blob pool
+def test_mva_filters(orc, dev):
+    """Filter_MVAValues_Any_c / _All_c / Filter_MVARange_Any_c / _All_c (sphinxfilter.cpp:340-383) over 32- and 64-bit multi-value
+    attributes in the blob pool: device == oracle, with trees, hit rankers, a second plain filter, dead rows; a damaged pool is
+    refused at mrk_segment_set_blobs."""
+    from test_oracle_filters import mva_rows
+    m, ctx, batch = dev
+    if ctx_path(ctx) != 0:
+        pytest.skip("filters run on the packed path")
+    rng = np.random.default_rng(4242)
+    n_docs = 30000
+    probs = [0.5, 0.3, 0.1, 0.02]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=2, max_pos=12)
+    hi = m.index_from_hits(W, R, H, n_terms=len(probs), total_docs=n_docs, n_fields=2)
+    rows, pool, v32, v64 = mva_rows(rng, n_docs)
+    rows = np.concatenate([rows, rng.integers(0, 9, (n_docs, 1)).astype(np.uint32)], axis=1)  # + a plain attribute at dword 4
+    B = 1 << 33
+    F = m.Filter
+
+    def rand_mva():
+        attr = int(rng.integers(0, 2))
+        k = int(rng.integers(0, 4))
+        common = dict(mva_bits=(32, 64)[attr], blob_attr_id=attr, n_blob_attrs=2, exclude=bool(rng.random() < 0.25))
+        scale = 1 if attr == 0 else B
+        lo = int(rng.integers(0, 35)) if attr == 0 else int(rng.integers(-20, 15))
+        if k == 0:
+            return F(0, 0, values=sorted(set(int(x) * scale for x in (rng.integers(0, 40, 4) if attr == 0 else rng.integers(-20, 20, 4)))), **common)
+        if k == 1:
+            return F(0, 0, values=sorted(set(int(x) * scale for x in (rng.integers(0, 40, 8) if attr == 0 else rng.integers(-20, 20, 8)))), mva_all=True, **common)
+        return F(0, 0, min=lo * scale, max=(lo + int(rng.integers(0, 12))) * scale, mva_all=(k == 3), has_equal_min=bool(rng.random() < 0.6),
+                 has_equal_max=bool(rng.random() < 0.6), **common)
+
+    qs = []
+    rankers = [m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_SPH04]
+    for i in range(120):
+        a, b = (int(t) for t in rng.choice(len(probs), 2, replace=False))
+        root = [kw(m, a, 1), m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), OR(m, kw(m, a, 1), kw(m, b, 2)), PHRASE(m, kw(m, a, 1), kw(m, b, 2))][i % 4]
+        fl = [rand_mva()] + ([F(128, 32, values=[1, 4, 7])] if rng.random() < 0.3 else [])
+        qs.append(m.Query(root, ranker=int(rng.choice(rankers)), max_matches=int(rng.choice([20, 1000])), filters=fl))
+    seg = m.Segment(ctx, hi)
+    oi = orc_index_of(orc, hi)
+    oi.attrs, oi.blobs = rows, pool
+    try:
+        seg.set_attrs(rows)
+        assert batch.search(seg, qs[:1])[0].status == -2  # no blob pool yet: declined
+        bad = pool.copy()
+        bad[int(rows[77][2]) + 1] = 250  # a length that runs past the pool's end for a short row
+        with pytest.raises(m.MrkError):
+            seg.set_blobs(bad[: int(rows[-1][2])], 2, rows)  # (and the last rows' offsets lie past the truncated pool)
+        seg.set_blobs(pool, 2, rows)
+        n_found = 0
+        for q, g in zip(qs, batch.search(seg, qs)):
+            want = to_orc(orc, q).run(oi)
+            assert g.status == 0 and g.total_found == want.total_found, (g.status, g.total_found, want.total_found, q.filters)
+            assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+            n_found += g.total_found
+        assert n_found > 20000, n_found
+        with pytest.raises(m.MrkError, match="blob attribute"):  # a locator that disagrees with the pool the segment was given: a caller's error
+            batch.search(seg, [m.Query(kw(m, 0, 1), filters=[F(0, 0, values=[1], mva_bits=32, blob_attr_id=1, n_blob_attrs=3)])])
+    finally:
+        seg.close()
+
+
 # ------------------------------------------------------------------ attribute filters (EarlyReject)
 def test_attribute_filters(orc, dev):
     """SPH_FILTER_VALUES / SPH_FILTER_RANGE over integer attributes of the row-wise storage (32-bit, 64-bit, bit fields) and

@@ -368,3 +368,22 @@ def test_rt_ram_rejects_damage(tmp_path):
         except m.MrkError:
             n_err += 1
     assert n_err > 100
+
+
+def test_blob_pool_of_reference_files():
+    """The blob pool travels with the index: the string attribute of test_233's index (the used part of its .spb: the first qword
+    is the used size) and of the release-3.2.0 RT segment decode to the values the tests' model.bin shows."""
+    import manticoresearch_amd as m
+
+    def blob_attr(pool, off, attr_id, n_attrs):  # GetBlobAttr, attribute.cpp:495-513
+        sz = (1, 2, 4)[pool[off]]
+        lens = [int.from_bytes(bytes(pool[off + 1 + i * sz: off + 1 + (i + 1) * sz]), "little") for i in range(n_attrs)]
+        l0 = lens[attr_id - 1] if attr_id else 0
+        data = off + 1 + n_attrs * sz
+        return bytes(pool[data + l0: data + lens[attr_id]])
+
+    hi = m.open_index(os.path.join(IDX, "t233_test"))
+    assert hi.n_blob_attrs == 1 and int(hi.attr_rows[0][2]) == 8  # the row's blob locator: right behind the size qword
+    assert blob_attr(hi.blobs, 8, 0, 1) == b"RELOAD INDEX"
+    (rt,) = m.open_rt_ram(os.path.join(IDX, "t406_idx320"))
+    assert rt.n_blob_attrs == 1 and blob_attr(rt.blobs, int(rt.attr_rows[0][2]), 0, 1) == b"kw1 at doc10"  # test_406/model.bin: postingtitle
