@@ -203,9 +203,9 @@ int assemble(std::vector<WordBytes>& wb, const std::vector<uint64_t>& spp_base, 
   parallel_for(nt, n_threads, [&](size_t t) { // parallel copy = parallel first touch of the big buffers
     WordBytes& w = wb[t];
     if (!w.docs) return;
-    memcpy(h->spd + od[t], w.spd.data(), w.spd.size());
-    memcpy(h->spp + op[t], w.spp.data(), w.spp.size());
-    memcpy(h->spe + oe[t], w.spe.data(), w.spe.size());
+    if (w.spd.size()) memcpy(h->spd + od[t], w.spd.data(), w.spd.size());
+    if (w.spp.size()) memcpy(h->spp + op[t], w.spp.data(), w.spp.size()); // (an all-inline term has no hitlist bytes: data() may be null)
+    if (w.spe.size()) memcpy(h->spe + oe[t], w.spe.data(), w.spe.size());
     w.spd.release();
     w.spp.release();
     w.spe.release();

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/fuzz_index_open.sh [SEED] [ITERATIONS] -- CPU only: builds csrc/mrk_files.cpp alone with ASan + UBSan and feeds
-# mrk_index_open mutated copies of the index fixtures under tests/golden/indexes/ (bytes flipped, files cut, junk inserted,
+# mrk_index_open (and mrk_rt_ram_open: RT RAM chunks) mutated copies of the index fixtures under tests/golden/indexes/ (bytes flipped, files cut, junk inserted,
 # and -- for the header's count fields: n_fields, n_attrs, n_checkpoints, m_iDocinfo, embedded-list counts -- dwords / qwords
 # at random header offsets overwritten with extreme values such as 0x40000000 or 2^62 + 1).
 # Every open must end in MRK_OK or an error code; the sanitizers abort on anything else.
@@ -17,7 +17,7 @@ int mrk_fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vs
 extern "C" void fuzz_free(mrk_host_index* h) { delete h; }
 CPP
 g++ -std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -shared -fPIC -I$ROOT/manticoresearch_amd/csrc \
-    $ROOT/manticoresearch_amd/csrc/mrk_files.cpp $W/stub.cpp -o $W/libfiles_asan.so
+    $ROOT/manticoresearch_amd/csrc/mrk_files.cpp $ROOT/manticoresearch_amd/csrc/mrk_writer.cpp $W/stub.cpp -lpthread -o $W/libfiles_asan.so
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
     python3 - "$ROOT" "$W" "${1:-1}" "${2:-4000}" <<'PY'
 import ctypes as C, os, random, sys
@@ -69,4 +69,36 @@ for _ in range(n_iter):
     else:
         err += 1
 print("opened", ok, "rejected", err, "-- no sanitizer report")
+# RT RAM chunks (mrk_rt_ram_open): the same treatment for <prefix>.meta + <prefix>.ram
+L.mrk_rt_ram_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+L.mrk_rt_ram_segments.argtypes = [C.c_void_p]
+L.mrk_rt_ram_free.argtypes = [C.c_void_p]
+import struct
+ok = err = 0
+for _ in range(n_iter):
+    name = random.choice(["t406_idx320", "t406_index"])
+    for e in ("meta", "ram"):
+        data = bytearray(open(src + name + "." + e, "rb").read())
+        if random.random() < 0.7:
+            for _ in range(random.randint(1, 4)):
+                if not data:
+                    break
+                k, r = random.randrange(len(data)), random.random()
+                if r < 0.4:
+                    data[k] = random.choice([0, 1, 0x7F, 0x80, 0xFF, random.randrange(256)])
+                elif r < 0.55:
+                    del data[k:]
+                elif r < 0.7:
+                    data[k:k] = bytes(random.randrange(256) for _ in range(random.randint(1, 8)))
+                else:
+                    data[k:k + 4] = struct.pack("<I", random.choice([0xFFFFFFFF, 0x40000000, 0x7FFFFFFF, 0x80000000, 0x10000, 257]))
+        open(w + "/y." + e, "wb").write(bytes(data))
+    rt = C.c_void_p()
+    if L.mrk_rt_ram_open((w + "/y").encode(), C.byref(rt)) == 0:
+        ok += 1
+        L.mrk_rt_ram_segments(rt)
+        L.mrk_rt_ram_free(rt)
+    else:
+        err += 1
+print("RT RAM chunks: opened", ok, "rejected", err, "-- no sanitizer report")
 PY
