@@ -802,12 +802,13 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    sb[t] = 0, so[t] = 0xFFFFFFFFu, sc[t] = 0, w0[t] = w1[t] = w2[t] = w3[t] = 0;
+    sb[t] = 0, so[t] = 0xFFFFFFFFu, sc[t] = 0xFFFFFFFFu, w0[t] = w1[t] = w2[t] = w3[t] = 0; // (current hit ~0: the stream is dry)
     if (on[t]) {
       if (lone[t])
         sc[t] = hv[t];
       else {
         const uint64_t p = hb[t] + hv[t];
+        sc[t] = 0;
         sb[t] = p & ~3ull;
         const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(C.spp + sb[t]);
         w0[t] = v.x, w1[t] = v.y, w2[t] = v.z, w3[t] = v.w;
@@ -818,7 +819,7 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
   // next hit of a stream out of its window (GetNextHit, sphinx.cpp:479-501); refills when fewer than 5 bytes are left
   auto next = [&](uint64_t& b, uint32_t& o, uint32_t& cur, uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
     if (o == 0xFFFFFFFFu) {
-      cur = 0;
+      cur = 0xFFFFFFFFu;
       return;
     }
     if (o > 11u) {
@@ -843,7 +844,7 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
     o += len;
     if (!d) {
       o = 0xFFFFFFFFu;
-      cur = 0;
+      cur = 0xFFFFFFFFu;
     } else
       cur += d;
   };
@@ -859,7 +860,7 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
     int best = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const uint32_t h = sc[t] ? sc[t] : 0xFFFFFFFFu;
+      const uint32_t h = sc[t];
       const bool less = h < bh || (h == bh && C.tq[t] < bq);
       if (t == 0 || less) best = t, bh = h, bq = C.tq[t];
     }
@@ -873,9 +874,19 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
       last_pwf = pwf;
       exp_delta = delta;
     }
+    // advance the stream the hit came from: its state is selected into temporaries, stepped ONCE and selected back (the
+    // lanes of a wave sit on different streams: NT predicated copies of the decoder cost NT times its instructions)
+    {
+      uint64_t xb = sb[0];
+      uint32_t xo = so[0], xc = sc[0], x0 = w0[0], x1 = w1[0], x2 = w2[0], x3 = w3[0];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-      if (t == best) next(sb[t], so[t], sc[t], w0[t], w1[t], w2[t], w3[t]);
+      for (int t = 1; t < NT; ++t)
+        if (t == best) xb = sb[t], xo = so[t], xc = sc[t], x0 = w0[t], x1 = w1[t], x2 = w2[t], x3 = w3[t];
+      next(xb, xo, xc, x0, x1, x2, x3);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t == best) sb[t] = xb, so[t] = xo, sc[t] = xc, w0[t] = x0, w1[t] = x1, w2[t] = x2, w3[t] = x3;
+    }
   }
   int rk = 0;
   for (uint32_t f = 0; f < C.nw; ++f) rk += (int)((lcs >> (8 * f)) & 0xffu) * C.fw[f];
