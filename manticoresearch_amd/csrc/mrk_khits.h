@@ -851,9 +851,10 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     if (on[t] && !lone[t]) next(sb[t], so[t], sc[t], w0[t], w1[t], w2[t], w3[t]);
-  uint64_t lcs = 0;
-  uint32_t cur_lcs = 0;
-  int exp_delta = -1, last_pwf = -1;
+  // m_uLCS[field]: the merged stream is ordered by (field, position), so one field is open at a time -- its best LCS is kept in
+  // a register and weighed in when the field changes (fields past the weights' count add nothing, as in Finalize)
+  uint32_t cur_lcs = 0, cur_f = 0xFFFFFFFFu, f_best = 0;
+  int exp_delta = -1, last_pwf = -1, rk = 0;
   for (;;) {
     // the least (hitpos, qpos) among the live streams
     uint32_t bh = 0xFFFFFFFFu, bq = 0xFFFFFFFFu;
@@ -870,7 +871,11 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
       const uint32_t hp = bh & ~(1u << 23), f = hp >> 24;
       const int pwf = (int)hp, delta = pwf - (int)(bq & 0xFFFFu);
       if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + 1u) & 0xffu;
-      if (f < 8 && cur_lcs > (uint32_t)((lcs >> (8 * f)) & 0xffu)) lcs = (lcs & ~(0xffull << (8 * f))) | ((uint64_t)cur_lcs << (8 * f));
+      if (f != cur_f) {
+        if (cur_f < C.nw) rk += (int)f_best * C.fw[cur_f];
+        cur_f = f, f_best = 0;
+      }
+      if (cur_lcs > f_best) f_best = cur_lcs;
       last_pwf = pwf;
       exp_delta = delta;
     }
@@ -888,8 +893,7 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
         if (t == best) sb[t] = xb, so[t] = xo, sc[t] = xc, w0[t] = x0, w1[t] = x1, w2[t] = x2, w3[t] = x3;
     }
   }
-  int rk = 0;
-  for (uint32_t f = 0; f < C.nw; ++f) rk += (int)((lcs >> (8 * f)) & 0xffu) * C.fw[f];
+  if (cur_f < C.nw) rk += (int)f_best * C.fw[cur_f];
   return rk;
 }
 
