@@ -128,6 +128,40 @@ def test_phrase_mix_with_field_weights(orc, corpus):
     assert n_found > 1000  # the corpus is dense enough (positions 1..64) for phrases to occur
 
 
+def test_generic_evaluator_shapes_at_scale(orc, corpus):
+    """The generic per-doc evaluator at bench scale (BASELINE config 5: "PHRASE op + field weights" and what lies beyond the specialised
+    passes): five common keywords under the hit rankers, a 5-word proximity, NEAR over phrases, BEFORE over groups, NOTNEAR, SENTENCE with
+    a keyword standing in for the boundary word, NEAR over four operands at the root (probe launch) -- each against the oracle."""
+    m, hi = corpus
+    rng = np.random.default_rng(8)
+    X = m.XQNode
+    qs = []
+    for _ in range(4):
+        a, b, c, d, e = (int(x) for x in rng.choice(np.arange(0, 7), 5, replace=False))
+        s = int(rng.choice(np.arange(6, 10)))
+        fw = [int(x) for x in rng.integers(1, 9, 3)]
+        roots = [X.AND(kw(m, a, 1), kw(m, b, 2), kw(m, c, 3), kw(m, d, 4), kw(m, e, 5)),
+                 X(m.SPH_QUERY_PROXIMITY, [kw(m, a, 1), kw(m, b, 2), kw(m, c, 3), kw(m, d, 4), kw(m, e, 5)], opt=12),
+                 X(m.SPH_QUERY_NEAR, [X(m.SPH_QUERY_PROXIMITY, [kw(m, a, 1), kw(m, b, 2)], opt=4), X(m.SPH_QUERY_PHRASE, [kw(m, c, 3), kw(m, d, 4)])], opt=9),
+                 X(m.SPH_QUERY_BEFORE, [OR(m, kw(m, a, 1), kw(m, s, 2)), kw(m, b, 3), kw(m, c, 4)]),
+                 X(m.SPH_QUERY_NOTNEAR, [kw(m, a, 1), OR(m, kw(m, b, 2), kw(m, c, 3))], opt=2),
+                 X(m.SPH_QUERY_SENTENCE, [kw(m, a, 1), kw(m, b, 2)], unit_term=c),
+                 X(m.SPH_QUERY_NEAR, [kw(m, a, 1), kw(m, b, 2), kw(m, c, 3), kw(m, d, 4)], opt=6)]
+        for i, root in enumerate(roots):
+            qs.append(m.Query(root, ranker=[m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_SPH04, m.SPH_RANK_BM25][i % 3], max_matches=1000, field_weights=fw if i % 2 else None))
+    got, _ = run_path(m, hi, qs, 0, 64)
+    oi = orc_index_of(orc, hi)
+    n_found = 0
+    for q, g in zip(qs, got):
+        assert g.status == 0, q.root
+        check_order(g)
+        want = to_orc(orc, q).run(oi)
+        assert g.total_found == want.total_found, (g.total_found, want.total_found, q.root)
+        assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+        n_found += g.total_found
+    assert n_found > 100000
+
+
 # ------------------------------------------------------------------ BASELINE.json's full size: 100 M docs
 FULL_DOCS = int(os.environ.get("MRK_FULL_DOCS", 100_000_000))  # 0 skips the test
 
