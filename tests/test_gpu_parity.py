@@ -761,6 +761,10 @@ def test_sharded_equals_unsharded(orc, dev):
     qs.append(mk(m.XQNode.AND(OR(m, kw(m, 2, 1), kw(m, 3, 2)), kw(m, 0, 3)), m.SPH_RANK_BM25))
     qs.append(mk(m.XQNode(m.SPH_QUERY_ANDNOT, [kw(m, 1, 1), kw(m, 0, 2)]), m.SPH_RANK_BM25, 37))
     qs.append(mk(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2), kw(m, 2, 3)), m.SPH_RANK_PROXIMITY_BM25))
+    # shapes of the generic per-doc evaluator: they shard like everything else (a segment's evaluator sees segment-local rowids)
+    qs.append(mk(m.XQNode(m.SPH_QUERY_NEAR, [m.XQNode(m.SPH_QUERY_PROXIMITY, [kw(m, 0, 1), kw(m, 1, 2)], opt=6), kw(m, 2, 3)], opt=12), m.SPH_RANK_PROXIMITY_BM25))
+    qs.append(mk(m.XQNode(m.SPH_QUERY_BEFORE, [OR(m, kw(m, 2, 1), kw(m, 3, 2)), kw(m, 0, 3)]), m.SPH_RANK_SPH04, 200))
+    qs.append(mk(m.XQNode(m.SPH_QUERY_NOTNEAR, [kw(m, 1, 1), m.XQNode(m.SPH_QUERY_PHRASE, [kw(m, 0, 2), kw(m, 2, 3)])], opt=4), m.SPH_RANK_BM25))
     nq = len(qs)
     seg = m.Segment(ctx, whole)
     want = batch.search(seg, qs)
