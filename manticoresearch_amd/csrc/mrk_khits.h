@@ -816,37 +816,33 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
       }
     }
   }
-  // next hit of a stream out of its window (GetNextHit, sphinx.cpp:479-501); refills when fewer than 5 bytes are left
+  // next hit of a stream out of its window (GetNextHit, sphinx.cpp:479-501); refills when fewer than 5 bytes are left.
+  // Written without branches but for the two rare ones (refill, 5-byte varint): the lanes of a wave sit on different
+  // streams and offsets, and every divergent branch costs the wave both sides plus the exec-mask bookkeeping.
   auto next = [&](uint64_t& b, uint32_t& o, uint32_t& cur, uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
-    if (o == 0xFFFFFFFFu) {
-      cur = 0xFFFFFFFFu;
-      return;
-    }
-    if (o > 11u) {
+    const bool dry = o == 0xFFFFFFFFu; // (a lone hit's stream, consumed)
+    if (!dry && o > 11u) {
       b += o & ~3u;
       const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(C.spp + b);
       x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
       o &= 3u;
     }
-    const uint32_t i = o >> 2;
+    const uint32_t i = (o >> 2) & 3u;
     const uint32_t lo = i == 0 ? x0 : i == 1 ? x1 : x2, hi = i == 0 ? x1 : i == 1 ? x2 : x3;
     const uint32_t x = __builtin_amdgcn_alignbyte(hi, lo, o & 3u);
     const uint32_t stop = ~x & 0x80808080u;
     const uint32_t n = stop ? ((uint32_t)__builtin_ctz(stop) >> 3) + 1u : 4u;
     const uint32_t all = ((x & 0x7Fu) << 21) | ((x & 0x7F00u) << 6) | ((x >> 9) & 0x3F80u) | ((x >> 24) & 0x7Fu);
     uint32_t d = all >> (7u * (4u - n)), len = n;
-    if (!stop) {
+    if (!dry && !stop) {
       const uint32_t j = (o + 4u) >> 2;
       const uint32_t wj = j == 1 ? x1 : j == 2 ? x2 : x3;
       d = (d << 7) | ((wj >> (8u * ((o + 4u) & 3u))) & 0x7Fu);
       len = 5;
     }
-    o += len;
-    if (!d) {
-      o = 0xFFFFFFFFu;
-      cur = 0xFFFFFFFFu;
-    } else
-      cur += d;
+    const bool end = dry || d == 0;
+    o = end ? 0xFFFFFFFFu : o + len;
+    cur = end ? 0xFFFFFFFFu : cur + d;
   };
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -867,17 +863,19 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
     }
     if (bh == 0xFFFFFFFFu) break;
     const uint32_t bm = best == 0 ? C.tm[0] : best == 1 ? C.tm[NT > 1 ? 1 : 0] : best == 2 ? C.tm[NT > 2 ? 2 : 0] : C.tm[NT > 3 ? 3 : 0];
-    if (field_queried(bm, bh)) { // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043)
+    { // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043): predicated, not branched
       const uint32_t hp = bh & ~(1u << 23), f = hp >> 24;
+      const bool q = f < 32u ? ((bm >> (f & 31u)) & 1u) != 0 : bm == 0xFFFFFFFFu;
       const int pwf = (int)hp, delta = pwf - (int)(bq & 0xFFFFu);
-      if (pwf > last_pwf) cur_lcs = (((delta == exp_delta) ? cur_lcs : 0u) + 1u) & 0xffu;
-      if (f != cur_f) {
+      const uint32_t grown = (((delta == exp_delta) ? cur_lcs : 0u) + 1u) & 0xffu;
+      cur_lcs = (q && pwf > last_pwf) ? grown : cur_lcs;
+      if (q && f != cur_f) { // (rare: once per field of the doc)
         if (cur_f < C.nw) rk += (int)f_best * C.fw[cur_f];
         cur_f = f, f_best = 0;
       }
-      if (cur_lcs > f_best) f_best = cur_lcs;
-      last_pwf = pwf;
-      exp_delta = delta;
+      f_best = (q && cur_lcs > f_best) ? cur_lcs : f_best;
+      last_pwf = q ? pwf : last_pwf;
+      exp_delta = q ? delta : exp_delta;
     }
     // advance the stream the hit came from: its state is selected into temporaries, stepped ONCE and selected back (the
     // lanes of a wave sit on different streams: NT predicated copies of the decoder cost NT times its instructions)
@@ -885,12 +883,18 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
       uint64_t xb = sb[0];
       uint32_t xo = so[0], xc = sc[0], x0 = w0[0], x1 = w1[0], x2 = w2[0], x3 = w3[0];
 #pragma unroll
-      for (int t = 1; t < NT; ++t)
-        if (t == best) xb = sb[t], xo = so[t], xc = sc[t], x0 = w0[t], x1 = w1[t], x2 = w2[t], x3 = w3[t];
+      for (int t = 1; t < NT; ++t) { // (one select per value: a block of assignments under `if` comes out as a branch)
+        const bool me = t == best;
+        xb = me ? sb[t] : xb, xo = me ? so[t] : xo, xc = me ? sc[t] : xc;
+        x0 = me ? w0[t] : x0, x1 = me ? w1[t] : x1, x2 = me ? w2[t] : x2, x3 = me ? w3[t] : x3;
+      }
       next(xb, xo, xc, x0, x1, x2, x3);
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t == best) sb[t] = xb, so[t] = xo, sc[t] = xc, w0[t] = x0, w1[t] = x1, w2[t] = x2, w3[t] = x3;
+      for (int t = 0; t < NT; ++t) {
+        const bool me = t == best;
+        sb[t] = me ? xb : sb[t], so[t] = me ? xo : so[t], sc[t] = me ? xc : sc[t];
+        w0[t] = me ? x0 : w0[t], w1[t] = me ? x1 : w1[t], w2[t] = me ? x2 : w2[t], w3[t] = me ? x3 : w3[t];
+      }
     }
   }
   if (cur_f < C.nw) rk += (int)f_best * C.fw[cur_f];
