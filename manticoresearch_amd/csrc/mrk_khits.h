@@ -781,6 +781,9 @@ __device__ __forceinline__ int hit_rank_plain(const HitCtx& C, uint32_t ref0, ui
 // results, about half the instructions per hit: the stream state is a window + a 32-bit offset (the 64-bit .spp position
 // is only touched at a refill), the ranker update is the three lines it is for this family, and the loop carries no
 // per-ranker branches.  rank_kernel is bound by instruction issue (vector and scalar), not by memory.
+#ifndef MRK_RKEXP
+#define MRK_RKEXP 0
+#endif
 template <int NT>
 __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uint32_t ref1, uint32_t ref2, uint32_t ref3, uint32_t smask) {
   uint64_t sb[NT];                                     // .spp position of the window's first byte
@@ -862,6 +865,9 @@ __device__ __forceinline__ int hit_rank_prox(const HitCtx& C, uint32_t ref0, uin
       if (t == 0 || less) best = t, bh = h, bq = C.tq[t];
     }
     if (bh == 0xFFFFFFFFu) break;
+#if MRK_RKEXP == 1 // ablation: the loop stops after one hit
+    if (cur_f != 0xFFFFFFFFu) break;
+#endif
     const uint32_t bm = best == 0 ? C.tm[0] : best == 1 ? C.tm[NT > 1 ? 1 : 0] : best == 2 ? C.tm[NT > 2 ? 2 : 0] : C.tm[NT > 3 ? 3 : 0];
     { // hits outside the keyword's own field limit never reach the ranker (AddHit, searchnode.cpp:3032-3043): predicated, not branched
       const uint32_t hp = bh & ~(1u << 23), f = hp >> 24;
