@@ -20,7 +20,7 @@
 // sphinxsort.cpp:4541-4547 -- not the whole match stream.  Feeding those K rows to any queue whose order is not exactly
 // that (ORDER BY attribute, expressions, group-by, several sorters, random) would silently drop rows the queue wanted, and
 // so would a filter the device did not evaluate (EarlyReject would thin the K rows out).  MrkEligible therefore admits:
-// one sorter, not group-by, not random, relevance order; no weight filter, no cutoff, no packed factors; max_matches <=
+// one sorter, not group-by, not random, relevance order; no weight filter, no packed factors; max_matches and cutoff <=
 // MRK_MAX_K; filters only if FlattenXQ could hand every one of them to the device.
 #pragma once
 
@@ -76,7 +76,7 @@ inline bool MrkEligible ( const CSphQuery & tQuery, const CSphQueryContext & tCt
 	if ( dSorters.GetLength()!=1 )					{ sWhy = "several sorters"; return false; }
 	if ( !MrkSorterIsRelevance ( tQuery, dSorters[0] ) )	{ sWhy = "sorter order is not (weight desc, rowid asc)"; return false; }
 	if ( tCtx.m_pWeightFilter )						{ sWhy = "weight filter"; return false; }	// sphinx.cpp:12216-12227: order-dependent
-	if ( tQuery.m_iCutoff>0 )						{ sWhy = "cutoff"; return false; }			// sphinx.cpp:12261-12267
+	if ( tQuery.m_iCutoff>MRK_MAX_K )				{ sWhy = "cutoff beyond the device top-K"; return false; }	// sphinx.cpp:12261-12267; smaller ones: mrk_query::cutoff
 	if ( uPackedFactorFlags!=SPH_FACTOR_DISABLE )	{ sWhy = "packed factors"; return false; }
 	if ( tQuery.m_iMaxMatches<1 || tQuery.m_iMaxMatches>MRK_MAX_K )	{ sWhy = "max_matches beyond the device top-K"; return false; }
 	if ( tQuery.m_dFilterTree.GetLength() )			{ sWhy = "filter tree"; return false; }
@@ -309,7 +309,7 @@ inline bool FlattenXQ ( const XQQuery_t & tXQ, const CSphQuery & tQuery, const C
 	q.normalized_tfidf = tQuery.m_bNormalizedTFIDF;
 	q.total_docs_override = tCtx.m_iTotalDocs;
 	q.local_docs = tCtx.m_pLocalDocs ? tOut.m_dLocalDocs.Begin() : nullptr;
-	q.cutoff = 0;
+	q.cutoff = tQuery.m_iCutoff>0 ? tQuery.m_iCutoff : 0;	// the device hands back the best of the first m_iCutoff matches; MatchExtended's own count then runs out on the last of them
 
 	// filters: every one of them on the device, or the query stays on the CPU (EarlyReject would thin the K rows out)
 	if ( tQuery.m_dFilters.GetLength()>MRK_MAX_FILTERS )	{ sWhy = "more filters than the device evaluates"; return false; }

@@ -256,6 +256,7 @@ struct DevQuery {
   uint32_t nn_a, nn_b, nn_dist;       // TF_NOTNEAR: keyword slots of the must / not side, the distance
   uint32_t max_qpos, n_qwords;        // ExtRanker_c::m_iMaxQpos (largest query position) / m_iQwords (distinct words)
   uint32_t gen_prog;                  // TF_GEN: index of the pass's GenProg
+  uint32_t rowid_max;                 // cutoff: rows past this one (segment-local) never reach the ranker; 0xFFFFFFFF = no bound
   uint32_t n_wfilters;                // filters on the match weight (m_pWeightFilter): all must pass, else the match is not one
   DevFilter wfilters[MRK_MAX_FILTERS];
   int32_t weights[32];

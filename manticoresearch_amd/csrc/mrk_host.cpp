@@ -168,6 +168,7 @@ struct mrk_batch {
   uint32_t n_pass = 0, last_max_terms = 1;
   bool last_prox = false, last_tree = false, last_ext = false;
   mrk_batch* retry = nullptr;
+  mrk_batch* probe = nullptr; // cutoff_probe's launches
   hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_merge1 = nullptr;
   mrk_batch_stats stats{};
 };
@@ -760,6 +761,7 @@ static void mrk_batch_destroy_impl(mrk_batch* b) {
   b->d_mq_count.release();
   b->d_gen_progs.release(), b->d_gen_lane.release(), b->d_gen_spill.release(), b->d_gen_used.release(), b->d_gen_near.release();
   if (b->retry) mrk_batch_destroy_impl(b->retry);
+  if (b->probe) mrk_batch_destroy_impl(b->probe);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->ev_scan0) (void)hipEventDestroy(b->ev_scan0);
   if (b->ev_scan1) (void)hipEventDestroy(b->ev_scan1);
@@ -885,6 +887,45 @@ static int launch_gen_rank(mrk::ScanArgs& sa, bool nearn, hipStream_t st) {
   return MRK_OK;
 }
 
+static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n);
+static int mrk_batch_wait_impl(mrk_batch* b);
+static int mrk_batch_result_impl(mrk_batch* b, uint32_t q, mrk_result* out);
+
+// CSphQuery::m_iCutoff (MatchExtended, sphinx.cpp:12197-12199, 12261-12267): the reference walks the matches in rowid order and
+// stops after the first `cutoff` of them that reached the sorter (past filters, dead rows; CSphMatchQueue::PushT returns true
+// whether or not the heap kept the match, sphinxsort.cpp:722-759).  Here the matches of a launch come in no order, so the
+// queries with a cutoff first run as a probe -- same tree, same filters, ranker NONE, K = cutoff: weights are all 1 and the
+// top-K order falls back to the rowid, so the K-th row is where the reference stops -- and the launch proper keeps the rows
+// up to it (DevQuery::rowid_max).  Costs a launch where the reference saves work; the results are the reference's.
+static int cutoff_probe(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n, std::vector<uint32_t>& rowid_max) {
+  std::vector<mrk_query> pq;
+  std::vector<uint32_t> who;
+  for (uint32_t i = 0; i < n; ++i)
+    if (queries[i].cutoff > 0 && queries[i].cutoff <= MRK_MAX_K && queries[i].n_weight_filters == 0) { // (the others: plan_query says why not)
+      mrk_query q = queries[i];
+      q.ranker = MRK_RANK_NONE;
+      q.max_matches = q.cutoff;
+      q.cutoff = 0;
+      pq.push_back(q);
+      who.push_back(i);
+    }
+  if (pq.empty()) return MRK_OK;
+  int rc;
+  if (b->probe && b->probe->max_queries < pq.size()) {
+    mrk_batch_destroy_impl(b->probe);
+    b->probe = nullptr;
+  }
+  if (!b->probe && (rc = mrk_batch_create_impl(b->ctx, (uint32_t)std::max<size_t>(pq.size(), 16), &b->probe))) return rc;
+  if ((rc = mrk_batch_submit_impl(b->probe, seg, pq.data(), (uint32_t)pq.size())) || (rc = mrk_batch_wait_impl(b->probe))) return rc;
+  for (size_t j = 0; j < pq.size(); ++j) {
+    mrk_result r{};
+    if ((rc = mrk_batch_result_impl(b->probe, (uint32_t)j, &r))) return rc;
+    // (a probe that was declined: the launch proper is declined for the same reason, with its own message)
+    if (r.status == MRK_OK && r.total_found > (int64_t)pq[j].max_matches && r.n == pq[j].max_matches) rowid_max[who[j]] = r.rowid[r.n - 1];
+  }
+  return MRK_OK;
+}
+
 static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n) {
   if (!b || !seg || (!queries && n)) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: NULL argument");
   if (n > b->max_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: %u queries > batch capacity %u", n, b->max_queries);
@@ -901,6 +942,14 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   b->rowid_base = seg->dev.rowid_base;
   b->stats = mrk_batch_stats{};
   if (!n) return MRK_OK;
+  std::vector<uint32_t> rowid_max;
+  for (uint32_t i = 0; i < n; ++i)
+    if (queries[i].cutoff > 0) {
+      rowid_max.assign(n, 0xFFFFFFFFu);
+      const int rc = cutoff_probe(b, seg, queries, n, rowid_max);
+      if (rc != MRK_OK) return rc;
+      break;
+    }
 
   // ---- plan
   const auto t_submit0 = std::chrono::steady_clock::now();
@@ -916,7 +965,7 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   for (uint32_t i = 0; i < n; ++i) {
     const size_t extra0 = extra.size(), items0 = items.size(), items_bm0 = items_bm.size(), gen0 = b->gen_progs.size();
     int rc = plan_query(seg, queries[i], b->ctx->item_bytes, use_packed, b->h_queries.p[i], extra, n, items, items_bm, i, algo_bytes,
-                        dev_bytes, cand_total, any_prox, any_tree, b->gen_progs);
+                        dev_bytes, cand_total, any_prox, any_tree, b->gen_progs, rowid_max.empty() ? 0xFFFFFFFFu : rowid_max[i]);
     b->status[i] = rc;
     if (rc == MRK_E_INVAL) return rc;
     if (rc != MRK_OK) { // unsupported: reported per query, runs no device work
@@ -928,7 +977,8 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
       b->h_queries.p[i].n_terms = 0;
     }
     max_terms = std::max(max_terms, b->h_queries.p[i].n_terms);
-    any_ext = any_ext || (b->h_queries.p[i].tree_flags & (mrk::TF_TERMPOS | mrk::TF_ORDER | mrk::TF_PHRASE_LEAF | mrk::TF_NOTNEAR)) != 0 || b->h_queries.p[i].n_filters != 0 || b->h_queries.p[i].n_wfilters != 0;
+    any_ext = any_ext || (b->h_queries.p[i].tree_flags & (mrk::TF_TERMPOS | mrk::TF_ORDER | mrk::TF_PHRASE_LEAF | mrk::TF_NOTNEAR)) != 0 || b->h_queries.p[i].n_filters != 0 || b->h_queries.p[i].n_wfilters != 0 ||
+              b->h_queries.p[i].rowid_max != 0xFFFFFFFFu;
     b->h_list_first.p[i] = b->h_queries.p[i].item_first;
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;

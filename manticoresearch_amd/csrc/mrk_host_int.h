@@ -96,7 +96,7 @@ namespace mrk {
 int plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
                std::vector<DevQuery>& extra, uint32_t n_queries, std::vector<DevItem>& items, std::vector<DevItem>& items_bm,
                uint32_t qi, uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out,
-               std::vector<mrk::GenProg>& gen_progs); // gen_progs: programs of the generic evaluator (DevQuery::gen_prog indexes it); their
+               std::vector<mrk::GenProg>& gen_progs, uint32_t rowid_max = 0xFFFFFFFFu); // gen_progs: programs of the generic evaluator (DevQuery::gen_prog indexes it); their
                                                       // work items go to items_bm with kind 2, already cut
 
 } // namespace mrk

@@ -682,14 +682,22 @@ static void fill_term(const mrk_segment* seg, const PlanKw& k, DevTerm& dt) {
 int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
                       std::vector<DevQuery>& extra, uint32_t n_queries, std::vector<DevItem>& items,
                       std::vector<DevItem>& items_bm, uint32_t qi,
-                      uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out, std::vector<mrk::GenProg>& gen_progs) {
+                      uint64_t& algo_bytes, uint64_t& dev_bytes, uint64_t& cand_total, bool& prox_out, bool& tree_out, std::vector<mrk::GenProg>& gen_progs,
+                      uint32_t rowid_max) {
   memset(&dq, 0, sizeof dq);
   dq.item_first = (uint32_t)items.size();
   dq.out_q = qi;
   if (!q.nodes || q.n_nodes <= 0 || q.root < 0 || q.root >= q.n_nodes) return mrk_fail(MRK_E_INVAL, "query %u: bad tree", qi);
   if (q.max_matches <= 0 || q.max_matches > MRK_MAX_K)
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: max_matches %d outside 1..%d", qi, q.max_matches, MRK_MAX_K);
-  if (q.cutoff > 0) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: cutoff is order-dependent; not on the device path", qi);
+  // cutoff (MatchExtended, sphinx.cpp:12197-12199, 12261-12267): the sorter's Push() never says no (sphinxsort.cpp:722-759), so the
+  // scan stops after the first `cutoff` rows that got as far as the sorter -- the caller found the last of them with a probe
+  // launch (cutoff_probe, mrk_host.cpp) and hands it down as rowid_max: rows past it never reach the ranker
+  if (q.cutoff > 0 && !use_packed) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: cutoff runs on the packed path only", qi);
+  if (q.cutoff > MRK_MAX_K) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: cutoff %d (device path: <= %d)", qi, q.cutoff, MRK_MAX_K);
+  if (q.cutoff > 0 && q.n_weight_filters > 0)
+    return mrk_fail(MRK_E_UNSUPPORTED, "query %u: cutoff next to a weight filter (which rows count depends on their weights)", qi);
+  const bool filtered = q.n_filters > 0 || rowid_max != 0xFFFFFFFFu;
 
   // The specialised paths first; a shape they decline goes to the generic per-doc evaluator (mrk_keval.h) when the segment
   // has what it reads (packed doclists + hit references), else the decline stands.
@@ -737,8 +745,8 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     if (gen && T.gen_nearn) {
       int mq = 0;
       for (const PlanKw& k : T.kws) mq = std::max(mq, k.atom_pos);
-      if (q.n_filters > 0 || seg->dev.dead || mq >= 64)
-        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NEAR over 3+ operands next to filters / dead rows / query positions past 63 (every doc of the node must reach the evaluator)", qi);
+      if (filtered || q.cutoff > 0 || seg->dev.dead || mq >= 64)
+        return mrk_fail(MRK_E_UNSUPPORTED, "query %u: NEAR over 3+ operands next to filters / cutoff / dead rows / query positions past 63 (every doc of the node must reach the evaluator)", qi);
     }
     if (gen && single_word) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: a single keyword is not a case for the generic evaluator", qi);
     if (gen) {
@@ -822,6 +830,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
 
   // attribute filters (EarlyReject): resolved locators over the segment's .spa rows
   dq.n_filters = 0;
+  dq.rowid_max = rowid_max;
   if (q.n_filters < 0 || (q.n_filters > 0 && !q.filters)) return mrk_fail(MRK_E_INVAL, "query %u: bad filter list", qi);
   if (q.n_filters > 0) {
     if (!seg->dev.attrs) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: filters need the segment's attribute rows (mrk_segment_set_attrs)", qi);
@@ -1052,7 +1061,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   tree_out = tree_out || !pure_and;
 
   // two dense keywords: the bitmap kernel (mrk_scan_bm.hip) walks 2048-rowid windows instead of blocks
-  if (use_packed && pure_and && !T.phrase && n == 2 && q.n_filters == 0 && q.n_weight_filters == 0 && (ranker == MRK_RANK_NONE || ranker == MRK_RANK_BM25) && seg->dev.bm &&
+  if (use_packed && pure_and && !T.phrase && n == 2 && !filtered && q.n_weight_filters == 0 && (ranker == MRK_RANK_NONE || ranker == MRK_RANK_BM25) && seg->dev.bm &&
       seg->ctx->bitmap_inv > 0 && seg->terms[T.kws[0].term_id].bm_off != ~0ull && seg->terms[T.kws[1].term_id].bm_off != ~0ull) {
     dq.n_terms = 2;
     for (int i = 0; i < 2; ++i) fill_term(seg, T.kws[i], dq.t[i]);
@@ -1079,7 +1088,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   {
     const uint32_t all_fields = seg->n_fields >= 32 ? 0xFFFFFFFFu : (1u << seg->n_fields) - 1u;
     bool ok = use_packed && seg->dev.bm && seg->ctx->bitmap_inv > 0 && seg->ctx->bt_cover_inv > 0 && !T.gen && !T.phrase && !T.ph_leaf && !T.quorum && !T.order &&
-              !T.termpos && !T.notnear && q.n_filters == 0 && q.n_weight_filters == 0 && n <= MAX_PROX_TERMS && seg->total_docs < (1ull << 32) && T.nodes.size() <= 16;
+              !T.termpos && !T.notnear && !filtered && q.n_weight_filters == 0 && n <= MAX_PROX_TERMS && seg->total_docs < (1ull << 32) && T.nodes.size() <= 16;
     uint64_t cover_docs = 0;
     for (int k : cover) cover_docs += (uint64_t)T.kws[k].docs;
     ok = ok && cover_docs * (uint64_t)seg->ctx->bt_cover_inv >= seg->total_docs;

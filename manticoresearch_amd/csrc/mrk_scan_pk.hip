@@ -774,6 +774,10 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
         for (int r = 0; r < 2; ++r)
           if (live[r] && !row_passes_filters(a.seg, Q->filters, Q->n_filters, row[r])) live[r] = false;
       }
+      if (EXT) { // cutoff: the scan stopped at that row (MatchExtended, sphinx.cpp:12261-12267)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) live[r] = live[r] && row[r] <= Q->rowid_max;
+      }
       if (a.seg.dead) { // MatchExtended drops dead rows before they reach the sorter (sphinx.cpp:12213-12217)
 #pragma unroll
         for (int r = 0; r < 2; ++r)

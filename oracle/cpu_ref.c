@@ -2123,8 +2123,7 @@ static enode* build_node(build_ctx* bc, int ni) {
              over the group's merged hits gives other docs and weights), so such operands are declined, not guessed at */
           bc->error = 1;
           fail("NEAR over AND / OR groups is not restated in the oracle");
-          for (int j = 0; j < i; j++) en_free(kids[j]);
-          return NULL;
+          return NULL; /* (no operand has been built yet) */
         }
       }
       for (int i = 0; i < k; i++) {

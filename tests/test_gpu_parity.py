@@ -39,7 +39,7 @@ def to_orc(orc, q):
 
     return orc.FlatQuery(conv(q.root), ranker=q.ranker, max_matches=q.max_matches, field_weights=q.field_weights,
                          index_weight=q.index_weight, plain_idf=q.plain_idf, normalized_tfidf=q.normalized_tfidf,
-                         total_docs_override=q.total_docs, local_docs=q.local_docs,
+                         total_docs_override=q.total_docs, local_docs=q.local_docs, cutoff=q.cutoff,
                          filters=[f.as_dict() for f in q.filters] if q.filters else None,
                          weight_filters=[f.as_dict() for f in q.weight_filters] if q.weight_filters else None)
 
@@ -1580,6 +1580,69 @@ def test_attribute_filters(orc, dev):
         # more filters / values than the device path holds: declined
         assert batch.search(seg, [m.Query(kw(m, 0, 1), filters=[F(64, 32, values=list(range(9)))])])[0].status == -2
         assert batch.search(seg, [m.Query(kw(m, 0, 1), filters=[F(64, 32, min=1, max=2)] * 3)])[0].status == -2
+    finally:
+        seg.close()
+
+
+# ------------------------------------------------------------------ cutoff (MatchExtended stops after N matches)
+def test_cutoff(orc, dev):
+    """CSphQuery::m_iCutoff (sphinx.cpp:12197-12199, 12261-12267): the first `cutoff` matches in rowid order that got past the filters
+    and the dead-row map are all the sorter sees -- they are the result set (best first), and total_found counts them.  Every
+    kind of path (single keyword, bitmap AND, trees, PHRASE, the generic evaluator), every ranker, with filters and dead rows;
+    cutoffs below, at and above the number of matches and the top-K size."""
+    m, ctx, batch = dev
+    if ctx_path(ctx) != 0:
+        pytest.skip("cutoff runs on the packed path")
+    rng = np.random.default_rng(777)
+    n_docs = 60000
+    probs = [0.5, 0.4, 0.2, 0.05, 0.01, 0.002, 0.0003]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=20, end_markers=True)
+    nt = len(probs)
+    hi = m.index_from_hits(W, R, H, n_terms=nt, total_docs=n_docs, n_fields=3)
+    rows = np.zeros((n_docs, 3), np.uint32)
+    rows[:, 0] = np.arange(n_docs)
+    rows[:, 2] = rng.integers(0, 10, n_docs)
+    F = m.Filter
+    rankers = [m.SPH_RANK_PROXIMITY_BM25, m.SPH_RANK_BM25, m.SPH_RANK_NONE, m.SPH_RANK_SPH04, m.SPH_RANK_WORDCOUNT]
+    qs = []
+    for i in range(160):
+        a, b, c = (int(t) for t in rng.choice(nt, 3, replace=False))
+        d, e = (int(t) for t in rng.choice(nt, 2))
+        shape = i % 8
+        root = [kw(m, a, 1), m.XQNode.AND(kw(m, a, 1), kw(m, b, 2)), OR(m, kw(m, a, 1), kw(m, b, 2)), m.XQNode.AND(OR(m, kw(m, a, 1), kw(m, b, 2)), kw(m, c, 3)),
+                PHRASE(m, kw(m, a, 1), kw(m, b, 2)), ANDNOT(m, kw(m, a, 1), kw(m, b, 2)),
+                m.XQNode.AND(kw(m, a, 1), kw(m, b, 2), kw(m, c, 3), kw(m, d, 4), kw(m, e, 5)),  # five streams: the generic evaluator
+                m.XQNode(m.SPH_QUERY_NEAR, [kw(m, a, 1), m.XQNode(m.SPH_QUERY_PROXIMITY, [kw(m, b, 2), kw(m, c, 3)], opt=6)], opt=4)][shape]
+        fl = [F(64, 32, values=sorted(set(int(v) for v in rng.integers(0, 10, 4))))] if rng.random() < 0.4 else None
+        qs.append(m.Query(root, ranker=int(rng.choice(rankers)), max_matches=int(rng.choice([20, 1000])), filters=fl,
+                          cutoff=int(rng.choice([1, 2, 7, 20, 21, 300, 1000, 1024]))))
+    # dense x dense under BM25 / NONE: the shape the bitmap kernel takes when nothing bounds the rows
+    qs.append(m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_BM25, max_matches=1000, cutoff=100))
+    qs.append(m.Query(m.XQNode.AND(kw(m, 0, 1), kw(m, 1, 2)), ranker=m.SPH_RANK_NONE, max_matches=10, cutoff=1000))
+    seg = m.Segment(ctx, hi)
+    seg.set_attrs(rows)
+    oi = orc_index_of(orc, hi)
+    oi.attrs = rows
+    dead = np.zeros((n_docs + 31) // 32, np.uint32)
+    for r in rng.choice(n_docs, 3000, replace=False):
+        dead[r >> 5] |= np.uint32(1 << (int(r) & 31))
+    try:
+        for with_dead in (False, True):
+            if with_dead:
+                seg.set_dead_rows(dead)
+                oi.dead_rows = dead
+            n_cut = 0
+            got = batch.search(seg, qs)
+            for q, g in zip(qs, got):
+                want = to_orc(orc, q).run(oi)
+                assert g.status == 0, (g.status, q.cutoff)
+                assert g.total_found == want.total_found, (g.total_found, want.total_found, q.cutoff)
+                assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+                n_cut += int(g.total_found == q.cutoff)
+            assert n_cut > 60, n_cut  # about half of them did stop at the cutoff
+        # what stays on the host: a cutoff past the device's top-K size, a cutoff next to a weight filter
+        assert batch.search(seg, [m.Query(kw(m, 0, 1), cutoff=1025)])[0].status == -2
+        assert batch.search(seg, [m.Query(kw(m, 0, 1), cutoff=5, weight_filters=[F(0, 32, min=0, max=5000)])])[0].status == -2
     finally:
         seg.close()
 
