@@ -677,6 +677,16 @@ static void fill_term(const mrk_segment* seg, const PlanKw& k, DevTerm& dt) {
   dt.dir_off = h.dir_off;
 }
 
+// the weight-range estimates below only shape the pruning bins: with absurd field weights they saturate instead of overflowing
+static int64_t sat_mul(int64_t a, int64_t b) {
+  const __int128 v = (__int128)a * b, lim = (__int128)1 << 61;
+  return (int64_t)(v > lim ? lim : v < -lim ? -lim : v);
+}
+static int64_t sat_add(int64_t a, int64_t b) {
+  const __int128 v = (__int128)a + b, lim = (__int128)1 << 61;
+  return (int64_t)(v > lim ? lim : v < -lim ? -lim : v);
+}
+
 // returns MRK_OK, or MRK_E_UNSUPPORTED / MRK_E_INVAL with the message set.  dq = the query's head pass
 // (index qi); further passes go to `extra` and get pass indices n_queries + position.
 int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_bytes, bool use_packed, DevQuery& dq,
@@ -688,6 +698,9 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   dq.item_first = (uint32_t)items.size();
   dq.out_q = qi;
   if (!q.nodes || q.n_nodes <= 0 || q.root < 0 || q.root >= q.n_nodes) return mrk_fail(MRK_E_INVAL, "query %u: bad tree", qi);
+  for (int i = 0; i < q.n_nodes; ++i) // (ExtHit_t::m_uQuerypos is a WORD, sphinxint.h:733; the arithmetic on positions below assumes as much)
+    if (q.nodes[i].op == MRK_OP_TERM && (q.nodes[i].atom_pos < 0 || q.nodes[i].atom_pos > 0xFFFF))
+      return mrk_fail(MRK_E_INVAL, "query %u: query position %d of node %d", qi, q.nodes[i].atom_pos, i);
   if (q.max_matches <= 0 || q.max_matches > MRK_MAX_K)
     return mrk_fail(MRK_E_UNSUPPORTED, "query %u: max_matches %d outside 1..%d", qi, q.max_matches, MRK_MAX_K);
   // cutoff (MatchExtended, sphinx.cpp:12197-12199, 12261-12267): the sorter's Push() never says no (sphinxsort.cpp:722-759), so the
@@ -994,6 +1007,9 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
         hi += std::max(a0, a1) - std::max(0.0, std::max(a0, a1));
       }
     }
+    // (a boost of inf / NaN makes the weights meaningless in the reference too; the estimate just must stay defined)
+    lo = std::isfinite(lo) ? std::max(lo, -1e12) : -1e12;
+    hi = std::isfinite(hi) ? std::min(hi, 1e12) : 1e12;
     const int64_t bm_lo = (int64_t)floor((lo + 0.5) * 1000.0) - 2, bm_hi = (int64_t)ceil((hi + 0.5) * 1000.0) + 2;
     int64_t rmin = INT64_MAX, rmax = INT64_MIN;
     const uint32_t nwf = std::min<uint32_t>(dq.n_weights, 8u);
@@ -1010,12 +1026,12 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       if (ranker == MRK_RANK_MATCHANY) {
         int64_t k = 0;
         for (uint32_t f = 0; f < nwf; ++f) k += dq.weights[f];
-        top = n + top * std::llabs(k * (int64_t)words.size());
+        top = sat_add(n, sat_mul(top, std::llabs(sat_mul(k, (int64_t)words.size()))));
       }
       for (uint32_t f = 0; f < nwf; ++f) {
-        const int64_t v = top * dq.weights[f];
-        rmin += ranker == MRK_RANK_MATCHANY ? -std::llabs(v) : std::min<int64_t>(0, v);
-        rmax += ranker == MRK_RANK_MATCHANY ? std::llabs(v) : std::max<int64_t>(0, v);
+        const int64_t v = sat_mul(top, dq.weights[f]);
+        rmin = sat_add(rmin, ranker == MRK_RANK_MATCHANY ? -std::llabs(v) : std::min<int64_t>(0, v));
+        rmax = sat_add(rmax, ranker == MRK_RANK_MATCHANY ? std::llabs(v) : std::max<int64_t>(0, v));
       }
       if (ranker == MRK_RANK_FIELDMASK) rmin = 0, rmax = (1ll << nwf) - 1;
     } else
@@ -1032,9 +1048,11 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     const bool with_bm = ranker == MRK_RANK_BM25 || ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_SPH04;
     const int64_t iw = (int32_t)dq.index_weight;
     const int64_t sc = with_bm ? 1000 : 1, b0 = with_bm ? bm_lo : 0, b1 = with_bm ? bm_hi : 0;
-    const int64_t c[4] = {(b0 + rmin * sc) * iw, (b0 + rmax * sc) * iw, (b1 + rmin * sc) * iw, (b1 + rmax * sc) * iw};
-    const int64_t wlo = *std::min_element(c, c + 4), whi = *std::max_element(c, c + 4);
-    if (wlo > INT32_MIN && whi < INT32_MAX && std::llabs(rmin * 1000) < INT32_MAX && std::llabs(rmax * 1000) < INT32_MAX) {
+    // (128-bit: absurd field weights x an absurd index weight must not overflow the estimate itself)
+    const __int128 c[4] = {((__int128)b0 + (__int128)rmin * sc) * iw, ((__int128)b0 + (__int128)rmax * sc) * iw, ((__int128)b1 + (__int128)rmin * sc) * iw,
+                           ((__int128)b1 + (__int128)rmax * sc) * iw};
+    const __int128 wlo = *std::min_element(c, c + 4), whi = *std::max_element(c, c + 4);
+    if (wlo > INT32_MIN && whi < INT32_MAX && std::llabs(rmin) < INT32_MAX / 1000 && std::llabs(rmax) < INT32_MAX / 1000) {
       const uint64_t span = (uint64_t)(whi - wlo) + 1;
       uint32_t sh = 0;
       while (sh < 31 && ((span - 1) >> sh) >= (uint64_t)NBINS) ++sh;
