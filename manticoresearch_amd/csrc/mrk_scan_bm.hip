@@ -25,17 +25,23 @@
 
 namespace mrk {
 
-constexpr int BM_CBUF = 128; // candidates a wave collects before it publishes them
-constexpr int BM_QCAP = 128; // match queue entries per wave (scored in batches of 64)
+constexpr int BM_CBUF = 112; // candidates a wave collects before it publishes them
 constexpr int BM_WORDS = 64; // words per window
+#ifndef MRK_BM_PREFETCH
+#define MRK_BM_PREFETCH 0 // 1: request the burst's tf / field lines as one run ahead of the gathers (measured: slower, 3.43 vs 2.82 ms)
+#endif
 #ifndef MRK_BM_BURST
 #define MRK_BM_BURST 4 // windows requested back to back
 #endif
 constexpr int BM_BURST = MRK_BM_BURST;
+constexpr int BM_WQCAP = 128; // word queue entries per wave (unpacked in batches of 64)
 
+// (7 workgroups per CU: 4 x (896 + 3072) B of wave queues + 7 KB of tables and publishing scratch)
 struct __align__(16) BmWaveLds {
   uint64_t cbuf[BM_CBUF];
-  uint4 q[BM_QCAP]; // match queue: rowid, rank in A, rank in B, (pad) -- one 16-byte LDS access per entry
+  // word queue: the windows' non-empty match words wait here until 64 of them can be unpacked with every lane busy
+  uint4 wq[BM_WQCAP];  // match word, keyword A's word, keyword B's word, rowid of bit 0
+  uint2 wqr[BM_WQCAP]; // ranks of the words' first bits in A and in B
 };
 
 struct __align__(16) BmSmem {
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
   const uint32_t w1 = w0 + per < item.blk_end ? w0 + per : item.blk_end;
   __syncthreads(); // tables ready; the waves never meet again
 
-  uint32_t total = 0, tau_bin = 0, cn = 0, qn = 0;
+  uint32_t total = 0, tau_bin = 0, cn = 0;
   // running ranks at the start of the next window (uniform)
   uint32_t baseA = 0, baseB = 0;
   if (w0 < w1) {
@@ -143,13 +149,8 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     if (gt > tau_bin) tau_bin = gt;
   };
 
-  // score the queue entries [from, from + n), n <= 64, one per lane
-  auto score = [&](uint32_t from, uint32_t n) {
-    wave_lds_fence();
-    const bool valid = lane < n;
-    const uint32_t e = from + (valid ? lane : 0u);
-    const uint4 qe = L.q[e];
-    const uint32_t row = qe.x, ra = qe.y, rb = qe.z;
+  // score one match per lane: its rowid, its slots in the two keywords' packed arrays
+  auto score = [&](const bool valid, const uint32_t row, const uint32_t ra, const uint32_t rb) {
     // packed attr word of slot r: block r >> 7, word r & 63, byte pair (r >> 6) & 1
     uint32_t tfa, tfb, fa, fb;
     if (attr1 && !none_fast) {
@@ -160,8 +161,12 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       if (tfa == 15u) tfa = (attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)] >> (((ra >> 6) & 1u) * 8u)) & 0xffu;
       if (tfb == 15u) tfb = (attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)] >> (((rb >> 6) & 1u) * 8u)) & 0xffu;
     } else {
+#if MRK_BMEXP == 4 // ablation: scoring without the two gathers
+      const uint32_t wa = 0x01010101u + (ra & 3u), wb = 0x01010101u + (rb & 1u);
+#else
       const uint32_t wa = none_fast ? 0x01010101u : attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)];
       const uint32_t wb = none_fast ? 0x01010101u : attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)];
+#endif
       const uint32_t sa = ((ra >> 6) & 1u) * 8u, sb = ((rb >> 6) & 1u) * 8u;
       tfa = (wa >> sa) & 0xffu, tfb = (wb >> sb) & 0xffu;
       fa = (wa >> (16u + sa)) & 0xffu & TA.queried32, fb = (wb >> (16u + sb)) & 0xffu & TB.queried32; // FitsFields
@@ -201,10 +206,53 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     }
   };
 
+  // Unpack the word queue entries [from, from + n), n <= 64, one word per lane: each lane's lowest match bit is a match to
+  // score -- all n lanes have one -- and the words that hold more bits go back on the queue, at `from`, for a later round.
+  // (A window holds a dozen matches in its 64 words: unpacking it on the spot would run the bit loop, and the scoring, with a
+  // fifth of the lanes busy.)
+  uint32_t wqn = 0;
+  auto unpack = [&](uint32_t from, uint32_t n) -> uint32_t {
+    wave_lds_fence();
+    const bool valid = lane < n;
+    const uint32_t e = from + (valid ? lane : 0u);
+    const uint4 we = L.wq[e];
+    const uint2 wr = L.wqr[e];
+    const uint32_t m = valid ? we.x : 0u, aw = we.y, bw = we.z, rowbase = we.w;
+    const uint32_t bit = valid ? (uint32_t)__builtin_ctz(m) : 0u; // (m != 0 for every queued word)
+    const uint32_t below = (1u << bit) - 1u;
+    const uint32_t rest = m & (m - 1u);
+    const uint64_t bal = __ballot(rest != 0);
+    wave_lds_fence(); // every lane holds its entry: the slots may be rewritten
+    if (rest) {
+      const uint32_t pos = from + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      L.wq[pos] = make_uint4(rest, aw, bw, rowbase);
+      L.wqr[pos] = wr;
+    }
+#if MRK_BMEXP != 2
+    score(valid, rowbase + bit, wr.x + (uint32_t)__popc(aw & below), wr.y + (uint32_t)__popc(bw & below));
+#endif
+    return (uint32_t)__popcll(bal);
+  };
+
+  // The tf / field words the burst's matches will be gathered from lie in ONE run of each keyword's packed array (slots = ranks,
+  // and the ranks of a burst are consecutive): lane l asks for line l of that run now, in one request -- the memory side
+  // gets a few KB in a row instead of one 128-byte line at a time as the scattered gathers of the scoring rounds arrive.
+  // (An estimate from the keyword's density + 2 lines of slack; what it misses the gathers fetch themselves.)
+  const bool pf_on = !none_fast && !attr1 && MRK_BM_PREFETCH;
+  const uint32_t pfA_lines = pf_on ? (uint32_t)(((uint64_t)TA.docs * BM_BURST * 2 / (a.seg.n_windows ? a.seg.n_windows : 1u)) / 128u) + 2u : 0u;
+  const uint32_t pfB_lines = pf_on ? (uint32_t)(((uint64_t)TB.docs * BM_BURST * 2 / (a.seg.n_windows ? a.seg.n_windows : 1u)) / 128u) + 2u : 0u;
+  const uint64_t endA = (uint64_t)(TA.blk_first + TA.nblocks) * 64, endB = (uint64_t)(TB.blk_first + TB.nblocks) * 64;
+  uint32_t sink = 0;
   for (uint32_t wb = w0; wb < w1; wb += BM_BURST) {
     // BM_BURST windows requested back to back (one memory round trip per burst)
     const uint32_t nb = w1 - wb < (uint32_t)BM_BURST ? w1 - wb : (uint32_t)BM_BURST;
     uint32_t av[BM_BURST], bv[BM_BURST], dv[BM_BURST];
+    uint32_t pfa = 0, pfb = 0;
+    if (pf_on) {
+      const uint64_t oa = (uint64_t)(TA.blk_first + (baseA >> 7)) * 64 + lane * 32u, ob = (uint64_t)(TB.blk_first + (baseB >> 7)) * 64 + lane * 32u;
+      if (lane < pfA_lines && oa < endA) pfa = attr[oa];
+      if (lane < pfB_lines && ob < endB) pfb = attr[ob];
+    }
 #pragma unroll
     for (int i = 0; i < BM_BURST; ++i) {
       av[i] = bv[i] = dv[i] = 0;
@@ -216,7 +264,9 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       }
     }
 #if MRK_BMEXP != 1
-    { // the query's shared pruning threshold rides along with the burst
+    // the query's shared pruning threshold rides along with every 4th burst (every wave of the query reads the one word: with
+    // every burst the reads cost 0.18 of the launch's 2.76 ms, without any the candidate lists grow by a quarter)
+    if (((wb - w0) / BM_BURST & 3u) == 0) {
       const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (gt > tau_bin) tau_bin = gt;
     }
@@ -240,33 +290,29 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
         baseA += tot & 0xFFFFu;
         baseB += tot >> 16;
         const uint32_t rowbase = (wb + i) * 2048u + lane * 32u;
-        uint64_t bal;
 #if MRK_BMEXP == 3
         total += __popc(m);
         m = 0;
 #endif
-        while ((bal = __ballot(m != 0)) != 0) {
-          const bool has = m != 0;
-          const uint32_t bit = has ? (uint32_t)__builtin_ctz(m) : 0u;
-          const uint32_t below = (1u << bit) - 1u;
-          const uint32_t pos = qn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        // A window holds a dozen matches in its 64 words: unpacking it on the spot would run the bit loop with a fifth of
+        // the lanes busy.  Its non-empty words are queued instead (one ballot, no loop) and unpacked 64 words at a time.
+        const bool has = m != 0;
+        const uint64_t bal = __ballot(has);
+        if (bal) {
           if (has) {
-            L.q[pos] = make_uint4(rowbase + bit, ra0 + (uint32_t)__popc(aw & below), rb0 + (uint32_t)__popc(bw & below), 0u);
+            const uint32_t pos = wqn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            L.wq[pos] = make_uint4(m, aw, bw, rowbase);
+            L.wqr[pos] = make_uint2(ra0, rb0);
           }
-          qn += (uint32_t)__popcll(bal);
-          m &= m - 1u;
-          if (qn >= 64u) {
-#if MRK_BMEXP != 2
-            score(qn - 64u, 64u);
-#endif
-            qn -= 64u;
-            wave_lds_fence(); // the scored entries' slots may be rewritten
-          }
+          wqn += (uint32_t)__popcll(bal);
+          while (wqn >= 64u) wqn = wqn - 64u + unpack(wqn - 64u, 64u);
         }
       }
     }
+    sink ^= pfa ^ pfb; // (the requested lines are not read here: they are for the caches)
   }
-  if (qn) score(0, qn);
+  while (wqn) wqn = unpack(0, wqn);
+  if (sink == 0x9E3779B9u && a.n_items == 0xFFFFFFFFu) ++total; // (keeps the requests alive; never true)
   if (cn) publish();
   {
     uint32_t t = total;
