@@ -149,24 +149,27 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     if (gt > tau_bin) tau_bin = gt;
   };
 
-  // score one match per lane: its rowid, its slots in the two keywords' packed arrays
-  auto score = [&](const bool valid, const uint32_t row, const uint32_t ra, const uint32_t rb) {
+  // Score one match per lane (its rowid, its slots in the two keywords' packed arrays) -- in two halves a round apart: a call
+  // first finishes the round the call before it started (weights, pruning test, candidate buffer), then only REQUESTS its own
+  // matches' tf / field words.  The gathers are the kernel's longest waits (a line per lane); this way they are in flight
+  // while the wave unpacks further words and works through the next windows, instead of being waited for on the spot.
+  bool p_any = false, p_valid = false; // a round is pending; the lane holds a match of it
+  uint32_t p_row = 0, p_ra = 0, p_rb = 0, p_wa = 0, p_wb = 0;
+  auto score = [&](const bool valid_new, const uint32_t row_new, const uint32_t ra_new, const uint32_t rb_new) __attribute__((always_inline)) {
+    if (p_any) {
+    const bool valid = p_valid;
+    const uint32_t row = p_row, ra = p_ra, rb = p_rb;
     // packed attr word of slot r: block r >> 7, word r & 63, byte pair (r >> 6) & 1
     uint32_t tfa, tfb, fa, fb;
     if (attr1 && !none_fast) {
       // nibble plane: one byte per doc (tf | fields << 4); tf 15 escapes to the attr word
-      const uint32_t ba = attr1[(uint64_t)TA.blk_first * 128 + ra], bb = attr1[(uint64_t)TB.blk_first * 128 + rb];
+      const uint32_t ba = p_wa, bb = p_wb;
       tfa = ba & 15u, tfb = bb & 15u;
       fa = (ba >> 4) & TA.queried32, fb = (bb >> 4) & TB.queried32; // FitsFields
       if (tfa == 15u) tfa = (attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)] >> (((ra >> 6) & 1u) * 8u)) & 0xffu;
       if (tfb == 15u) tfb = (attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)] >> (((rb >> 6) & 1u) * 8u)) & 0xffu;
     } else {
-#if MRK_BMEXP == 4 // ablation: scoring without the two gathers
-      const uint32_t wa = 0x01010101u + (ra & 3u), wb = 0x01010101u + (rb & 1u);
-#else
-      const uint32_t wa = none_fast ? 0x01010101u : attr[(uint64_t)(TA.blk_first + (ra >> 7)) * 64 + (ra & 63u)];
-      const uint32_t wb = none_fast ? 0x01010101u : attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)];
-#endif
+      const uint32_t wa = p_wa, wb = p_wb;
       const uint32_t sa = ((ra >> 6) & 1u) * 8u, sb = ((rb >> 6) & 1u) * 8u;
       tfa = (wa >> sa) & 0xffu, tfb = (wb >> sb) & 0xffu;
       fa = (wa >> (16u + sa)) & 0xffu & TA.queried32, fb = (wb >> (16u + sb)) & 0xffu & TB.queried32; // FitsFields
@@ -203,6 +206,19 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       if (push) L.cbuf[cn + __popcll(bal & ((1ull << lane) - 1ull))] = key;
       cn += np;
       if (cn >= (uint32_t)BM_CBUF - 64u) publish();
+    }
+    } // (the pending round)
+    // ... and this round's requests
+    p_any = true, p_valid = valid_new, p_row = row_new, p_ra = ra_new, p_rb = rb_new;
+    if (attr1 && !none_fast)
+      p_wa = attr1[(uint64_t)TA.blk_first * 128 + ra_new], p_wb = attr1[(uint64_t)TB.blk_first * 128 + rb_new];
+    else {
+#if MRK_BMEXP == 4 // ablation: scoring without the two gathers
+      p_wa = 0x01010101u + (ra_new & 3u), p_wb = 0x01010101u + (rb_new & 1u);
+#else
+      p_wa = none_fast ? 0x01010101u : attr[(uint64_t)(TA.blk_first + (ra_new >> 7)) * 64 + (ra_new & 63u)];
+      p_wb = none_fast ? 0x01010101u : attr[(uint64_t)(TB.blk_first + (rb_new >> 7)) * 64 + (rb_new & 63u)];
+#endif
     }
   };
 
@@ -312,6 +328,9 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     sink ^= pfa ^ pfb; // (the requested lines are not read here: they are for the caches)
   }
   while (wqn) wqn = unpack(0, wqn);
+#if MRK_BMEXP != 2
+  if (p_any) score(false, 0u, 0u, 0u); // finishes the last round (its own, empty one stays unfinished)
+#endif
   if (sink == 0x9E3779B9u && a.n_items == 0xFFFFFFFFu) ++total; // (keeps the requests alive; never true)
   if (cn) publish();
   {
