@@ -27,9 +27,6 @@ namespace mrk {
 
 constexpr int BM_CBUF = 112; // candidates a wave collects before it publishes them
 constexpr int BM_WORDS = 64; // words per window
-#ifndef MRK_BM_PREFETCH
-#define MRK_BM_PREFETCH 0 // 1: request the burst's tf / field lines as one run ahead of the gathers (measured: slower, 3.43 vs 2.82 ms)
-#endif
 #ifndef MRK_BM_BURST
 #define MRK_BM_BURST 4 // windows requested back to back
 #endif
@@ -250,25 +247,10 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
     return (uint32_t)__popcll(bal);
   };
 
-  // The tf / field words the burst's matches will be gathered from lie in ONE run of each keyword's packed array (slots = ranks,
-  // and the ranks of a burst are consecutive): lane l asks for line l of that run now, in one request -- the memory side
-  // gets a few KB in a row instead of one 128-byte line at a time as the scattered gathers of the scoring rounds arrive.
-  // (An estimate from the keyword's density + 2 lines of slack; what it misses the gathers fetch themselves.)
-  const bool pf_on = !none_fast && !attr1 && MRK_BM_PREFETCH;
-  const uint32_t pfA_lines = pf_on ? (uint32_t)(((uint64_t)TA.docs * BM_BURST * 2 / (a.seg.n_windows ? a.seg.n_windows : 1u)) / 128u) + 2u : 0u;
-  const uint32_t pfB_lines = pf_on ? (uint32_t)(((uint64_t)TB.docs * BM_BURST * 2 / (a.seg.n_windows ? a.seg.n_windows : 1u)) / 128u) + 2u : 0u;
-  const uint64_t endA = (uint64_t)(TA.blk_first + TA.nblocks) * 64, endB = (uint64_t)(TB.blk_first + TB.nblocks) * 64;
-  uint32_t sink = 0;
   for (uint32_t wb = w0; wb < w1; wb += BM_BURST) {
     // BM_BURST windows requested back to back (one memory round trip per burst)
     const uint32_t nb = w1 - wb < (uint32_t)BM_BURST ? w1 - wb : (uint32_t)BM_BURST;
     uint32_t av[BM_BURST], bv[BM_BURST], dv[BM_BURST];
-    uint32_t pfa = 0, pfb = 0;
-    if (pf_on) {
-      const uint64_t oa = (uint64_t)(TA.blk_first + (baseA >> 7)) * 64 + lane * 32u, ob = (uint64_t)(TB.blk_first + (baseB >> 7)) * 64 + lane * 32u;
-      if (lane < pfA_lines && oa < endA) pfa = attr[oa];
-      if (lane < pfB_lines && ob < endB) pfb = attr[ob];
-    }
 #pragma unroll
     for (int i = 0; i < BM_BURST; ++i) {
       av[i] = bv[i] = dv[i] = 0;
@@ -325,13 +307,11 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
         }
       }
     }
-    sink ^= pfa ^ pfb; // (the requested lines are not read here: they are for the caches)
   }
   while (wqn) wqn = unpack(0, wqn);
 #if MRK_BMEXP != 2
   if (p_any) score(false, 0u, 0u, 0u); // finishes the last round (its own, empty one stays unfinished)
 #endif
-  if (sink == 0x9E3779B9u && a.n_items == 0xFFFFFFFFu) ++total; // (keeps the requests alive; never true)
   if (cn) publish();
   {
     uint32_t t = total;
