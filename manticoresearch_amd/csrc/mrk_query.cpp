@@ -239,8 +239,8 @@ struct Parser {
     if (*p == '^' && !t.start) t.start = true, ++p;
     const char* b = p;
     while (wordch((unsigned char)*p)) ++p;
-    if (p == b) { // a character that means nothing here: skip it like the tokenizer would
-      ++p;
+    if (p == b) { // a character that means nothing here: skip it like the tokenizer would ('^' / '=' at the very end: nothing to skip)
+      if (*p) ++p;
       return next();
     }
     t.t = T_WORD;

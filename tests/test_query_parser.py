@@ -184,8 +184,10 @@ def test_parser_under_sanitizers(tmp_path):
     rnd = random.Random(99)
     alphabet = ["a", "bb", "ccc", " ", " ", "(", ")", "|", "-", "!", '"', "~", "/", "1", "0.5", "<<", "NEAR/2", "NOTNEAR/3", "NEAR/", "MAYBE", "SENTENCE",
                 "PARAGRAPH", "@title", "@(title,body)", "@!", "@*", "@body[3]", "@nosuch", "@@relaxed", "^", "$", "=", "*", "^1.5", "\\", "\xc3\xa9", "\x03",
-                "[", "99999999999999999999", "~99999999999", "/0", "@(", "@(title,", "@title["]
-    text = "\n".join("".join(rnd.choice(alphabet) for _ in range(rnd.randint(1, 40))) for _ in range(20000)) + "\n"
+                "[", "99999999999999999999", "~99999999999", "/0", "@(", "@(title,", "@title[", "NEAR", "NOTNEAR/", "SENTENC", "@", "@@", "@@relaxe"]
+    # (short queries too: what a query ENDS with matters -- the harness hands the parser an allocation of the text's exact size, so a
+    # lexer that steps over the terminator, as '... ^' once made it do, lands in ASan's red zone)
+    text = "\n".join("".join(rnd.choice(alphabet) for _ in range(rnd.randint(1, 40 if i & 1 else 6))) for i in range(20000)) + "\n"
     out = subprocess.run([exe], input=text.encode("utf-8"), capture_output=True, timeout=300)
     assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
     ok, bad = (int(x) for x in out.stdout.split()[1::2])
