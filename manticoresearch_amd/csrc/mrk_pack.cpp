@@ -48,6 +48,10 @@ bool validate_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e
     err = "corrupt: doclist outside .spd";
     return false;
   }
+  if ((uint64_t)e.docs * 3 > e.doclist_len || (total_rows && e.docs > total_rows)) {
+    err = "corrupt: the dictionary's doc count does not fit the doclist";
+    return false;
+  }
   Rd rd{spd + e.doclist_off, spd + e.doclist_off + e.doclist_len};
   uint32_t rowid = 0xFFFFFFFFu;
   uint64_t hit_position = 0;
@@ -102,6 +106,11 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
   if (!e.docs) return true;
   if (e.doclist_off == 0 || e.doclist_off > spd_len || e.doclist_len > spd_len - e.doclist_off) {
     err = "corrupt: doclist outside .spd";
+    return false;
+  }
+  // (before anything is sized by the doc count: an entry takes at least 3 bytes in either format, and rowids are distinct)
+  if ((uint64_t)e.docs * 3 > e.doclist_len || (total_rows && e.docs > total_rows)) {
+    err = "corrupt: the dictionary's doc count does not fit the doclist";
     return false;
   }
   Rd rd{spd + e.doclist_off, spd + e.doclist_off + e.doclist_len};
