@@ -332,7 +332,9 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
       }
       dvv[i] = dead ? dead[(uint64_t)w * BT_WORDS + lane] : 0u;
     }
-    {
+    // the query's shared pruning threshold: only a pass that weighs its matches itself prunes, and every 4th burst is often enough
+    // (all waves of the query read the one word; see scan_bm_kernel)
+    if (!need_hits && ((wb - w0) / BT_BURST & 3u) == 0) {
       const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (gt > tau_bin) tau_bin = gt;
     }
