@@ -93,6 +93,7 @@ def main() -> None:
     ap.add_argument("--strata", default="cc,sc,ss", help="subset of strata to run (profiling aid; the metric uses all three)")
     ap.add_argument("--path", type=int, default=0, help="0 = packed doclists (default), 1 = VLB-direct")
     ap.add_argument("--attr-nibbles", action="store_true", help="build the one-byte tf/field plane (ctx key attr_nibbles)")
+    ap.add_argument("--ctx", action="append", default=[], metavar="KEY=VALUE", help="context tunable (mrk_ctx_set), e.g. attr_seq=0")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra 3-term AND/OR mix leg (BASELINE config 3)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = --docs in total, split N ways (default); weak = --docs per GPU (BASELINE config 4: 8 x 100 M)")
@@ -146,6 +147,8 @@ def main() -> None:
     ctx.set("path", args.path)
     if args.attr_nibbles:
         ctx.set("attr_nibbles", 1)
+    for kv in args.ctx:
+        ctx.set(kv.split("=")[0], int(kv.split("=")[1]))
     seg = m.Segment(ctx, hi, rowid_base=row0)
     batch = m.Batch(ctx, args.queries)
     sharded = world > 1 or force_dist
