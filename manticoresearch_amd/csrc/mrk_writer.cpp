@@ -277,7 +277,10 @@ inline uint64_t splitmix64(uint64_t& s) {
 extern "C" int mrk_index_from_hits(const uint64_t* wordid, const uint32_t* rowid, const uint32_t* hitpos, uint64_t n,
                                    uint32_t n_terms, uint32_t skiplist_block_size, uint32_t hit_format,
                                    mrk_host_index** out) {
-  if ((!wordid || !rowid || !hitpos) && n) return mrk_fail(MRK_E_INVAL, "mrk_index_from_hits: NULL argument");
+  if (!out || ((!wordid || !rowid || !hitpos) && n)) return mrk_fail(MRK_E_INVAL, "mrk_index_from_hits: NULL argument");
+  if (skiplist_block_size == 0 || skiplist_block_size > 65536 || hit_format > 1)
+    return mrk_fail(MRK_E_INVAL, "mrk_index_from_hits: skiplist_block_size %u / hit_format %u", skiplist_block_size, hit_format);
+  try {
   std::vector<WordPostings> words(n_terms);
   uint64_t prev_w = 0;
   uint32_t prev_r = 0, prev_h = 0;
@@ -310,6 +313,9 @@ extern "C" int mrk_index_from_hits(const uint64_t* wordid, const uint32_t* rowid
       for (uint32_t h = wp.hit_begin[d]; h + 1 < wp.hit_begin[d + 1]; ++h)
         if ((wp.hits[h] & (1u << 23)) && (wp.hits[h] >> 24) == (wp.hits[h + 1] >> 24)) wp.hits[h] &= ~(1u << 23);
   return build(words, skiplist_block_size, hit_format, 1, out);
+  } catch (const std::bad_alloc&) {
+    return mrk_fail(MRK_E_NOMEM, "mrk_index_from_hits: out of memory (%u terms, %llu hits)", n_terms, (unsigned long long)n);
+  }
 }
 
 // Synthetic postings, deterministic in (seed, term index, GLOBAL rowid): the global rowid space is cut into chunks of
