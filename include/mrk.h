@@ -173,7 +173,9 @@ typedef struct {
   int64_t total_docs_override;  /* CSphQueryContext::m_iTotalDocs (local_df), <= 0: segment's */
   const int64_t* local_docs;    /* per node: m_pLocalDocs override of term docs, < 0 none; or NULL */
   int32_t cutoff;               /* CSphQuery::m_iCutoff (0 = none): the first `cutoff` matches in rowid order are the result set.
-                                   <= MRK_MAX_K, packed path, not next to a weight filter; costs a probe launch inside mrk_batch_submit */
+                                   <= MRK_MAX_K, packed path, not next to a weight filter; costs a probe launch inside mrk_batch_submit.
+                                   Per segment, as MatchExtended counts per disk index; an RT index counts ON across its RAM segments
+                                   (PerformFullTextSearch, sphinxrt.cpp:6302-6380): the caller lowers the cutoff by each segment's total_found */
   const mrk_filter* filters;    /* CSphQuery::m_dFilters resolved against the schema; needs mrk_segment_set_attrs */
   int32_t n_filters;            /* <= MRK_MAX_FILTERS on the device */
   /* CSphQueryContext::m_pWeightFilter: filters on the match weight ('WHERE weight() >= N'; Filter_WeightValues /
