@@ -36,6 +36,7 @@ struct DevSegment {
   const uint32_t* pk_delta; // delta arena
   const uint32_t* pk_attr;  // per block 64 words: tf[l] | tf[l+64]<<8 | fields[l]<<16 | fields[l+64]<<24
   const uint8_t* pk_attr1;  // per doc slot (block*128 + i): tf nibble (15 = see pk_attr) | fields nibble; NULL if > 4 fields
+  const uint16_t* pk_attr2; // per doc slot (block*128 + i) in slot order: tf | fields << 8, filled for keywords with a bitmap, cut after the last of them; NULL = not built
   const uint64_t* pk_exc;   // tf exceptions (tf >= 255): rowid<<32 | tf, sorted per term
   const uint32_t* pk_hit;   // per doc slot (block*128 + i): inlined hit, or hitlist offset from pk_hbase[block]
   const uint64_t* pk_hbase; // per block: .spp position of the block's first hitlist

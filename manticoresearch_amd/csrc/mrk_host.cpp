@@ -225,6 +225,10 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
     c->pack = value != 0;
     return MRK_OK;
   }
+  if (!strcmp(key, "attr_seq")) {
+    c->attr_seq = value != 0;
+    return MRK_OK;
+  }
   if (!strcmp(key, "attr_nibbles")) {
     c->attr_nibbles = value != 0;
     return MRK_OK;
@@ -297,6 +301,7 @@ static void mrk_segment_destroy_impl(mrk_segment* s) {
   if (s->d_pk_hit) (void)hipFree(s->d_pk_hit);
   if (s->d_pk_hbase) (void)hipFree(s->d_pk_hbase);
   if (s->d_pk_attr1) (void)hipFree(s->d_pk_attr1);
+  if (s->d_pk_attr2) (void)hipFree(s->d_pk_attr2);
   if (s->d_dead) (void)hipFree(s->d_dead);
   if (s->d_attrs) (void)hipFree(s->d_attrs);
   if (s->d_blobs) (void)hipFree(s->d_blobs);
@@ -540,6 +545,9 @@ static int mrk_segment_create_impl(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_
   std::vector<uint64_t> pk_exc;
   std::vector<uint32_t> bm_words, bm_dir;
   std::vector<uint8_t> pk_attr1;
+  std::vector<uint16_t> pk_attr2; // (indexed like pk_hit; holds zeros for keywords without a bitmap, cut after the last keyword with one)
+  size_t attr2_end = 0;
+  bool attr2_ok = ctx->attr_seq != 0;
   bool attr1_ok = ctx->attr_nibbles && d->n_fields <= 4;
   bool packed = ctx->pack && d->n_fields <= 8;
   if (!packed) { // no transcode, no walk by pack_term: validate every doclist before any of it reaches the VLB kernel
@@ -624,6 +632,14 @@ static int mrk_segment_create_impl(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_
           attr1_ok = attr1_ok && x.attr1_ok;
           if (attr1_ok) pk_attr1.insert(pk_attr1.end(), x.attr1.begin(), x.attr1.end());
           pk_hbase.insert(pk_hbase.end(), x.hbase.begin(), x.hbase.end());
+          if (attr2_ok) {
+            if (!x.bm.empty() && x.attr2.size() == x.hit.size()) {
+              pk_attr2.resize(pk_hit.size() - x.hit.size(), 0); // (zeros for the keywords since the last dense one)
+              pk_attr2.insert(pk_attr2.end(), x.attr2.begin(), x.attr2.end());
+              attr2_end = pk_attr2.size();
+            } else if (!x.bm.empty())
+              attr2_ok = false;
+          }
           if (!x.bm.empty()) {
             h.bm_off = bm_words.size();
             h.dir_off = bm_dir.size();
@@ -656,6 +672,13 @@ static int mrk_segment_create_impl(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_
         return rc;
       }
       s->device_bytes += pk_attr1.size();
+    }
+    if (attr2_ok && !bm_words.empty() && attr2_end) { // only the bitmap kernel reads it
+      if ((rc = upload(&s->d_pk_attr2, pk_attr2.data(), attr2_end * 2, 256, ctx->stream)) != MRK_OK) {
+        mrk_segment_destroy_impl(s);
+        return rc;
+      }
+      s->device_bytes += attr2_end * 2;
     }
     if (!bm_words.empty()) {
       if ((rc = upload(&s->d_bm, bm_words.data(), bm_words.size() * 4, 1024, ctx->stream)) != MRK_OK ||
@@ -691,6 +714,7 @@ static int mrk_segment_create_impl(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_
   s->dev.pk_hit = (const uint32_t*)s->d_pk_hit;
   s->dev.pk_hbase = (const uint64_t*)s->d_pk_hbase;
   s->dev.pk_attr1 = (const uint8_t*)s->d_pk_attr1;
+  s->dev.pk_attr2 = (const uint16_t*)s->d_pk_attr2;
   s->dev.bm = (const uint32_t*)s->d_bm;
   s->dev.bm_dir = (const uint32_t*)s->d_bm_dir;
   s->dev.n_windows = (uint32_t)((d->total_docs + 2047) / 2048);

@@ -29,6 +29,7 @@ struct mrk_ctx {
   int path = 0;                   // 0 = packed doclists when the segment has them, 1 = VLB (.spd) direct, 2 = packed only
   int pack = 1;                   // build packed doclists at segment load
   int bitmap_inv = 64;            // terms in >= 1/bitmap_inv of the docs also get a bitmap (0 = never)
+  int attr_seq = 1;               // keywords with a bitmap also get their tf / field bytes in slot order (what the bitmap kernel gathers from)
   int attr_nibbles = 0;           // also build the one-byte tf/field plane the bitmap kernel can gather from (<= 4 fields)
   int bm_target_items = 6144;     // bitmap kernel: work items per launch the window ranges are cut into
   int bt_cover_inv = 32;          // trees whose candidate cover holds >= 1/bt_cover_inv of the docs run on bitmap words (0 = never)
@@ -68,6 +69,7 @@ struct mrk_segment {
   void* d_pk_hit = nullptr;
   void* d_pk_hbase = nullptr;
   void* d_pk_attr1 = nullptr;
+  void* d_pk_attr2 = nullptr;
   void* d_dead = nullptr;
   void* d_attrs = nullptr; // .spa rows (mrk_segment_set_attrs)
   void* d_blobs = nullptr; // blob pool (mrk_segment_set_blobs)

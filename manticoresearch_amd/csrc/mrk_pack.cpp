@@ -122,6 +122,7 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
   out.attr.assign((size_t)nblk * 64, 0);
   out.hit.assign((size_t)nblk * 128, 0);
   out.attr1.assign((size_t)nblk * 128, 0);
+  if (bitmap_rows) out.attr2.assign((size_t)nblk * 128, 0);
   out.hbase.reserve(nblk);
   uint64_t hit_position = 0; // m_uHitPosition / m_iHitlistPos (sphinx.cpp:534, 542)
   out.delta.reserve((size_t)nblk * 32 + 8);
@@ -219,6 +220,7 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
       if (hits >= 255) out.exc.push_back(((uint64_t)rowid << 32) | hits);
       if (fields > 15u) out.attr1_ok = false;
       out.attr1[(size_t)b * 128 + i] = (uint8_t)((hits < 15u ? hits : 15u) | ((fields & 15u) << 4));
+      if (bitmap_rows) out.attr2[(size_t)b * 128 + i] = (uint16_t)((hits < 255u ? hits : 255u) | ((fields & 0xffu) << 8));
     }
     out.hbase[b] = hb;
     for (uint32_t i = n; i < 128; ++i) d[i] = 0, tf[i] = 0, fl[i] = 0;
@@ -257,9 +259,10 @@ bool pack_term(const uint8_t* spd, uint64_t spd_len, const mrk_dict_entry& e, bo
   }
   out.packed_bytes = out.delta.size() * 4 + out.attr.size() * 4 + (uint64_t)nblk * 9;
   out.last_rowid = rowid;
-  if (!want_bm)
+  if (!want_bm) {
     out.bm.clear();
-  else {
+    out.attr2.clear();
+  } else {
     const size_t groups = out.bm.size() / (BM_GROUP / 32);
     out.bm_dir.resize(groups + 1);
     uint32_t run = 0;

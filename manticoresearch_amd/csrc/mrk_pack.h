@@ -19,6 +19,9 @@ struct PackedTerm {
   // one byte per doc slot for the bitmap kernel's gathers (half the bytes of the attr words): tf in the low nibble
   // (15 = look at the attr word), fields in the high one; attr1_ok = false when a doc has a field bit >= 4
   std::vector<uint8_t> attr1;
+  // dense terms only (bitmap_rows != 0): tf | fields << 8 per doc slot IN SLOT ORDER (the attr words above interleave slots l and l + 64
+  // for the block decoder; the bitmap kernel gathers by rank, and a line whose docs are scored rounds apart is fetched twice)
+  std::vector<uint16_t> attr2;
   bool attr1_ok = true;
   uint32_t last_rowid = 0; // rowid of the term's last doc
   std::vector<uint32_t> hit;   // 128 per block: the inlined Hitpos_t (inline format, tf == 1) or the doc's

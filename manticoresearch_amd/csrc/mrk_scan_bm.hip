@@ -49,6 +49,8 @@ struct __align__(16) BmSmem {
   float tfidf[2][256];
 };
 
+// SEQ: the segment holds the dense keywords' tf / field bytes in slot order (DevSegment::pk_attr2) and the gathers read those
+template <bool SEQ>
 __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
   __shared__ BmSmem s;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -82,8 +84,9 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
   const uint32_t* __restrict__ bmA = a.seg.bm + TA.bm_off;
   const uint32_t* __restrict__ bmB = a.seg.bm + TB.bm_off;
   const uint32_t* __restrict__ dead = a.seg.dead;
-  const uint32_t* __restrict__ attr = a.seg.pk_attr;
-  const uint8_t* __restrict__ attr1 = a.seg.pk_attr1;
+  const uint32_t* __restrict__ attr = SEQ ? nullptr : a.seg.pk_attr;
+  const uint8_t* __restrict__ attr1 = SEQ ? nullptr : a.seg.pk_attr1; // (the SEQ instance is only launched without the nibble plane)
+  const uint16_t* __restrict__ attr2 = SEQ ? a.seg.pk_attr2 : nullptr;
   // SPH_RANK_NONE without field limits: every common doc matches with weight 1 and the sorter keeps the lowest
   // rowids, so matches are counted straight off the match words, tf / field bytes are never fetched, and windows
   // that lie wholly behind the pruning threshold are not even unpacked
@@ -167,9 +170,9 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       if (tfb == 15u) tfb = (attr[(uint64_t)(TB.blk_first + (rb >> 7)) * 64 + (rb & 63u)] >> (((rb >> 6) & 1u) * 8u)) & 0xffu;
     } else {
       const uint32_t wa = p_wa, wb = p_wb;
-      const uint32_t sa = ((ra >> 6) & 1u) * 8u, sb = ((rb >> 6) & 1u) * 8u;
+      const uint32_t sa = SEQ ? 0u : ((ra >> 6) & 1u) * 8u, sb = SEQ ? 0u : ((rb >> 6) & 1u) * 8u;
       tfa = (wa >> sa) & 0xffu, tfb = (wb >> sb) & 0xffu;
-      fa = (wa >> (16u + sa)) & 0xffu & TA.queried32, fb = (wb >> (16u + sb)) & 0xffu & TB.queried32; // FitsFields
+      fa = (wa >> ((SEQ ? 8u : 16u) + sa)) & 0xffu & TA.queried32, fb = (wb >> ((SEQ ? 8u : 16u) + sb)) & 0xffu & TB.queried32; // FitsFields
     }
     const bool live = valid && (none_fast || (fa != 0 && fb != 0));
     float ta = s.tfidf[0][tfa], tb = s.tfidf[1][tfb];
@@ -213,8 +216,13 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
 #if MRK_BMEXP == 4 // ablation: scoring without the two gathers
       p_wa = 0x01010101u + (ra_new & 3u), p_wb = 0x01010101u + (rb_new & 1u);
 #else
-      p_wa = none_fast ? 0x01010101u : attr[(uint64_t)(TA.blk_first + (ra_new >> 7)) * 64 + (ra_new & 63u)];
-      p_wb = none_fast ? 0x01010101u : attr[(uint64_t)(TB.blk_first + (rb_new >> 7)) * 64 + (rb_new & 63u)];
+      if (SEQ) { // slot order: the matches of a line arrive together
+        p_wa = none_fast ? 0x0101u : attr2[(uint64_t)TA.blk_first * 128 + ra_new];
+        p_wb = none_fast ? 0x0101u : attr2[(uint64_t)TB.blk_first * 128 + rb_new];
+      } else {
+        p_wa = none_fast ? 0x01010101u : attr[(uint64_t)(TA.blk_first + (ra_new >> 7)) * 64 + (ra_new & 63u)];
+        p_wb = none_fast ? 0x01010101u : attr[(uint64_t)(TB.blk_first + (rb_new >> 7)) * 64 + (rb_new & 63u)];
+      }
 #endif
     }
   };
@@ -322,7 +330,10 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
 
 void launch_scan_bm(const ScanArgs& a, void* stream) {
   if (!a.n_items) return;
-  hipLaunchKernelGGL(scan_bm_kernel, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
+  if (a.seg.pk_attr2 && !a.seg.pk_attr1)
+    hipLaunchKernelGGL(scan_bm_kernel<true>, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(scan_bm_kernel<false>, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
 }
 
 } // namespace mrk
