@@ -656,6 +656,11 @@ def test_bitmap_and_kernel(orc, dev):
             check_batch(orc, dev, hi, qs)
         finally:
             ctx.set("attr_nibbles", 0)
+        ctx.set("attr_seq", 0)  # without the slot-ordered plane the gathers read the block decoder's interleaved words
+        try:
+            check_batch(orc, dev, hi, qs)
+        finally:
+            ctx.set("attr_seq", 1)
         seg = m.Segment(ctx, hi)
         batch.search(seg, qs[:8])
         assert batch.stats()["n_items_bm"] > 0  # the bitmap kernel did run
