@@ -674,11 +674,13 @@ static int mrk_segment_create_impl(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_
       s->device_bytes += pk_attr1.size();
     }
     if (attr2_ok && !bm_words.empty() && attr2_end) { // only the bitmap kernel reads it
-      if ((rc = upload(&s->d_pk_attr2, pk_attr2.data(), attr2_end * 2, 256, ctx->stream)) != MRK_OK) {
-        mrk_segment_destroy_impl(s);
-        return rc;
-      }
-      s->device_bytes += attr2_end * 2;
+      // (the plane only saves the bitmap kernel a second fetch of some lines: a segment that does not fit with it loads without it)
+      if (upload(&s->d_pk_attr2, pk_attr2.data(), attr2_end * 2, 256, ctx->stream) != MRK_OK) {
+        if (s->d_pk_attr2) (void)hipFree(s->d_pk_attr2);
+        s->d_pk_attr2 = nullptr;
+        (void)hipGetLastError();
+      } else
+        s->device_bytes += attr2_end * 2;
     }
     if (!bm_words.empty()) {
       if ((rc = upload(&s->d_bm, bm_words.data(), bm_words.size() * 4, 1024, ctx->stream)) != MRK_OK ||
