@@ -522,7 +522,9 @@ int emit(const Parser& P, int ni, mrk_parsed_query& out) {
 } // namespace
 
 extern "C" int mrk_query_parse(const char* text, const char* const* field_names, uint32_t n_fields, uint32_t min_word_len, mrk_parsed_query** out) {
-  if (!text || !out) return mrk_fail(MRK_E_INVAL, "mrk_query_parse: NULL argument");
+  if (!text || !out || (n_fields && !field_names)) return mrk_fail(MRK_E_INVAL, "mrk_query_parse: NULL argument");
+  for (uint32_t i = 0; i < n_fields; ++i)
+    if (!field_names[i]) return mrk_fail(MRK_E_INVAL, "mrk_query_parse: field name %u is NULL", i);
   *out = nullptr;
   Parser P;
   P.p = text, P.fields = field_names, P.n_fields = n_fields, P.min_word_len = min_word_len ? min_word_len : 1;
