@@ -223,7 +223,8 @@ void mrk_ctx_destroy(mrk_ctx* ctx);
    "attr_nibbles" (1 = segments with <= 4 fields also get a one-byte tf/field plane for the bitmap kernel's gathers:
    28 % fewer bytes per dense x dense query, +14 % queries/s on the 100 M-doc bench, +1 byte per posting; default 0 --
    see DESIGN.md section 6; read at segment load);
-   "bm_target_items" (work items per launch the bitmap kernel's window ranges are cut into, default 6144);
+   "bm_target_items" / "bt_target_items" (work items per launch the window ranges of the two-bitmap AND kernel / of the tree kernel over
+   bitmap words are cut into, defaults 8960 / 6144; the AND kernel's items never run under 256 windows);
    "bt_cover_inv" (boolean trees whose candidate cover -- the keywords whose doc lists together hold every possible match --
    names >= 1/bt_cover_inv of the segment's docs are evaluated on doc-set bitmap words, 2048 rowids per step, instead of
    block by block; default 32, 0 = never; read at submit);
