@@ -95,6 +95,7 @@ def main() -> None:
     ap.add_argument("--attr-nibbles", action="store_true", help="build the one-byte tf/field plane (ctx key attr_nibbles)")
     ap.add_argument("--ctx", action="append", default=[], metavar="KEY=VALUE", help="context tunable (mrk_ctx_set), e.g. attr_seq=0")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra 3-term AND/OR mix leg (BASELINE config 3)")
+    ap.add_argument("--sets", type=int, default=0, help="steps kept in flight (sets of batches used in turn); 0 = 2 on one GPU, 4 sharded")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = --docs in total, split N ways (default); weak = --docs per GPU (BASELINE config 4: 8 x 100 M)")
     args = ap.parse_args()
@@ -184,7 +185,7 @@ def main() -> None:
     # two sets of batches used alternately: a step submits its batches and only then collects the previous step's
     # results, so host-side planning of one step overlaps the kernels of the other (what concurrent searchd workers
     # do); every step's results still land in host memory inside the timed region
-    n_sets = 4 if sharded else 2  # the sharded chain (scan, selection, exchange, merge) is longer: keep 4 steps in flight
+    n_sets = args.sets if args.sets > 0 else (4 if sharded else 2)  # the sharded chain (scan, selection, exchange, merge) is longer: keep 4 steps in flight
     sets = [{g: (batch if (i == 0 and g == "cc") else m.Batch(ctx, n)) for g, n in groups} for i in range(n_sets)]
     merger = None
     if sharded:

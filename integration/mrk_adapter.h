@@ -20,8 +20,10 @@
 // sphinxsort.cpp:4541-4547 -- not the whole match stream.  Feeding those K rows to any queue whose order is not exactly
 // that (ORDER BY attribute, expressions, group-by, several sorters, random) would silently drop rows the queue wanted, and
 // so would a filter the device did not evaluate (EarlyReject would thin the K rows out).  MrkEligible therefore admits:
-// one sorter, not group-by, not random, relevance order; no weight filter, no packed factors; max_matches and cutoff <=
-// MRK_MAX_K; filters only if FlattenXQ could hand every one of them to the device.
+// one sorter, not group-by, not random, relevance order; no packed factors; max_matches and cutoff <= MRK_MAX_K; filters
+// (attribute filters: integer VALUES / RANGE, FLOATRANGE, MVA any / all; weight filters) only if FlattenXQ could hand every
+// one of them to the device; a weight filter next to a cutoff stays on the CPU (the cutoff counts matches in rowid order
+// AFTER the weight filter, sphinx.cpp:12223-12267; the device's cutoff probe runs without weights).
 #pragma once
 
 #include "sphinx.h"
@@ -31,6 +33,7 @@
 #include "sphinxsort.h"
 
 #include "mrk.h" // include/mrk.h of the mrk repository
+#include "mrk_replay.h" // the frame replay + keyword-statistics order, free of reference types (executed by tests/cpp/test_replay.cpp)
 
 /// what the host keeps per index / disk chunk next to its CSphIndex
 struct MrkIndexBinding_t
@@ -49,8 +52,12 @@ struct MrkFlatQuery_t
 	CSphVector<int64_t>		m_dLocalDocs;
 	CSphVector<int64_t>		m_dFilterValues [ MRK_MAX_FILTERS ];
 	mrk_filter				m_dFilters [ MRK_MAX_FILTERS ];
+	CSphVector<int64_t>		m_dWeightFilterValues [ MRK_MAX_FILTERS ];
+	mrk_filter				m_dWeightFilters [ MRK_MAX_FILTERS ];	///< filters on @weight / a weight column (CSphQueryContext::m_pWeightFilter)
 	mrk_query				m_tQuery;
-	CSphVector<CSphString>	m_dDictWords;			///< per keyword node, for tMeta.AddStat
+	CSphVector<CSphString>	m_dDictWords;			///< per node (empty for operators), for tMeta.AddStat
+	CSphVector<CSphString>	m_dWords;				///< per node: the query word hQwords is keyed by (XQKeyword_t::m_sWord)
+	int						m_iIndexWeight = 1;		///< what the device multiplied the weights by (only when a weight filter needs the final value there)
 };
 
 
@@ -75,7 +82,7 @@ inline bool MrkEligible ( const CSphQuery & tQuery, const CSphQueryContext & tCt
 {
 	if ( dSorters.GetLength()!=1 )					{ sWhy = "several sorters"; return false; }
 	if ( !MrkSorterIsRelevance ( tQuery, dSorters[0] ) )	{ sWhy = "sorter order is not (weight desc, rowid asc)"; return false; }
-	if ( tCtx.m_pWeightFilter )						{ sWhy = "weight filter"; return false; }	// sphinx.cpp:12216-12227: order-dependent
+	if ( tCtx.m_pWeightFilter && tQuery.m_iCutoff>0 )	{ sWhy = "weight filter next to a cutoff"; return false; }	// sphinx.cpp:12223-12267
 	if ( tQuery.m_iCutoff>MRK_MAX_K )				{ sWhy = "cutoff beyond the device top-K"; return false; }	// sphinx.cpp:12261-12267; smaller ones: mrk_query::cutoff
 	if ( uPackedFactorFlags!=SPH_FACTOR_DISABLE )	{ sWhy = "packed factors"; return false; }
 	if ( tQuery.m_iMaxMatches<1 || tQuery.m_iMaxMatches>MRK_MAX_K )	{ sWhy = "max_matches beyond the device top-K"; return false; }
@@ -187,6 +194,7 @@ public:
 			m_tOut.m_dChildren.Add ( iKid );
 		m_tOut.m_dLocalDocs.Add ( -1 );
 		m_tOut.m_dDictWords.Add ( CSphString() );
+		m_tOut.m_dWords.Add ( CSphString() );
 		return m_tOut.m_dNodes.GetLength()-1;
 	}
 
@@ -226,6 +234,7 @@ private:
 		}
 		m_tOut.m_dLocalDocs.Add ( iLocal );
 		m_tOut.m_dDictWords.Add ( sDictWord );
+		m_tOut.m_dWords.Add ( tWord.m_sWord );
 		return m_tOut.m_dNodes.GetLength()-1;
 	}
 
@@ -237,53 +246,125 @@ private:
 };
 
 
-/// CSphFilterSettings over an integer attribute -> mrk_filter; false = this filter cannot travel (the query stays on the CPU)
-inline bool MrkFlattenFilter ( const CSphFilterSettings & tFilter, const ISphSchema & tSchema, mrk_filter & tOut, CSphVector<int64_t> & dValues )
+/// IsWeightColumn (sphinxfilter.cpp:1895-1902): such a filter becomes part of CSphQueryContext::m_pWeightFilter
+inline bool MrkIsWeightFilter ( const CSphFilterSettings & tFilter, const ISphSchema & tSchema )
+{
+	if ( tFilter.m_sAttrName=="@weight" )
+		return true;
+	const CSphColumnInfo * pCol = tSchema.GetAttr ( tFilter.m_sAttrName.cstr() );
+	return pCol && pCol->m_bWeight;
+}
+
+
+/// the VALUES of a filter, ascending (IFilter_Values::SetValues expects them so), into the flat query's storage
+inline bool MrkFilterValues ( const CSphFilterSettings & tFilter, mrk_filter & tOut, CSphVector<int64_t> & dValues )
+{
+	if ( tFilter.GetNumValues()<1 || tFilter.GetNumValues()>MRK_MAX_FILTER_VALUES )
+		return false;
+	dValues.Resize ( 0 );
+	for ( int i=0; i<tFilter.GetNumValues(); ++i )
+		dValues.Add ( tFilter.GetValue(i) );
+	dValues.Sort();
+	tOut.values = dValues.Begin();
+	tOut.n_values = dValues.GetLength();
+	return true;
+}
+
+
+/// a filter on the match weight (Filter_WeightValues / Filter_WeightRange, sphinxfilter.cpp:304-320, created by
+/// CreateSpecialFilter :944-951: VALUES or RANGE, exclusion wraps it in FilterNot) -> mrk_query::weight_filters
+inline bool MrkFlattenWeightFilter ( const CSphFilterSettings & tFilter, mrk_filter & tOut, CSphVector<int64_t> & dValues )
 {
 	if ( tFilter.m_eType!=SPH_FILTER_VALUES && tFilter.m_eType!=SPH_FILTER_RANGE )
 		return false;
-	if ( tFilter.m_eMvaFunc!=SPH_MVAFUNC_NONE || tFilter.m_bIsNull )
+	memset ( &tOut, 0, sizeof(tOut) );
+	tOut.kind = tFilter.m_eType==SPH_FILTER_VALUES ? MRK_FILTER_VALUES : MRK_FILTER_RANGE;
+	tOut.exclude = tFilter.m_bExclude;
+	tOut.has_equal_min = tFilter.m_bHasEqualMin;
+	tOut.has_equal_max = tFilter.m_bHasEqualMax;
+	tOut.min_value = tFilter.m_iMinValue;
+	tOut.max_value = tFilter.m_iMaxValue;
+	return tFilter.m_eType!=SPH_FILTER_VALUES || MrkFilterValues ( tFilter, tOut, dValues );
+}
+
+
+/// CSphFilterSettings over a row-stored attribute -> mrk_filter, following CreateFilter's dispatch on the attribute type
+/// (sphinxfilter.cpp:954-1060): integer VALUES / RANGE; float columns (FLOATRANGE, and RANGE / one-value VALUES after
+/// FixupFilterSettings :1565-1583 turned them into a float range); MVA columns VALUES / RANGE with ANY() / ALL()
+/// (Filter_MVAValues_Any_c ... Filter_MVARange_All_c, :340-383).  false = this filter cannot travel: the query stays on the CPU
+inline bool MrkFlattenFilter ( const CSphFilterSettings & tFilter, const ISphSchema & tSchema, mrk_filter & tOut, CSphVector<int64_t> & dValues )
+{
+	if ( tFilter.m_bIsNull )
 		return false;
 	const int iAttr = tSchema.GetAttrIndex ( tFilter.m_sAttrName.cstr() );
 	if ( iAttr<0 )
 		return false;
 	const CSphColumnInfo & tCol = tSchema.GetAttr ( iAttr );
-	if ( tCol.m_pExpr || tCol.m_tLocator.m_bDynamic || tCol.m_tLocator.IsBlobAttr() )
-		return false;	// computed / dynamic / blob-stored: not in the .spa row the device holds
-	switch ( tCol.m_eAttrType )
-	{
-		case SPH_ATTR_INTEGER: case SPH_ATTR_TIMESTAMP: case SPH_ATTR_BOOL: case SPH_ATTR_BIGINT: break;
-		default: return false;	// float, string, MVA, JSON ...
-	}
+	if ( tCol.m_pExpr || tCol.m_tLocator.m_bDynamic )
+		return false;	// computed / dynamic: not in the .spa row the device holds
 	memset ( &tOut, 0, sizeof(tOut) );
-	tOut.kind = tFilter.m_eType==SPH_FILTER_VALUES ? MRK_FILTER_VALUES : MRK_FILTER_RANGE;
-	tOut.bit_offset = tCol.m_tLocator.m_iBitOffset;
-	tOut.bit_count = tCol.m_tLocator.m_iBitCount;
 	tOut.exclude = tFilter.m_bExclude;
 	tOut.has_equal_min = tFilter.m_bHasEqualMin;
 	tOut.has_equal_max = tFilter.m_bHasEqualMax;
-	tOut.open_left = tFilter.m_bOpenLeft;
-	tOut.open_right = tFilter.m_bOpenRight;
-	tOut.min_value = tFilter.m_iMinValue;
-	tOut.max_value = tFilter.m_iMaxValue;
-	if ( tFilter.m_eType==SPH_FILTER_VALUES )
+	switch ( tCol.m_eAttrType )
 	{
-		if ( tFilter.GetNumValues()<1 || tFilter.GetNumValues()>MRK_MAX_FILTER_VALUES )
-			return false;
-		dValues.Resize ( 0 );
-		for ( int i=0; i<tFilter.GetNumValues(); ++i )
-			dValues.Add ( tFilter.GetValue(i) );
-		dValues.Sort();	// IFilter_Values::SetValues expects them ascending
-		tOut.values = dValues.Begin();
-		tOut.n_values = dValues.GetLength();
+		case SPH_ATTR_INTEGER: case SPH_ATTR_TIMESTAMP: case SPH_ATTR_BOOL: case SPH_ATTR_BIGINT:
+			if ( tFilter.m_eType!=SPH_FILTER_VALUES && tFilter.m_eType!=SPH_FILTER_RANGE )
+				return false;
+			if ( tFilter.m_eMvaFunc!=SPH_MVAFUNC_NONE || tCol.m_tLocator.IsBlobAttr() )
+				return false;
+			tOut.kind = tFilter.m_eType==SPH_FILTER_VALUES ? MRK_FILTER_VALUES : MRK_FILTER_RANGE;
+			tOut.bit_offset = tCol.m_tLocator.m_iBitOffset;
+			tOut.bit_count = tCol.m_tLocator.m_iBitCount;
+			tOut.open_left = tFilter.m_bOpenLeft;
+			tOut.open_right = tFilter.m_bOpenRight;
+			tOut.min_value = tFilter.m_iMinValue;
+			tOut.max_value = tFilter.m_iMaxValue;
+			return tFilter.m_eType!=SPH_FILTER_VALUES || MrkFilterValues ( tFilter, tOut, dValues );
+
+		case SPH_ATTR_FLOAT:
+			if ( tCol.m_tLocator.IsBlobAttr() )
+				return false;
+			tOut.kind = MRK_FILTER_FLOATRANGE;
+			tOut.bit_offset = tCol.m_tLocator.m_iBitOffset;
+			tOut.bit_count = tCol.m_tLocator.m_iBitCount;
+			if ( tFilter.m_eType==SPH_FILTER_FLOATRANGE )
+			{
+				tOut.fmin = tFilter.m_fMinValue;
+				tOut.fmax = tFilter.m_fMaxValue;
+			} else if ( tFilter.m_eType==SPH_FILTER_RANGE )				// "fltcol BETWEEN 1 AND 3"
+			{
+				tOut.fmin = (float)tFilter.m_iMinValue;
+				tOut.fmax = (float)tFilter.m_iMaxValue;
+			} else if ( tFilter.m_eType==SPH_FILTER_VALUES && tFilter.GetNumValues()==1 )	// "fltcol=intval"
+				tOut.fmin = tOut.fmax = (float)tFilter.GetValue(0);
+			else
+				return false;
+			return true;
+
+		case SPH_ATTR_UINT32SET: case SPH_ATTR_INT64SET:
+			if ( tFilter.m_eType!=SPH_FILTER_VALUES && tFilter.m_eType!=SPH_FILTER_RANGE )
+				return false;
+			if ( !tCol.m_tLocator.IsBlobAttr() )
+				return false;
+			tOut.kind = tFilter.m_eType==SPH_FILTER_VALUES ? MRK_FILTER_VALUES : MRK_FILTER_RANGE;
+			tOut.mva_bits = tCol.m_eAttrType==SPH_ATTR_INT64SET ? 64 : 32;
+			tOut.mva_all = tFilter.m_eMvaFunc==SPH_MVAFUNC_ALL;		// (no explicit ANY() / ALL(): the reference warns and takes ANY)
+			tOut.blob_attr_id = tCol.m_tLocator.m_iBlobAttrId;
+			tOut.n_blob_attrs = tCol.m_tLocator.m_nBlobAttrs;
+			tOut.min_value = tFilter.m_iMinValue;
+			tOut.max_value = tFilter.m_iMaxValue;
+			return tFilter.m_eType!=SPH_FILTER_VALUES || MrkFilterValues ( tFilter, tOut, dValues );
+
+		default:
+			return false;	// string, JSON, pointer-typed attributes of the result set ...
 	}
-	return true;
 }
 
 
 /// XQQuery_t + CSphQuery + CSphQueryContext -> mrk_query.  false + sWhy = keep the CPU ranker.
 inline bool FlattenXQ ( const XQQuery_t & tXQ, const CSphQuery & tQuery, const CSphQueryContext & tCtx, const ISphQwordSetup & tSetup,
-	const MrkIndexBinding_t & tIndex, const ISphSchema & tIndexSchema, MrkFlatQuery_t & tOut, CSphString & sWhy )
+	const MrkIndexBinding_t & tIndex, const ISphSchema & tIndexSchema, int iIndexWeight, MrkFlatQuery_t & tOut, CSphString & sWhy )
 {
 	if ( !tXQ.m_pRoot || tXQ.m_bEmpty )				{ sWhy = "empty query"; return false; }
 	if ( tXQ.m_dZones.GetLength() )					{ sWhy = "zones"; return false; }
@@ -304,23 +385,43 @@ inline bool FlattenXQ ( const XQQuery_t & tXQ, const CSphQuery & tQuery, const C
 		tOut.m_dWeights.Add ( tCtx.m_dWeights[i] );
 	q.field_weights = tOut.m_dWeights.Begin();
 	q.n_weights = tOut.m_dWeights.GetLength();
-	q.index_weight = 1;								// MatchExtended multiplies by iIndexWeight itself (sphinx.cpp:12220); positive, so the order holds
+	q.index_weight = 1;								// MatchExtended multiplies by iIndexWeight itself (sphinx.cpp:12220); positive, so the order holds (weight filters: below)
 	q.plain_idf = tQuery.m_bPlainIDF;
 	q.normalized_tfidf = tQuery.m_bNormalizedTFIDF;
 	q.total_docs_override = tCtx.m_iTotalDocs;
 	q.local_docs = tCtx.m_pLocalDocs ? tOut.m_dLocalDocs.Begin() : nullptr;
 	q.cutoff = tQuery.m_iCutoff>0 ? tQuery.m_iCutoff : 0;	// the device hands back the best of the first m_iCutoff matches; MatchExtended's own count then runs out on the last of them
 
-	// filters: every one of them on the device, or the query stays on the CPU (EarlyReject would thin the K rows out)
-	if ( tQuery.m_dFilters.GetLength()>MRK_MAX_FILTERS )	{ sWhy = "more filters than the device evaluates"; return false; }
+	// filters: every one of them on the device, or the query stays on the CPU (EarlyReject would thin the K rows out).
+	// sphCreateFilters' split (sphinxfilter.cpp:2040-2105): filters on @weight / a weight column make up m_pWeightFilter,
+	// the rest m_pFilter; nameless entries are skipped
+	int nFilters = 0, nWeightFilters = 0;
 	ARRAY_FOREACH ( i, tQuery.m_dFilters )
-		if ( !MrkFlattenFilter ( tQuery.m_dFilters[i], tIndexSchema, tOut.m_dFilters[i], tOut.m_dFilterValues[i] ) )
+	{
+		const CSphFilterSettings & tFilter = tQuery.m_dFilters[i];
+		if ( tFilter.m_sAttrName.IsEmpty() )
+			continue;
+		const bool bWeight = MrkIsWeightFilter ( tFilter, tIndexSchema );
+		int & nKind = bWeight ? nWeightFilters : nFilters;
+		if ( nKind>=MRK_MAX_FILTERS )					{ sWhy = "more filters than the device evaluates"; return false; }
+		const bool bOk = bWeight
+			? MrkFlattenWeightFilter ( tFilter, tOut.m_dWeightFilters[nKind], tOut.m_dWeightFilterValues[nKind] )
+			: MrkFlattenFilter ( tFilter, tIndexSchema, tOut.m_dFilters[nKind], tOut.m_dFilterValues[nKind] );
+		if ( !bOk )
 		{
-			sWhy.SetSprintf ( "filter on '%s' is not an integer VALUES / RANGE filter over a row-stored attribute", tQuery.m_dFilters[i].m_sAttrName.cstr() );
+			sWhy.SetSprintf ( "filter on '%s' is not one the device evaluates (integer VALUES / RANGE, FLOATRANGE, MVA, weight)", tFilter.m_sAttrName.cstr() );
 			return false;
 		}
-	q.filters = tQuery.m_dFilters.GetLength() ? tOut.m_dFilters : nullptr;
-	q.n_filters = tQuery.m_dFilters.GetLength();
+		++nKind;
+	}
+	q.filters = nFilters ? tOut.m_dFilters : nullptr;
+	q.n_filters = nFilters;
+	q.weight_filters = nWeightFilters ? tOut.m_dWeightFilters : nullptr;
+	q.n_weight_filters = nWeightFilters;
+	// the weight filter sees the weight AFTER "m_iWeight *= iIndexWeight" (sphinx.cpp:12220-12223): only then does the device
+	// multiply too, and the replay divides again before MatchExtended multiplies (MrkFrameReplay_T::Next)
+	tOut.m_iIndexWeight = nWeightFilters ? Max ( iIndexWeight, 1 ) : 1;
+	q.index_weight = tOut.m_iIndexWeight;
 	return true;
 }
 
@@ -331,24 +432,38 @@ class MrkRankerAdapter_c final : public ISphRanker
 public:
 	static const int FRAME = 256;	///< the buffer length is the ranker's choice: MatchExtended only uses the returned count
 
-	MrkRankerAdapter_c ( mrk_batch * pBatch, const MrkIndexBinding_t & tIndex, ISphMatchSorter * pSorter, MrkFlatQuery_t * pFlat, const ISphQwordSetup & tSetup )
-		: m_pBatch ( pBatch ), m_tIndex ( tIndex ), m_pSorter ( pSorter ), m_pFlat ( pFlat )
+	MrkRankerAdapter_c ( mrk_batch * pBatch, mrk_batcher * pBatcher, const MrkIndexBinding_t & tIndex, ISphMatchSorter * pSorter, MrkFlatQuery_t * pFlat, const ISphQwordSetup & tSetup )
+		: m_pBatch ( pBatch ), m_pBatcher ( pBatcher ), m_tIndex ( tIndex ), m_pSorter ( pSorter ), m_pFlat ( pFlat )
 	{
 		Bind ( tSetup );
 	}
 
-	/// submit + wait; false = the device declined (MRK_E_UNSUPPORTED) or failed: the caller falls back to ExtRanker_*
+	/// run the query on the device; false = the device declined (MRK_E_UNSUPPORTED) or failed: the caller falls back to ExtRanker_*.
+	/// With a batcher the query joins whatever the other workers have queued: one mrk_batch_submit for
+	/// all of them, the calling coroutine's thread sleeps on a condition variable meanwhile (no HIP on its 128 KB stack); the rows
+	/// land in this ranker's own buffers.  Without one: a batch of one on the worker's own mrk_batch.
 	bool Run ( CSphString & sError )
 	{
-		m_iNext = 0;
-		m_bDone = false;
-		memset ( &m_tResult, 0, sizeof(m_tResult) );
-		if ( mrk_batch_submit ( m_pBatch, m_tIndex.m_pSegment, &m_pFlat->m_tQuery, 1 )!=MRK_OK || mrk_batch_wait ( m_pBatch )!=MRK_OK
-			|| mrk_batch_result ( m_pBatch, 0, &m_tResult )!=MRK_OK || m_tResult.status!=MRK_OK )
+		mrk_result tResult;
+		memset ( &tResult, 0, sizeof(tResult) );
+		if ( m_pBatcher )
+		{
+			const int iCap = m_pFlat->m_tQuery.max_matches;
+			m_dRowIDs.Resize ( iCap );
+			m_dWeights.Resize ( iCap );
+			if ( mrk_batcher_search ( m_pBatcher, m_tIndex.m_pSegment, &m_pFlat->m_tQuery, m_dRowIDs.Begin(), m_dWeights.Begin(), iCap, &tResult )!=MRK_OK
+				|| tResult.status!=MRK_OK )
+			{
+				sError = mrk_last_error();
+				return false;
+			}
+		} else if ( mrk_batch_submit ( m_pBatch, m_tIndex.m_pSegment, &m_pFlat->m_tQuery, 1 )!=MRK_OK || mrk_batch_wait ( m_pBatch )!=MRK_OK
+			|| mrk_batch_result ( m_pBatch, 0, &tResult )!=MRK_OK || tResult.status!=MRK_OK )
 		{
 			sError = mrk_last_error();
 			return false;
 		}
+		m_tReplay.Start ( tResult, m_pFlat->m_iIndexWeight );
 		return true;
 	}
 
@@ -357,28 +472,22 @@ public:
 	/// next frame of the device's K best; 0 = end of stream
 	int GetMatches() final
 	{
-		int iRes = 0;
-		while ( !iRes && m_iNext<m_tResult.n )
-			while ( iRes<FRAME && m_iNext<m_tResult.n )
-			{
-				CSphMatch & tMatch = m_dMatches[iRes];
-				tMatch.m_tRowID = m_tResult.rowid[m_iNext];
-				tMatch.m_iWeight = m_tResult.weight[m_iNext];
-				++m_iNext;
-				// sets m_pStatic and runs the query's filters (the device already applied them all: none rejects)
-				if ( !m_pIndex->EarlyReject ( m_pCtx, tMatch ) )
-					++iRes;
-			}
-		if ( !iRes && !m_bDone )
-		{
-			// End of stream: every row above has been Push()ed by now (MatchExtended pushes a frame before it asks for the
-			// next one).  The queue counted K pushes; the query matched total_found docs (CSphMatchQueueTraits::m_iTotal,
-			// sphinxsort.cpp:724) -- m_iTotal is a public member of ISphMatchSorter, no setter needed.
-			m_bDone = true;
-			if ( m_pSorter )
-				m_pSorter->m_iTotal += m_tResult.total_found - m_tResult.n;
-		}
+		// EarlyReject sets m_pStatic and runs the query's filters (the device already applied them all: none rejects)
+		const int iRes = m_tReplay.Next ( m_dMatches, FRAME, [this] ( CSphMatch & tMatch ) { return m_pIndex->EarlyReject ( m_pCtx, tMatch ); } );
+		// End of stream: every row above has been Push()ed by now (MatchExtended pushes a frame before it asks for the next
+		// one).  The queue counted K pushes; the query matched total_found docs (CSphMatchQueueTraits::m_iTotal,
+		// sphinxsort.cpp:724) -- m_iTotal is a public member of ISphMatchSorter, no setter needed.
+		if ( !iRes )
+			m_tReplay.Finish ( m_pSorter );
 		return iRes;
+	}
+
+	/// called once behind the match loop (sphinx.cpp:15919, sphinxrt.cpp:6441), also when a cutoff ended the loop on the last
+	/// row of a frame and GetMatches() never saw the end of the stream
+	void FinalizeCache ( const ISphSchema & ) final
+	{
+		if ( m_tReplay.AtEnd() )
+			m_tReplay.Finish ( m_pSorter );
 	}
 
 	/// RT rebinding to the next RAM segment (sphinxrt.cpp:6313-6314) does not come here: RAM segments are not on the device
@@ -386,12 +495,12 @@ public:
 	void Reset ( const ISphQwordSetup & tSetup ) final
 	{
 		Bind ( tSetup );
-		m_iNext = m_tResult.n;
+		m_tReplay.Exhaust();
 	}
 
 	bool IsCache() const final { return false; }
 
-	int64_t GetTotalFound() const { return m_tResult.total_found; }
+	int64_t GetTotalFound() const { return m_tReplay.Result().total_found; }
 	const MrkFlatQuery_t & GetFlatQuery() const { return *m_pFlat; }
 
 private:
@@ -406,45 +515,61 @@ private:
 	}
 
 	mrk_batch *					m_pBatch;
+	mrk_batcher *				m_pBatcher;
 	MrkIndexBinding_t			m_tIndex;
 	ISphMatchSorter *			m_pSorter;
 	CSphScopedPtr<MrkFlatQuery_t> m_pFlat;
 	const CSphIndex *			m_pIndex = nullptr;
 	CSphQueryContext *			m_pCtx = nullptr;
-	mrk_result					m_tResult;
-	int							m_iNext = 0;
-	bool						m_bDone = false;
+	MrkFrameReplay_T<CSphMatch>	m_tReplay;
+	CSphVector<uint32_t>		m_dRowIDs;		///< the batcher copies the query's rows here (a shared batch is resubmitted at once)
+	CSphVector<int32_t>			m_dWeights;
 	CSphMatch					m_dMatches[FRAME];
 };
 
 
 /// What sphCreateRanker calls before its "switch ( tQuery.m_eRanker )" (INTEGRATION.md section 2).  nullptr (sWhy says why)
-/// = this query keeps the ExtRanker_* path; never an error.  pBatch: the calling worker's mrk_batch (one per thread).
+/// = this query keeps the ExtRanker_* path; never an error.  pBatcher: the index's shared MrkBatcher (all workers' queries
+/// leave in common launches); or pBatch: the calling worker's own mrk_batch (one per thread, one query per launch).
+/// iIndexWeight: MatchExtended's argument (CSphMultiQueryArgs::m_iIndexWeight, visible where sphCreateRanker is called,
+/// sphinx.cpp:15770): only a weight filter needs it on the device.
 inline ISphRanker * MrkCreateRanker ( const XQQuery_t & tXQ, const CSphQuery & tQuery, CSphQueryResultMeta & tMeta, const ISphQwordSetup & tSetup,
 	const CSphQueryContext & tCtx, const ISphSchema & tIndexSchema, const VecTraits_T<ISphMatchSorter *> & dSorters, DWORD uPackedFactorFlags,
-	const MrkIndexBinding_t & tIndex, mrk_batch * pBatch, CSphString & sWhy )
+	const MrkIndexBinding_t & tIndex, mrk_batch * pBatch, mrk_batcher * pBatcher, int iIndexWeight, CSphString & sWhy )
 {
-	if ( !tIndex.m_pSegment || !tIndex.m_pFiles || !pBatch )	{ sWhy = "index has no device segment"; return nullptr; }
+	if ( !tIndex.m_pSegment || !tIndex.m_pFiles || ( !pBatch && !pBatcher ) )	{ sWhy = "index has no device segment"; return nullptr; }
 	if ( !MrkEligible ( tQuery, tCtx, dSorters, uPackedFactorFlags, sWhy ) )
 		return nullptr;
 	CSphScopedPtr<MrkFlatQuery_t> pFlat ( new MrkFlatQuery_t );
-	if ( !FlattenXQ ( tXQ, tQuery, tCtx, tSetup, tIndex, tIndexSchema, *pFlat.Ptr(), sWhy ) )
+	if ( !FlattenXQ ( tXQ, tQuery, tCtx, tSetup, tIndex, tIndexSchema, iIndexWeight, *pFlat.Ptr(), sWhy ) )
 		return nullptr;
 	MrkFlatQuery_t * pRawFlat = pFlat.LeakPtr();
-	CSphScopedPtr<MrkRankerAdapter_c> pRanker ( new MrkRankerAdapter_c ( pBatch, tIndex, dSorters[0], pRawFlat, tSetup ) );
+	CSphScopedPtr<MrkRankerAdapter_c> pRanker ( new MrkRankerAdapter_c ( pBatch, pBatcher, tIndex, dSorters[0], pRawFlat, tSetup ) );
 	if ( !pRanker->Run ( sWhy ) )
 		return nullptr;	// MRK_E_UNSUPPORTED (DESIGN.md section 1 lists what the device declines): not an error
-	// keyword statistics in query-position order, as sphCreateRanker reports them (sphinxsearch.cpp:4365-4371)
+	// keyword statistics: once per DISTINCT query word, in query-position order, as sphCreateRanker reports them
+	// (sphinxsearch.cpp:4365-4371: hQwords is keyed by the query word; CSphQueryResultMeta::AddStat accumulates,
+	// sphinx.cpp:27907-27914, so a repeated keyword must not be reported twice)
+	CSphVector<int> dTermNodes, dAtomPos;
+	CSphVector<bool> dNotWeighted;
 	ARRAY_FOREACH ( i, pRawFlat->m_dNodes )
+		if ( pRawFlat->m_dNodes[i].op==MRK_OP_TERM )
+		{
+			dTermNodes.Add ( i );
+			dAtomPos.Add ( pRawFlat->m_dNodes[i].atom_pos );
+			dNotWeighted.Add ( pRawFlat->m_dNodes[i].not_weighted!=0 );
+		}
+	CSphVector<MrkWordStat_t> dStats ( dTermNodes.GetLength() );
+	const int nStats = MrkDistinctWords ( dTermNodes.GetLength(), dAtomPos.Begin(), dNotWeighted.Begin(),
+		[&] ( int a, int b ) { return pRawFlat->m_dWords[dTermNodes[a]]==pRawFlat->m_dWords[dTermNodes[b]]; }, dStats.Begin() );
+	uint32_t nTerms = 0;
+	const mrk_dict_entry * pDict = mrk_host_index_dict ( tIndex.m_pFiles, &nTerms );
+	for ( int i=0; i<nStats; ++i )
 	{
-		const mrk_node & tNode = pRawFlat->m_dNodes[i];
-		if ( tNode.op!=MRK_OP_TERM )
-			continue;
-		const mrk_dict_entry * pDict = nullptr;
-		uint32_t nTerms = 0;
-		pDict = mrk_host_index_dict ( tIndex.m_pFiles, &nTerms );
+		const int iNode = dTermNodes[dStats[i].m_iNode];
+		const mrk_node & tNode = pRawFlat->m_dNodes[iNode];
 		const bool bKnown = tNode.term_id>=0 && (uint32_t)tNode.term_id<nTerms;
-		tMeta.AddStat ( pRawFlat->m_dDictWords[i], bKnown ? pDict[tNode.term_id].docs : 0, bKnown ? pDict[tNode.term_id].hits : 0 );
+		tMeta.AddStat ( pRawFlat->m_dDictWords[iNode], bKnown ? pDict[tNode.term_id].docs : 0, bKnown ? pDict[tNode.term_id].hits : 0 );
 	}
 	return pRanker.LeakPtr();
 }

@@ -348,16 +348,55 @@ struct ScanArgs {
   GenArgs gen;
 };
 
+// Top-K selection over the candidate lists (mrk_select.hip), three launches on the batch's stream:
+//   sel_tau_kernel    one wave per query: final threshold bin of its histogram, number of 2048-key slices of its list
+//   sel_filter_kernel a grid over ALL slices of ALL queries: keys whose bin reaches the threshold are compacted to the
+//                     front of their own slice (in place: a slice belongs to one workgroup), the count goes to slice_cnt
+//   sel_sort_kernel   one workgroup per query: gathers the slices' survivors (about K + the threshold bin's population),
+//                     sorts, emits the best K
+// A query's selection cost no longer depends on the length of its candidate list (one workgroup used to walk it all).
+constexpr int SEL_SLICE = 2048;  // keys per slice
+constexpr int SEL_MAXQ = 4096;   // queries per launch group (the filter kernel keeps their slice prefix in LDS)
 struct SelectArgs {
   const DevQuery* queries;
   const uint32_t* q_hist;
   const uint32_t* q_cand_n;
-  const uint64_t* cand;
+  uint64_t* cand;     // (the filter pass compacts each slice in place)
   uint32_t n_queries;
   uint32_t rowid_base;
   uint64_t* out_keys; // [n_queries][KCAP], sorted descending
   uint32_t* out_cnt;
+  uint32_t* sel_tau;    // [n_queries] final threshold bin
+  uint32_t* sel_nslice; // [n_queries] slices of the query's list in use
+  uint32_t* slice_cnt;  // survivors per slice; slice j of query q sits at (cand_off >> 11) + q + j
+  uint32_t max_slices;  // upper bound of the batch's slices in use (sizes the filter grid)
+  uint32_t rowid_hi;    // largest global rowid of the segment (rowid_base + docs - 1) and the bits of docs - 1: the sort pass
+  uint32_t rowid_bits;  // orders the survivors of the threshold bin by (weight, rowid_hi - rowid) in sub-bins
+  // The sort pass also hands the batch's results to the host: it writes them straight into pinned host memory (stores over
+  // PCIe from the kernel).  A batch used to queue five device-to-host copies behind its selection; on MI355X those go through
+  // the SDMA engine, which serves the copies of ALL streams in order -- the next batch's descriptor upload waited behind the
+  // previous batch's result copies, and a 12.5 M-doc step spent a third of its time with the GPU idle.
+  const uint64_t* q_total; // [n_queries] matches counted by the scan
+  const uint32_t* q_flags; // [n_queries] QF_*
+  uint64_t* h_keys;        // pinned host [n_queries][KCAP] or NULL (the batch feeds a shard exchange: rows stay on the device)
+  uint32_t* h_cnt;         // pinned host [n_queries] or NULL
+  uint64_t* h_total;       // pinned host [n_queries] or NULL
+  uint32_t* h_flags;       // pinned host [n_queries] or NULL
+  uint32_t* h_cand_n;      // pinned host [n_queries] or NULL
 };
+
+// One launch instead of two copies and a memset in front of every scan: query and work-item descriptors are read from the
+// batch's pinned staging memory by the kernel itself (no SDMA engine between two scans), the per-query scan state is cleared.
+struct PrepArgs {
+  uint32_t* dst[2];
+  const uint32_t* src[2]; // pinned host memory
+  uint32_t n4[2];         // dwords
+  uint32_t* zero;
+  uint32_t zero_n4;
+};
+void launch_prep(const PrepArgs& a, void* stream);
+// slice_cnt entries a batch of n queries with cand_total candidate slots needs
+inline uint64_t sel_slice_slots(uint64_t cand_total, uint64_t n) { return (cand_total >> 11) + n + 2; }
 
 struct MergeArgs {
   const uint64_t* in_keys;  // lists of <= KCAP keys

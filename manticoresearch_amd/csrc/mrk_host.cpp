@@ -137,6 +137,7 @@ struct mrk_batch {
   DevBuf<uint32_t> d_list_first, d_list_n, d_kq;
   DevBuf<uint64_t> d_out_keys;
   DevBuf<uint32_t> d_out_cnt;
+  DevBuf<uint32_t> d_sel; // selection scratch: threshold bin | slices in use per query, then the survivors per slice
   // packed path: pruning histograms, candidate lists
   View<uint32_t> d_q_hist, d_q_cand_n, d_q_flags, d_q_tau_bin;
   PinBuf<uint32_t> h_cand_n;
@@ -261,6 +262,16 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "mq_max_chunks")) {
     if (value < 1 || value > (1 << 24)) return mrk_fail(MRK_E_INVAL, "mq_max_chunks must be 1 .. 2^24");
     c->mq_max_chunks = (int)value;
+    return MRK_OK;
+  }
+  if (!strcmp(key, "pk_min_items")) {
+    if (value < 1 || value > (1 << 20)) return mrk_fail(MRK_E_INVAL, "pk_min_items must be 1 .. 2^20");
+    c->pk_min_items = (int)value;
+    return MRK_OK;
+  }
+  if (!strcmp(key, "bm_min_windows")) {
+    if (value < 16 || value > 4096) return mrk_fail(MRK_E_INVAL, "bm_min_windows must be 16 .. 4096");
+    c->bm_min_windows = (int)value;
     return MRK_OK;
   }
   if (!strcmp(key, "bitmap_inv")) {
@@ -782,6 +793,7 @@ static void mrk_batch_destroy_impl(mrk_batch* b) {
   b->d_kq.release();
   b->d_out_keys.release();
   b->d_out_cnt.release();
+  b->d_sel.release();
 
   b->h_cand_n.release();
   b->d_cand.release();
@@ -957,6 +969,15 @@ static int cutoff_probe(mrk_batch* b, mrk_segment* seg, const mrk_query* queries
   return MRK_OK;
 }
 
+// the selection's sub-bin geometry: the segment's largest global rowid and the bits its rowid range needs
+static void sel_rowid_range(const mrk_segment* seg, mrk::SelectArgs& se) {
+  const uint64_t docs = std::max<uint64_t>(seg->total_docs, 1);
+  uint32_t bits = 1;
+  while (bits < 32 && ((docs - 1) >> bits)) ++bits;
+  se.rowid_bits = bits;
+  se.rowid_hi = (uint32_t)(seg->dev.rowid_base + docs - 1);
+}
+
 static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n) {
   if (!b || !seg || (!queries && n)) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: NULL argument");
   if (n > b->max_queries) return mrk_fail(MRK_E_INVAL, "mrk_batch_submit: %u queries > batch capacity %u", n, b->max_queries);
@@ -1014,6 +1035,51 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
     b->h_list_n.p[i] = b->h_queries.p[i].n_items;
     b->h_kq.p[i] = b->h_queries.p[i].k ? b->h_queries.p[i].k : 1;
   }
+  // A small batch (one-eighth shards, selective keywords, a lone query): the planner cuts a driver doclist into ~item_bytes
+  // pieces whatever the batch holds, and 280 workgroups that each walk 70 blocks per wave one after the other leave the chip
+  // idle for 0.1 ms.  Cut the block ranges finer until the launch has pk_min_items work items (never under one block per wave).
+  if (use_packed && !items.empty() && items.size() < (size_t)b->ctx->pk_min_items) {
+    uint64_t total_blocks = 0;
+    for (const DevItem& it : items) total_blocks += it.blk_end - it.blk_begin;
+    uint64_t per = (total_blocks + (uint64_t)b->ctx->pk_min_items - 1) / (uint64_t)b->ctx->pk_min_items;
+    per = std::max<uint64_t>(T0_BLOCKS, (per + T0_BLOCKS - 1) / T0_BLOCKS * T0_BLOCKS);
+    std::vector<DevItem> cut;
+    cut.reserve(items.size() + (size_t)(total_blocks / per) + 1);
+    std::vector<uint32_t> per_pass((size_t)n + extra.size(), 0);
+    for (const DevItem& whole : items)
+      for (uint64_t x = whole.blk_begin; x < whole.blk_end; x += per) {
+        DevItem it = whole;
+        it.blk_begin = (uint32_t)x;
+        it.blk_end = (uint32_t)std::min<uint64_t>(whole.blk_end, x + per);
+        cut.push_back(it);
+        if (it.query < per_pass.size()) ++per_pass[it.query];
+      }
+    items.swap(cut);
+    // (the counts feed the match-queue sizing below; the VLB path's per-query list ranges are not built from a packed plan)
+    for (uint32_t i = 0; i < n; ++i)
+      if (per_pass[i]) b->h_queries.p[i].n_items = per_pass[i];
+    for (size_t e = 0; e < extra.size(); ++e)
+      if (per_pass[n + e]) extra[e].n_items = per_pass[n + e];
+  }
+  // ... and in piece-major order, for the reason given at the window-range items below: concurrent workgroups should belong
+  // to different queries (the planner emits a query's items back to back; only the VLB path needs them that way)
+  if (use_packed && items.size() > 1) {
+    std::vector<DevItem> rr;
+    rr.reserve(items.size());
+    std::vector<size_t> run_begin, run_end; // runs of items of one pass
+    for (size_t i = 0; i < items.size();) {
+      size_t j = i + 1;
+      while (j < items.size() && items[j].query == items[i].query) ++j;
+      run_begin.push_back(i), run_end.push_back(j);
+      i = j;
+    }
+    if (run_begin.size() > 1) {
+      for (size_t k = 0; rr.size() < items.size(); ++k)
+        for (size_t r = 0; r < run_begin.size(); ++r)
+          if (run_begin[r] + k < run_end[r]) rr.push_back(items[run_begin[r] + k]);
+      items.swap(rr);
+    }
+  }
   const float plan_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count();
   const size_t n_items_pk = items.size();
   // window-range work items (two-bitmap AND kernel, then the window-driven tree kernel) ride behind the block work
@@ -1027,16 +1093,27 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
     if (!total_win) continue;
     const uint64_t unit = 4 * WAVES; // one burst per wave
     uint64_t wpi = (total_win / (uint64_t)(kind == 0 ? b->ctx->bm_target_items : b->ctx->bt_target_items) / unit) * unit;
-    wpi = std::min<uint64_t>(std::max<uint64_t>(wpi, kind == 0 ? 16 * unit : 4 * unit), 4096); // (short runs: a wave's fixed costs show -- 12.5 M docs, 8192 items: 0.55 vs 0.47 ms)
+    wpi = std::min<uint64_t>(std::max<uint64_t>(wpi, kind == 0 ? (uint64_t)b->ctx->bm_min_windows / unit * unit : 4 * unit), 4096); // (short runs: a wave's fixed costs show -- 12.5 M docs, 8192 items: 0.55 vs 0.47 ms)
+    // Piece-major order: the k-th piece of every query, then the (k+1)-th ...  Workgroups that run at the same time then
+    // belong to DIFFERENT queries.  Query-major order put a query's 20-50 workgroups on the chip together, all of them adding
+    // to the one candidate counter, the same few histogram bins and the one threshold word of that query: device-scope
+    // atomics on one address serialize at the memory side (~70 ns each), about 0.1 ms per query whatever the shard size --
+    // hidden behind 100 M docs, the whole launch at 12.5 M (12288 work items: 0.85 ms; 4096: 0.39 ms, same bytes).
     const size_t before = items.size();
-    for (const DevItem& whole : items_bm)
-      if (whole.kind == kind)
-        for (uint64_t w = whole.blk_begin; w < whole.blk_end; w += wpi) {
-          DevItem it = whole;
-          it.blk_begin = (uint32_t)w;
-          it.blk_end = (uint32_t)std::min<uint64_t>(whole.blk_end, w + wpi);
-          items.push_back(it);
-        }
+    for (uint64_t piece = 0;; ++piece) {
+      bool any = false;
+      for (const DevItem& whole : items_bm) {
+        if (whole.kind != kind) continue;
+        const uint64_t w = whole.blk_begin + piece * wpi;
+        if (w >= whole.blk_end) continue;
+        any = true;
+        DevItem it = whole;
+        it.blk_begin = (uint32_t)w;
+        it.blk_end = (uint32_t)std::min<uint64_t>(whole.blk_end, w + wpi);
+        items.push_back(it);
+      }
+      if (!any) break;
+    }
     n_items_kind[kind] = items.size() - before;
   }
   for (const DevItem& it : items_bm) // the generic evaluator's candidates: block ranges, cut by the planner
@@ -1072,25 +1149,32 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   const size_t n_pass = (size_t)n + extra.size();
   if ((rc = b->h_queries.reserve_keep(n_pass, n)) || (rc = b->d_queries.reserve(n_pass))) return rc;
   if (!extra.empty()) memcpy(b->h_queries.p + n, extra.data(), extra.size() * sizeof(DevQuery));
-  if (use_packed && (rc = b->d_cand.reserve(cand_total + 64))) return rc;
+  if (use_packed && ((rc = b->d_cand.reserve(cand_total + 64)) || (rc = b->d_sel.reserve(2 * (size_t)n + mrk::sel_slice_slots(cand_total, n))))) return rc;
 
   static const bool phase_timing = getenv("MRK_SUBMIT_TIMING") != nullptr;
   auto lap = [&](const char* what) {
     if (phase_timing)
-      fprintf(stderr, "mrk submit n=%u %s @%.3f ms\n", n, what,
-              std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count());
+      fprintf(stderr, "mrk submit %p n=%u %s @%.3f ms (abs %.3f)\n", (void*)b, n, what,
+              std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
   };
   lap("planned+staged");
-  // ---- copy descriptors, launch
-  HIP_TRY(hipMemcpyAsync(b->d_queries.p, b->h_queries.p, n_pass * sizeof(DevQuery), hipMemcpyHostToDevice, st));
-  if (n_items) HIP_TRY(hipMemcpyAsync(b->d_items.p, b->h_items.p, n_items * sizeof(DevItem), hipMemcpyHostToDevice, st));
+  // ---- descriptors up + scan state cleared: one kernel on the scan stream (prep_kernel reads the pinned staging itself)
+  {
+    static_assert(sizeof(DevQuery) % 4 == 0 && sizeof(DevItem) % 4 == 0, "descriptors are copied dword-wise");
+    mrk::PrepArgs pa{};
+    pa.dst[0] = (uint32_t*)b->d_queries.p, pa.src[0] = (const uint32_t*)b->h_queries.p, pa.n4[0] = (uint32_t)(n_pass * sizeof(DevQuery) / 4);
+    pa.dst[1] = (uint32_t*)b->d_items.p, pa.src[1] = (const uint32_t*)b->h_items.p, pa.n4[1] = (uint32_t)(n_items * sizeof(DevItem) / 4);
+    // totals, thresholds, counters (+ the pruning histograms of the queries in use)
+    pa.zero = (uint32_t*)b->d_state.p;
+    pa.zero_n4 = (uint32_t)(((size_t)b->max_queries * 28 + (use_packed ? (size_t)n * NBINS * 4 : 0)) / 4);
+    launch_prep(pa, st);
+  }
   if (!use_packed) { // the VLB path's merge kernel reads per-query list ranges
     HIP_TRY(hipMemcpyAsync(b->d_list_first.p, b->h_list_first.p, n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b->d_list_n.p, b->h_list_n.p, n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b->d_kq.p, b->h_kq.p, n * 4, hipMemcpyHostToDevice, st));
   }
-  // totals, thresholds, counters (+ the pruning histograms of the queries in use): one memset
-  HIP_TRY(hipMemsetAsync(b->d_state.p, 0, (size_t)b->max_queries * 28 + (use_packed ? (size_t)n * NBINS * 4 : 0), st));
 
   ScanArgs sa{};
   sa.seg = seg->dev;
@@ -1168,6 +1252,18 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
     se.rowid_base = seg->dev.rowid_base;
     se.out_keys = b->d_out_keys.p;
     se.out_cnt = b->d_out_cnt.p;
+    se.sel_tau = b->d_sel.p;
+    se.sel_nslice = b->d_sel.p + n;
+    se.slice_cnt = b->d_sel.p + 2 * (size_t)n;
+    se.max_slices = (uint32_t)std::min<uint64_t>(mrk::sel_slice_slots(cand_total, n), 1u << 30);
+    sel_rowid_range(seg, se);
+    // results straight into the batch's pinned host memory (a batch with a standing rows destination feeds a shard merge:
+    // its own lists stay on the device unless mrk_batch_result asks for them)
+    se.q_total = b->d_q_total.p;
+    se.q_flags = b->d_q_flags.p;
+    se.h_flags = b->h_flags.p;
+    se.h_cand_n = b->h_cand_n.p;
+    if (!b->rows_dst) se.h_keys = b->h_keys.p, se.h_cnt = b->h_cnt.p, se.h_total = b->h_total.p;
     launch_select(se, st2);
   } else
     launch_merge(ma, st2);
@@ -1201,16 +1297,10 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   b->last_prox = any_prox;
   b->last_tree = any_tree;
   b->last_ext = any_ext;
-  if (use_packed) {
-    HIP_TRY(hipMemcpyAsync(b->h_flags.p, b->d_q_flags.p, n * 4, hipMemcpyDeviceToHost, st2));
-    HIP_TRY(hipMemcpyAsync(b->h_cand_n.p, b->d_q_cand_n.p, n * 4, hipMemcpyDeviceToHost, st2));
-  }
-
   lap("select launched");
-  // ---- results to pinned host memory (a batch with a standing rows destination feeds a shard merge: its own
-  // lists are only copied if mrk_batch_result asks for them)
+  // ---- results to pinned host memory: the packed path's selection wrote them itself; the VLB path copies
   b->host_copied = b->rows_dst == nullptr;
-  if (b->host_copied) {
+  if (b->host_copied && !use_packed) {
     HIP_TRY(hipMemcpyAsync(b->h_cnt.p, b->d_out_cnt.p, n * 4, hipMemcpyDeviceToHost, st2));
     HIP_TRY(hipMemcpyAsync(b->h_total.p, b->d_q_total.p, n * 8, hipMemcpyDeviceToHost, st2));
     HIP_TRY(hipMemcpyAsync(b->h_keys.p, b->d_out_keys.p, (size_t)n * KCAP * 8, hipMemcpyDeviceToHost, st2));
@@ -1265,7 +1355,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   const size_t n_items = items_pk.size();
   int rc;
   if ((rc = r->h_queries.reserve(passes.size())) || (rc = r->d_queries.reserve(passes.size())) || (rc = r->h_items.reserve(n_items + 1)) ||
-      (rc = r->d_items.reserve(n_items + 1)) || (rc = r->d_cand.reserve(cap + 64)))
+      (rc = r->d_items.reserve(n_items + 1)) || (rc = r->d_cand.reserve(cap + 64)) || (rc = r->d_sel.reserve(2 + mrk::sel_slice_slots(cap, 1))))
     return rc;
   memcpy(r->h_queries.p, passes.data(), passes.size() * sizeof(DevQuery));
   if (n_items) memcpy(r->h_items.p, items_pk.data(), n_items * sizeof(DevItem));
@@ -1328,6 +1418,11 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   se.rowid_base = seg->dev.rowid_base;
   se.out_keys = r->d_out_keys.p;
   se.out_cnt = r->d_out_cnt.p;
+  se.sel_tau = r->d_sel.p;
+  se.sel_nslice = r->d_sel.p + 1;
+  se.slice_cnt = r->d_sel.p + 2;
+  se.max_slices = (uint32_t)std::min<uint64_t>(mrk::sel_slice_slots(cap, 1), 1u << 30);
+  sel_rowid_range(seg, se);
   launch_select(se, st);
   HIP_TRY(hipGetLastError());
   uint32_t flags = 0;
@@ -1351,7 +1446,9 @@ static int mrk_batch_wait_impl(mrk_batch* b) {
   if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_wait: NULL batch");
   if (!b->in_flight) return MRK_OK;
   HIP_TRY(hipSetDevice(b->ctx->device));
+  static const bool wait_timing = getenv("MRK_SUBMIT_TIMING") != nullptr;
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (wait_timing) fprintf(stderr, "mrk wait   %p end   (abs %.3f)\n", (void*)b, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
   b->in_flight = false;
   float ms = 0;
   if (hipEventElapsedTime(&ms, b->ev_scan0, b->ev_scan1) == hipSuccess) b->stats.scan_ms = ms;
@@ -1690,6 +1787,8 @@ extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query*
 extern "C" int mrk_batch_wait(mrk_batch* b) {
   if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_wait: NULL batch");
   mrk_worker* w = b->ctx ? b->ctx->worker : nullptr;
+  static const bool wait_timing = getenv("MRK_SUBMIT_TIMING") != nullptr;
+  if (wait_timing) fprintf(stderr, "mrk wait   %p begin (abs %.3f)\n", (void*)b, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
   if (!w) return mrk_batch_wait_impl(b);
   constexpr int NOT_READY = 1;
   for (;;) {

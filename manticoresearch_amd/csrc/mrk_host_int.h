@@ -31,7 +31,9 @@ struct mrk_ctx {
   int bitmap_inv = 64;            // terms in >= 1/bitmap_inv of the docs also get a bitmap (0 = never)
   int attr_seq = 1;               // keywords with a bitmap also get their tf / field bytes in slot order (what the bitmap kernel gathers from)
   int attr_nibbles = 0;           // also build the one-byte tf/field plane the bitmap kernel can gather from (<= 4 fields)
-  int bm_target_items = 8960;     // two-bitmap AND kernel: work items per launch the window ranges are cut into (never under 256 windows each)
+  int bm_target_items = 1 << 20;  // two-bitmap AND kernel: cap of the work items per launch ...
+  int bm_min_windows = 128;       // ... and the least windows per work item (a wave's fixed costs show on short runs)
+  int pk_min_items = 2048;        // block-scan kernel: a batch with fewer work items has its block ranges cut finer (>= one block per wave)
   int bt_target_items = 6144;     // ... and the tree kernel over bitmap words
   int bt_cover_inv = 32;          // trees whose candidate cover holds >= 1/bt_cover_inv of the docs run on bitmap words (0 = never)
   int gen_lane_hits = 256;        // generic evaluator: hits (16 B) of per-lane list memory, GEN_GRID * 256 lanes

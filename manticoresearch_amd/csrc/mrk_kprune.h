@@ -58,6 +58,29 @@ __device__ __forceinline__ void flush_hist(uint32_t* lh, uint32_t* gh) {
   }
 }
 
+// add the bins of the wave's buffered candidate keys to the query's global histogram: per 64 keys one atomic per DISTINCT
+// bin (candidates crowd around the threshold: a handful of bins), straight to memory -- no LDS histogram to clear, fill and
+// flush, no lock around one
+__device__ __forceinline__ void hist_add_keys(uint32_t* __restrict__ gh, const uint64_t* cbuf, uint32_t cn, uint32_t mode, int32_t lo, uint32_t shift) {
+  const uint32_t lane = lane_id();
+  for (uint32_t i0 = 0; i0 < cn; i0 += 64) {
+    const bool v = i0 + lane < cn;
+    uint32_t bin = 0xFFFFFFFFu;
+    if (v) {
+      const uint64_t key = cbuf[i0 + lane];
+      bin = bin_of(mode, lo, shift, key_weight(key), key_rowid(key));
+    }
+    uint64_t left = __ballot(v);
+    while (left) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(left);
+      const uint32_t b = rdlane(bin, l);
+      const uint64_t same = __ballot(bin == b);
+      if (lane == l) atomicAdd(gh + b, (uint32_t)__popcll(same));
+      left &= ~same;
+    }
+  }
+}
+
 // exact hit count of a doc whose packed tf saturated (>= 255)
 static __device__ uint32_t exc_tf(const DevSegment& seg, const DevTerm& T, uint32_t rowid) {
   const uint64_t* __restrict__ e = seg.pk_exc + T.exc_first;

@@ -33,18 +33,17 @@ constexpr int BM_WORDS = 64; // words per window
 constexpr int BM_BURST = MRK_BM_BURST;
 constexpr int BM_WQCAP = 128; // word queue entries per wave (unpacked in batches of 64)
 
-// (7 workgroups per CU: 4 x (896 + 3072) B of wave queues + 7 KB of tables and publishing scratch)
+// (4 x (896 + 3072) B of wave queues + 3 KB of tables)
 struct __align__(16) BmWaveLds {
   uint64_t cbuf[BM_CBUF];
   // word queue: the windows' non-empty match words wait here until 64 of them can be unpacked with every lane busy
   uint4 wq[BM_WQCAP];  // match word, keyword A's word, keyword B's word, rowid of bit 0
   uint2 wqr[BM_WQCAP]; // ranks of the words' first bits in A and in B
+  uint16_t wpre[BM_WQCAP]; // final drain: matches held by the queue entries before this one (<= 128 x 32)
 };
 
 struct __align__(16) BmSmem {
   BmWaveLds w[WAVES];
-  uint32_t hist[NBINS]; // publishing scratch, one per workgroup behind hist_lock (publishes are rare once pruning bites;
-  uint32_t hist_lock;   // a private 4 KB per wave would cap the occupancy at 5 waves per SIMD)
   uint32_t rank[256];
   float tfidf[2][256];
 };
@@ -72,7 +71,6 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       for (uint32_t f = 0; f < nw; ++f)
         if (tid & (1u << f)) rk += (uint32_t)Q->weights[f];
     s.rank[tid] = rk;
-    if (!tid) s.hist_lock = 0;
   }
   const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
   const int32_t bin_lo = Q->bin_lo;
@@ -114,27 +112,13 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       basep = rdlane(basep, 0);
       const bool fits = basep + cn <= cand_cap;
       const uint32_t npub = cn;
-      if (lane == 0) {
-        uint32_t expected = 0;
-        while (!__hip_atomic_compare_exchange_strong(&s.hist_lock, &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
-          expected = 0;
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
       wave_lds_fence();
-      for (uint32_t i = lane; i < (uint32_t)NBINS; i += 64) s.hist[i] = 0;
+      if (fits)
+        for (uint32_t i = lane; i < cn; i += 64) cand[basep + i] = L.cbuf[i];
+      else if (lane == 0)
+        atomicOr(a.q_flags + oq, QF_OVERFLOW);
+      hist_add_keys(ghist, L.cbuf, cn, bin_mode, bin_lo, bin_shift);
       wave_lds_fence();
-      for (uint32_t i = lane; i < cn; i += 64) {
-        const uint64_t key = L.cbuf[i];
-        if (fits) cand[basep + i] = key;
-        atomicAdd(&s.hist[bin_of(bin_mode, bin_lo, bin_shift, key_weight(key), key_rowid(key))], 1u);
-      }
-      if (!fits && lane == 0) atomicOr(a.q_flags + oq, QF_OVERFLOW);
-      wave_lds_fence();
-      flush_hist(s.hist, ghist);
-      wave_lds_fence();
-      if (lane == 0) __hip_atomic_store(&s.hist_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       cn = 0;
       // only the publisher whose slice crosses a 2048-candidate boundary recomputes the threshold
       if ((basep >> 11) != ((basep + npub) >> 11) || basep == 0) {
@@ -316,7 +300,49 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       }
     }
   }
-  while (wqn) wqn = unpack(0, wqn);
+  // Final drain.  One bit per word per round (unpack) would take as many rounds as the fullest word has bits -- six to eight
+  // gather round trips with a handful of lanes busy at the end of EVERY wave, which is what a wave of a one-eighth shard (64
+  // windows) mostly consisted of.  Here the queue's matches are numbered through (prefix sum of the words' popcounts) and
+  // lane l of round r takes match 64 r + l: its word by binary search, its bit by rank.
+  if (wqn) {
+    wave_lds_fence();
+    const uint32_t e0 = lane, e1 = lane + 64u;
+    const uint32_t c0 = e0 < wqn ? (uint32_t)__popc(L.wq[e0].x) : 0u, c1 = e1 < wqn ? (uint32_t)__popc(L.wq[e1].x) : 0u;
+    const uint32_t i0 = wave_incl_scan(c0), t0 = rdlane(i0, 63);
+    const uint32_t i1 = wave_incl_scan(c1) + t0, nmatch = rdlane(i1, 63);
+    L.wpre[e0] = (uint16_t)(i0 - c0);
+    L.wpre[e1] = (uint16_t)(i1 - c1);
+    wave_lds_fence();
+    for (uint32_t r0 = 0; r0 < nmatch; r0 += 64u) {
+      const uint32_t j = r0 + lane;
+      const bool valid = j < nmatch;
+      uint32_t lo = 0, hi = wqn; // entry = last e with wpre[e] <= j
+      while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (L.wpre[mid] <= j)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      const uint4 we = L.wq[lo];
+      const uint2 wr = L.wqr[lo];
+      uint32_t k = valid ? j - L.wpre[lo] : 0u, m = we.x, bit = 0; // the k-th set bit of m (k < popc(m))
+      uint32_t c = (uint32_t)__popc(m & 0xFFFFu);
+      if (k >= c) k -= c, bit += 16u, m >>= 16;
+      c = (uint32_t)__popc(m & 0xFFu);
+      if (k >= c) k -= c, bit += 8u, m >>= 8;
+      c = (uint32_t)__popc(m & 0xFu);
+      if (k >= c) k -= c, bit += 4u, m >>= 4;
+      c = (uint32_t)__popc(m & 0x3u);
+      if (k >= c) k -= c, bit += 2u, m >>= 2;
+      if (k >= (m & 1u)) bit += 1u;
+      const uint32_t below = (1u << bit) - 1u;
+#if MRK_BMEXP != 2
+      score(valid, we.w + bit, wr.x + (uint32_t)__popc(we.y & below), wr.y + (uint32_t)__popc(we.z & below));
+#endif
+    }
+    wqn = 0;
+  }
 #if MRK_BMEXP != 2
   if (p_any) score(false, 0u, 0u, 0u); // finishes the last round (its own, empty one stays unfinished)
 #endif

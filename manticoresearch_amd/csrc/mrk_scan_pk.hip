@@ -829,65 +829,6 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// select: exact top-K of a query's candidate list, one workgroup per query
-// ---------------------------------------------------------------------------------------
-struct __align__(16) SelSmem {
-  uint64_t cand[CAND];
-  uint32_t wave_cnt[2 * WAVES];
-  uint32_t cand_n;
-  uint32_t tau_bin;
-  uint64_t tau;
-};
-
-__global__ __launch_bounds__(WG) void select_kernel(SelectArgs a) {
-  __shared__ SelSmem s;
-  const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
-  if (q >= a.n_queries) return;
-  const DevQuery* __restrict__ Q = a.queries + q;
-  const uint32_t K = Q->k ? Q->k : 1u;
-  uint32_t n = a.q_cand_n[q];
-  if (n > Q->cand_cap) n = Q->cand_cap;
-  if (tid == 0) {
-    s.cand_n = 0;
-    s.tau = 0;
-  }
-  if (tid < 64) {
-    const uint32_t tb = threshold_bin(a.q_hist + (uint64_t)q * NBINS, K);
-    if (lane == 0) s.tau_bin = tb;
-  }
-  __syncthreads();
-  const uint32_t tau_bin = s.tau_bin;
-  const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
-  const int32_t bin_lo = Q->bin_lo;
-  const uint64_t* __restrict__ src = a.cand + Q->cand_off;
-  for (uint32_t f0 = 0; f0 < n; f0 += 4 * WG) {
-    if (s.cand_n > (uint32_t)(CAND - 4 * WG)) compact_cand(s, K, &s.tau);
-    const uint64_t tau = s.tau;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t f = f0 + r * WG + tid;
-      uint64_t key = 0;
-      bool push = false;
-      if (f < n) {
-        key = src[f];
-        push = key >= tau && bin_of(bin_mode, bin_lo, bin_shift, key_weight(key), key_rowid(key)) >= tau_bin;
-      }
-      const uint64_t bal = __ballot(push);
-      if (bal) {
-        uint32_t basep = 0;
-        if (lane == 0) basep = atomicAdd(&s.cand_n, (uint32_t)__popcll(bal));
-        basep = rdlane(basep, 0);
-        if (push) s.cand[basep + __popcll(bal & ((1ull << lane) - 1ull))] = key;
-      }
-    }
-    __syncthreads();
-  }
-  const uint32_t m = compact_cand(s, K, &s.tau); // sorted best-first
-  for (uint32_t i = tid; i < m; i += WG) a.out_keys[(uint64_t)q * KCAP + i] = s.cand[i];
-  if (tid == 0) a.out_cnt[q] = m;
-}
-
 template <bool PROX, bool TREE, bool EXT = false, int NREF = MAX_PROX_TERMS>
 static void launch_pk(const ScanArgs& a, size_t tail, hipStream_t st) {
   hipLaunchKernelGGL((scan_pk_kernel<PROX, TREE, EXT, NREF>), dim3(a.n_items), dim3(WG), sizeof(PkSmem<PROX, TREE, NREF>) + tail, st, a);
@@ -906,11 +847,6 @@ void launch_scan_pk(const ScanArgs& a, uint32_t max_terms, bool prox, bool tree,
     prox ? launch_pk<true, true>(a, tail, st) : launch_pk<false, true>(a, tail, st);
   else
     prox ? launch_pk<true, false>(a, tail, st) : launch_pk<false, false>(a, tail, st);
-}
-
-void launch_select(const SelectArgs& a, void* stream) {
-  if (!a.n_queries) return;
-  hipLaunchKernelGGL(select_kernel, dim3(a.n_queries), dim3(WG), 0, (hipStream_t)stream, a);
 }
 
 } // namespace mrk

@@ -15,6 +15,7 @@ import manticoresearch_amd as m  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=12_500_000)
 ap.add_argument("--items", default="1024,2048,3072,4096,6144,8192,12288")
+ap.add_argument("--min-windows", default="256", help="comma list: floor of windows per work item (ctx key bm_min_windows)")
 args = ap.parse_args()
 c = bench.zipf_c()
 ranks, strata = bench.make_queries(c, 256)
@@ -24,9 +25,10 @@ kw = m.XQNode.keyword
 qs = [m.Query(m.XQNode.AND(kw(a, 1), kw(b, 2)), ranker=m.SPH_RANK_BM25, max_matches=1000) for a, b in strata["cc"]]
 cq = m.prepare(qs)
 out = {}
-for items in [int(x) for x in args.items.split(",")]:
+for items, minw in [(int(x), int(y)) for y in args.min_windows.split(",") for x in args.items.split(",")]:
     ctx = m.Context(0)
     ctx.set("bm_target_items", items)
+    ctx.set("bm_min_windows", minw)
     seg = m.Segment(ctx, hi)
     b = m.Batch(ctx, len(qs))
     ts = []
@@ -34,8 +36,8 @@ for items in [int(x) for x in args.items.split(",")]:
         b.submit_prepared(seg, cq, len(qs))
         b.wait()
         ts.append(b.stats()["scan_ms"])
-    out[items] = {"scan_ms": round(min(ts[1:]), 4), "n_items": b.stats()["n_items"]}
-    print(items, out[items], flush=True)
+    out[f"{items}/{minw}"] = {"scan_ms": round(min(ts[1:]), 4), "n_items": b.stats()["n_items"], "cands": b.stats()["n_cands"]}
+    print(items, minw, out[f"{items}/{minw}"], flush=True)
     b.close()
     seg.close()
     ctx.close()
