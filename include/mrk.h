@@ -210,8 +210,11 @@ typedef struct {
 const char* mrk_last_error(void);
 
 int mrk_ctx_create(int device, mrk_ctx** out);
-/* destroy a context's segments and batches BEFORE the context: their destructors run on its submission thread */
-void mrk_ctx_destroy(mrk_ctx* ctx);
+/* Destroy a context's segments, batches and batchers BEFORE the context: their destructors run on its submission thread.
+   The context counts them: with any still alive the call destroys nothing and returns MRK_E_INVAL (the message says how many);
+   destroy them and call again.  (Until round 3 this was a comment only: a segment or batch destroyed after its context posted
+   its destructor to a thread that no longer existed and waited forever.) */
+int mrk_ctx_destroy(mrk_ctx* ctx);
 /* tunables: "item_bytes" (work-item size target); "pack" (1 = build packed doclists at segment
    load, default); "path" (0 = packed when present, 1 = VLB-direct, 2 = packed only);
    "bitmap_inv" (keywords found in >= 1/bitmap_inv of a segment's docs also get a doc-set bitmap,
@@ -263,12 +266,40 @@ int mrk_segment_set_blobs(mrk_segment* seg, const uint8_t* pool, uint64_t pool_l
 /* device bytes held, and the reference-format doclist bytes of one term */
 uint64_t mrk_segment_device_bytes(const mrk_segment* seg);
 
+/* ---- the batching front: ONE query per caller, common launches ----------------------------------------------------------
+   searchd runs one ranker per (query x index) on a pool of workers (SearchHandler_c::RunLocalSearches, searchd.cpp:5596-5797);
+   a ranker that submits a batch of one pays a launch chain per query.  A batcher (one per index / context) lets the workers'
+   queries meet: mrk_batcher_search enqueues the caller's query and sleeps (mutex + condition variable: nothing of HIP on the
+   caller's stack) until a driver thread has sent it down -- together with everything else that arrived while the device was
+   busy with the launch before, up to max_batch queries of the same segment per mrk_batch_submit, three launches in flight --
+   and copied its rows into the caller's own buffers (rowid_out / weight_out, cap entries; res->rowid / res->weight point
+   there).  max_wait_us: how long an IDLE device waits for a batch to fill up (0 = launch at once; under load arrivals queue
+   behind the running launch anyway).  A query the planner refuses with MRK_E_INVAL fails alone: the others of its launch are
+   rerun one by one.  Returns MRK_OK with res->status = the query's own status (MRK_E_UNSUPPORTED = keep the CPU ranker). */
+typedef struct mrk_batcher mrk_batcher;
+typedef struct {
+  uint64_t launches;   /* mrk_batch_submit calls */
+  uint64_t queries;    /* queries answered */
+  uint32_t max_batch;  /* most queries one launch carried */
+  double submit_ms;    /* driver thread: time inside mrk_batch_submit, in all */
+  double collect_ms;   /* ... inside mrk_batch_wait + handing the rows out */
+  double flight_ms;    /* sum over launches of submit-return -> found complete */
+} mrk_batcher_stats;
+int mrk_batcher_create(mrk_ctx* ctx, uint32_t max_batch, uint32_t max_wait_us, mrk_batcher** out);
+void mrk_batcher_destroy(mrk_batcher* b);
+int mrk_batcher_search(mrk_batcher* b, mrk_segment* seg, const mrk_query* q, uint32_t* rowid_out, int32_t* weight_out, int32_t cap, mrk_result* res);
+int mrk_batcher_stats_get(mrk_batcher* b, mrk_batcher_stats* out);
+
 int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** out);
 void mrk_batch_destroy(mrk_batch* b);
 /* plan on host, copy descriptors, launch kernels, start the result copy; returns at once */
 int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n_queries);
 /* block until the results of the last submit are in host memory */
 int mrk_batch_wait(mrk_batch* b);
+/* has the device finished the last submit?  MRK_OK = yes (mrk_batch_wait returns without blocking), 1 = not yet.  A stream
+   query on the CALLING thread (no hop to the submission thread: a polling loop must not queue behind other callers'
+   submits): call it from an ordinary thread, not from a coroutine stack. */
+int mrk_batch_test(mrk_batch* b);
 int mrk_batch_result(mrk_batch* b, uint32_t q, mrk_result* out);
 int mrk_batch_stats_get(mrk_batch* b, mrk_batch_stats* out);
 /* device-resident partial top-K of the last submit, for shard merges without a host hop:

@@ -17,7 +17,7 @@ cat > $W/tu.cpp <<'CPP'
 #include "mrk_adapter.h"
 // instantiate what a caller would: the factory and the six ISphRanker methods
 ISphRanker * (*g_fnCreate)( const XQQuery_t &, const CSphQuery &, CSphQueryResultMeta &, const ISphQwordSetup &, const CSphQueryContext &,
-	const ISphSchema &, const VecTraits_T<ISphMatchSorter *> &, DWORD, const MrkIndexBinding_t &, mrk_batch *, CSphString & ) = &MrkCreateRanker;
+	const ISphSchema &, const VecTraits_T<ISphMatchSorter *> &, DWORD, const MrkIndexBinding_t &, mrk_batch *, mrk_batcher *, int, CSphString & ) = &MrkCreateRanker;
 static_assert ( std::is_base_of<ISphRanker, MrkRankerAdapter_c>::value, "MrkRankerAdapter_c is an ISphRanker" );
 static_assert ( !std::is_abstract<MrkRankerAdapter_c>::value, "every pure virtual of ISphRanker is implemented" );
 CPP

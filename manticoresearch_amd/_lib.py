@@ -71,6 +71,11 @@ class BatchStats(C.Structure):
                 ("n_items_bm", C.c_uint64), ("plan_ms", C.c_float), ("submit_ms", C.c_float)]
 
 
+class BatcherStats(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("queries", C.c_uint64), ("max_batch", C.c_uint32), ("submit_ms", C.c_double), ("collect_ms", C.c_double),
+                ("flight_ms", C.c_double)]
+
+
 class IndexInfo(C.Structure):
     """mrk_index_info (include/mrk.h)"""
     _fields_ = [("version", C.c_uint32), ("n_fields", C.c_uint32), ("n_attrs", C.c_uint32),
@@ -100,7 +105,11 @@ class SynthParams(C.Structure):
 SYMBOLS = [
     ("mrk_last_error", C.c_char_p, []),
     ("mrk_ctx_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
-    ("mrk_ctx_destroy", None, [C.c_void_p]),
+    ("mrk_ctx_destroy", C.c_int, [C.c_void_p]),
+    ("mrk_batcher_create", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mrk_batcher_destroy", None, [C.c_void_p]),
+    ("mrk_batcher_search", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Query), C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(Result)]),
+    ("mrk_batcher_stats_get", C.c_int, [C.c_void_p, C.POINTER(BatcherStats)]),
     ("mrk_ctx_set", C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("mrk_segment_create", C.c_int, [C.c_void_p, C.POINTER(SegmentDesc), C.POINTER(C.c_void_p)]),
     ("mrk_segment_validate", C.c_int, [C.POINTER(SegmentDesc)]),
@@ -119,6 +128,7 @@ SYMBOLS = [
     ("mrk_batch_destroy", None, [C.c_void_p]),
     ("mrk_batch_submit", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Query), C.c_uint32]),
     ("mrk_batch_wait", C.c_int, [C.c_void_p]),
+    ("mrk_batch_test", C.c_int, [C.c_void_p]),
     ("mrk_batch_result", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Result)]),
     ("mrk_batch_stats_get", C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     ("mrk_batch_device_results", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

@@ -456,7 +456,8 @@ class Context:
         if self._h:
             for child in list(self._children):
                 child.close()
-            lib().mrk_ctx_destroy(self._h)
+            # (the library refuses while a segment, batch or batcher of the context is alive: MRK_E_INVAL, nothing destroyed)
+            check(lib().mrk_ctx_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -605,6 +606,42 @@ class Batch:
             pass
 
 
+class Batcher:
+    """mrk_batcher: many threads, one query each, common launches (include/mrk.h "the batching front")."""
+
+    def __init__(self, ctx: Context, max_batch: int = 256, max_wait_us: int = 0):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        check(lib().mrk_batcher_create(ctx._h, max_batch, max_wait_us, C.byref(self._h)))
+        ctx._children.add(self)
+
+    def search(self, seg: Segment, query: Query) -> Matches:
+        """Blocks until the query's rows are there; callable from any number of threads (the GIL is released in the call)."""
+        cq = _CQueries([query])
+        cap = max(1, query.max_matches)
+        rowid = np.empty(cap, np.uint32)
+        weight = np.empty(cap, np.int32)
+        r = _lib.Result()
+        check(lib().mrk_batcher_search(self._h, seg._h, cq.arr, rowid.ctypes.data, weight.ctypes.data, cap, C.byref(r)))
+        return Matches(rowid[: r.n].copy(), weight[: r.n].copy(), int(r.total_found), int(r.status))
+
+    def stats(self) -> dict:
+        s = _lib.BatcherStats()
+        check(lib().mrk_batcher_stats_get(self._h, C.byref(s)))
+        return {"launches": int(s.launches), "queries": int(s.queries), "max_batch": int(s.max_batch)}
+
+    def close(self) -> None:
+        if self._h:
+            lib().mrk_batcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def prepare(queries: Sequence[Query]) -> _CQueries:
     return _CQueries(queries)
 
@@ -618,4 +655,4 @@ __all__ = ["open_rt_ram", "SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
            "parse_query", "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE", "SPH_QUERY_NEAR", "SPH_QUERY_NOTNEAR", "SPH_QUERY_SENTENCE", "SPH_QUERY_PARAGRAPH",
            "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Filter", "Matches", "Context",
-           "Segment", "Batch", "prepare", "idf", "MrkError", "validate_index", "pair_stats"]
+           "Segment", "Batch", "Batcher", "prepare", "idf", "MrkError", "validate_index", "pair_stats"]

@@ -179,6 +179,10 @@ __device__ __forceinline__ bool row_is_dead(const DevSegment& seg, uint32_t rowi
 }
 
 constexpr uint32_t PK_WIDE = 0xFFu;
+// A query's candidate counter and its threshold word are the two addresses every wave of the query hits (a returning atomic per
+// publish, a read per few bursts): each sits in a 64-byte line of its own -- sixteen queries' counters in one line made the
+// atomics of DIFFERENT queries serialize on that line
+constexpr int QSTRIDE = 16; // dwords between consecutive queries' entries in ScanArgs::q_cand_n / q_tau_bin
 constexpr int NBINS = 1024; // pruning histogram bins per query
 constexpr uint32_t BIN_WEIGHT = 0, BIN_ROWID = 1;
 constexpr uint32_t PN_TERM = 0, PN_AND = 1, PN_OR = 2, PN_MAYBE = 3, PN_ANDNOT = 4, PN_PHRASEFIX = 5, PN_QUORUM = 6, PN_ORDERFIX = 7, PN_NOTNEAR = 8; // prog[] opcodes
@@ -340,9 +344,9 @@ struct ScanArgs {
   uint32_t n_items;
   // packed path: global pruning histograms + per-query candidate lists
   uint32_t* q_hist;    // [n_queries][NBINS]
-  uint32_t* q_cand_n;  // [n_queries]
+  uint32_t* q_cand_n;  // [n_queries * QSTRIDE]
   uint32_t* q_flags;   // [n_queries]
-  uint32_t* q_tau_bin; // [n_queries] running pruning threshold (bin index), atomicMax
+  uint32_t* q_tau_bin; // [n_queries * QSTRIDE] running pruning threshold (bin index), atomicMax
   uint64_t* cand;      // candidate arena
   MatchQueue mq[3];    // [0] plain boolean trees, [1] queries with PHRASE / PROXIMITY / BEFORE nodes or position modifiers, [2] TF_GEN
   GenArgs gen;

@@ -105,6 +105,9 @@ struct PinBuf {
   }
 };
 
+// per-query scan state in front of the histograms: total u64 | tau u64 | flags u32 | cand_n, tau_bin: QSTRIDE dwords each
+constexpr size_t STATE_BYTES = 8 + 8 + 4 + 2 * 4 * mrk::QSTRIDE;
+
 struct mrk_batch {
   mrk_ctx* ctx = nullptr;
   uint64_t* rows_dst = nullptr; // mrk_batch_set_rows_dst
@@ -262,6 +265,11 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "mq_max_chunks")) {
     if (value < 1 || value > (1 << 24)) return mrk_fail(MRK_E_INVAL, "mq_max_chunks must be 1 .. 2^24");
     c->mq_max_chunks = (int)value;
+    return MRK_OK;
+  }
+  if (!strcmp(key, "item_order")) {
+    if (value < 0 || value > 7) return mrk_fail(MRK_E_INVAL, "item_order is a mask 0 .. 7");
+    c->item_order = (int)value;
     return MRK_OK;
   }
   if (!strcmp(key, "pk_min_items")) {
@@ -824,7 +832,7 @@ static int mrk_batch_create_impl(mrk_ctx* ctx, uint32_t max_queries, mrk_batch**
   if ((rc = b->h_queries.reserve(nq)) || (rc = b->h_list_first.reserve(nq)) || (rc = b->h_list_n.reserve(nq)) ||
       (rc = b->h_kq.reserve(nq)) || (rc = b->h_keys.reserve(nq * KCAP)) || (rc = b->h_cnt.reserve(nq)) ||
       (rc = b->h_total.reserve(nq)) || (rc = b->d_queries.reserve(nq)) ||
-      (rc = b->d_state.reserve(nq * (8 + 8 + 4 + 4 + 4 + (size_t)NBINS * 4))) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
+      (rc = b->d_state.reserve(nq * (STATE_BYTES + (size_t)NBINS * 4))) || (rc = b->d_list_first.reserve(nq)) || (rc = b->d_list_n.reserve(nq)) ||
       (rc = b->d_kq.reserve(nq)) || (rc = b->d_out_keys.reserve(nq * KCAP)) || (rc = b->d_out_cnt.reserve(nq)) ||
       (rc = b->h_flags.reserve(nq)) || (rc = b->h_cand_n.reserve(nq)) || (rc = b->h_decl.reserve(nq)) || (rc = b->d_decl.reserve(nq)) || (rc = b->d_mq_count.reserve(3 * mrk::MQ_SHARDS))) {
     mrk_batch_destroy_impl(b);
@@ -834,10 +842,10 @@ static int mrk_batch_create_impl(mrk_ctx* ctx, uint32_t max_queries, mrk_batch**
     uint8_t* base = b->d_state.p;
     b->d_q_total.p = (uint64_t*)base;
     b->d_q_tau.p = (uint64_t*)(base + nq * 8);
-    b->d_q_cand_n.p = (uint32_t*)(base + nq * 16);
-    b->d_q_flags.p = (uint32_t*)(base + nq * 20);
-    b->d_q_tau_bin.p = (uint32_t*)(base + nq * 24);
-    b->d_q_hist.p = (uint32_t*)(base + nq * 28);
+    b->d_q_flags.p = (uint32_t*)(base + nq * 16);
+    b->d_q_cand_n.p = (uint32_t*)(base + nq * 20);                        // QSTRIDE dwords per query
+    b->d_q_tau_bin.p = (uint32_t*)(base + nq * (20 + 4 * mrk::QSTRIDE));  // QSTRIDE dwords per query
+    b->d_q_hist.p = (uint32_t*)(base + nq * STATE_BYTES);
   }
   hipError_t e1 = hipEventCreate(&b->ev_scan0), e2 = hipEventCreate(&b->ev_scan1), e3 = hipEventCreate(&b->ev_merge1);
   if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
@@ -1063,7 +1071,9 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   }
   // ... and in piece-major order, for the reason given at the window-range items below: concurrent workgroups should belong
   // to different queries (the planner emits a query's items back to back; only the VLB path needs them that way)
-  if (use_packed && items.size() > 1) {
+  // (not for batches whose matches travel through the match queue to the hit pass: config 3 measured 6.6 ms query-major, 7.1 ms
+  // interleaved -- the rank kernel likes a query's chunks in rowid order)
+  if (use_packed && items.size() > 1 && (b->ctx->item_order & 1) && !any_prox) {
     std::vector<DevItem> rr;
     rr.reserve(items.size());
     std::vector<size_t> run_begin, run_end; // runs of items of one pass
@@ -1100,6 +1110,16 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
     // atomics on one address serialize at the memory side (~70 ns each), about 0.1 ms per query whatever the shard size --
     // hidden behind 100 M docs, the whole launch at 12.5 M (12288 work items: 0.85 ms; 4096: 0.39 ms, same bytes).
     const size_t before = items.size();
+    if (!(b->ctx->item_order & (kind == 0 ? 2 : 4)) || (kind == 1 && any_prox)) { // query-major (experiments; trees that feed the match queue)
+      for (const DevItem& whole : items_bm)
+        if (whole.kind == kind)
+          for (uint64_t w = whole.blk_begin; w < whole.blk_end; w += wpi) {
+            DevItem it = whole;
+            it.blk_begin = (uint32_t)w;
+            it.blk_end = (uint32_t)std::min<uint64_t>(whole.blk_end, w + wpi);
+            items.push_back(it);
+          }
+    } else
     for (uint64_t piece = 0;; ++piece) {
       bool any = false;
       for (const DevItem& whole : items_bm) {
@@ -1167,7 +1187,7 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
     pa.dst[1] = (uint32_t*)b->d_items.p, pa.src[1] = (const uint32_t*)b->h_items.p, pa.n4[1] = (uint32_t)(n_items * sizeof(DevItem) / 4);
     // totals, thresholds, counters (+ the pruning histograms of the queries in use)
     pa.zero = (uint32_t*)b->d_state.p;
-    pa.zero_n4 = (uint32_t)(((size_t)b->max_queries * 28 + (use_packed ? (size_t)n * NBINS * 4 : 0)) / 4);
+    pa.zero_n4 = (uint32_t)(((size_t)b->max_queries * STATE_BYTES + (use_packed ? (size_t)n * NBINS * 4 : 0)) / 4);
     launch_prep(pa, st);
   }
   if (!use_packed) { // the VLB path's merge kernel reads per-query list ranges
@@ -1361,7 +1381,7 @@ static int rerun_overflowed(mrk_batch* b, uint32_t qi) {
   if (n_items) memcpy(r->h_items.p, items_pk.data(), n_items * sizeof(DevItem));
   HIP_TRY(hipMemcpyAsync(r->d_queries.p, r->h_queries.p, passes.size() * sizeof(DevQuery), hipMemcpyHostToDevice, st));
   if (n_items) HIP_TRY(hipMemcpyAsync(r->d_items.p, r->h_items.p, n_items * sizeof(DevItem), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(r->d_state.p, 0, (size_t)r->max_queries * 28 + (size_t)NBINS * 4, st));
+  HIP_TRY(hipMemsetAsync(r->d_state.p, 0, (size_t)r->max_queries * STATE_BYTES + (size_t)NBINS * 4, st));
   ScanArgs sa{};
   sa.seg = seg->dev;
   sa.queries = r->d_queries.p;
@@ -1731,10 +1751,18 @@ extern "C" int mrk_ctx_create(int device, mrk_ctx** out) {
   return MRK_OK;
 }
 
-extern "C" void mrk_ctx_destroy(mrk_ctx* c) {
-  if (!c) return;
+extern "C" int mrk_ctx_destroy(mrk_ctx* c) {
+  if (!c) return MRK_OK;
+  // children alive: their destructors would post to a submission thread that is gone and wait forever (the hang of round 2,
+  // gpurun_out/hang_lib.txt: Context.close <- __del__ with a Batch still alive).  Refuse, leave everything as it is.
+  const int ns = c->n_segments.load(), nb = c->n_batches.load();
+  if (ns || nb)
+    return mrk_fail(MRK_E_INVAL, "mrk_ctx_destroy: %d segment(s) and %d batch(es) of this context are still alive; destroy them first", ns, nb);
   mrk_worker* w = c->worker;
-  if (!w) return mrk_ctx_destroy_impl(c);
+  if (!w) {
+    mrk_ctx_destroy_impl(c);
+    return MRK_OK;
+  }
   mrk_ctx boot;
   boot.worker = w;
   (void)on_worker(&boot, [&] {
@@ -1748,16 +1776,22 @@ extern "C" void mrk_ctx_destroy(mrk_ctx* c) {
   w->cv.notify_one();
   w->th.join();
   delete w;
+  return MRK_OK;
 }
 
 extern "C" int mrk_segment_create(mrk_ctx* ctx, const mrk_segment_desc* d, mrk_segment** out) {
-  return on_worker(ctx, [&] { return mrk_segment_create_impl(ctx, d, out); });
+  const int rc = on_worker(ctx, [&] { return mrk_segment_create_impl(ctx, d, out); });
+  if (rc == MRK_OK) ++ctx->n_segments;
+  return rc;
 }
 extern "C" void mrk_segment_destroy(mrk_segment* s) {
-  if (s) (void)on_worker(s->ctx, [&] {
+  if (!s) return;
+  mrk_ctx* ctx = s->ctx;
+  (void)on_worker(ctx, [&] {
     mrk_segment_destroy_impl(s);
     return MRK_OK;
   });
+  if (ctx) --ctx->n_segments;
 }
 extern "C" int mrk_segment_set_dead_rows(mrk_segment* s, const uint32_t* bitmap, uint64_t n_rows) {
   return on_worker(s ? s->ctx : nullptr, [&] { return mrk_segment_set_dead_rows_impl(s, bitmap, n_rows); });
@@ -1769,13 +1803,18 @@ extern "C" int mrk_segment_set_blobs(mrk_segment* s, const uint8_t* pool, uint64
   return on_worker(s ? s->ctx : nullptr, [&] { return mrk_segment_set_blobs_impl(s, pool, len, n_blob, rows, stride, n_rows); });
 }
 extern "C" int mrk_batch_create(mrk_ctx* ctx, uint32_t max_queries, mrk_batch** out) {
-  return on_worker(ctx, [&] { return mrk_batch_create_impl(ctx, max_queries, out); });
+  const int rc = on_worker(ctx, [&] { return mrk_batch_create_impl(ctx, max_queries, out); });
+  if (rc == MRK_OK) ++ctx->n_batches;
+  return rc;
 }
 extern "C" void mrk_batch_destroy(mrk_batch* b) {
-  if (b) (void)on_worker(b->ctx, [&] {
+  if (!b) return;
+  mrk_ctx* ctx = b->ctx;
+  (void)on_worker(ctx, [&] {
     mrk_batch_destroy_impl(b);
     return MRK_OK;
   });
+  --ctx->n_batches;
 }
 extern "C" int mrk_batch_submit(mrk_batch* b, mrk_segment* seg, const mrk_query* queries, uint32_t n) {
   return on_worker(b ? b->ctx : nullptr, [&] { return mrk_batch_submit_impl(b, seg, queries, n); });
@@ -1807,7 +1846,23 @@ extern "C" int mrk_batch_wait(mrk_batch* b) {
   }
 }
 
+extern "C" int mrk_batch_test(mrk_batch* b) {
+  if (!b) return mrk_fail(MRK_E_INVAL, "mrk_batch_test: NULL batch");
+  if (!b->in_flight) return MRK_OK;
+  static thread_local int device_set = -1;
+  if (device_set != b->ctx->device) {
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    device_set = b->ctx->device;
+  }
+  const hipError_t e = hipStreamQuery(b->stream);
+  if (e == hipSuccess) return MRK_OK;
+  if (e == hipErrorNotReady) return 1;
+  return mrk_fail(MRK_E_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
+}
+
 extern "C" int mrk_batch_result(mrk_batch* b, uint32_t q, mrk_result* out) {
+  // results already in host memory: plain reads, no hop to the submission thread (16 callers' rows used to cost 16 hops)
+  if (b && b->host_copied && !b->in_flight) return mrk_batch_result_impl(b, q, out);
   return on_worker(b ? b->ctx : nullptr, [&] { return mrk_batch_result_impl(b, q, out); });
 }
 extern "C" int mrk_batch_export_device(mrk_batch* b, uint64_t* keys_dst, uint32_t* counts_dst, uint64_t* totals_dst) {

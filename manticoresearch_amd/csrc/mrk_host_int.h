@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <vector>
 
 #include "mrk_dev.h"
@@ -18,6 +19,7 @@ struct mrk_worker; // the context's submission thread (mrk_host.cpp)
 struct mrk_comm;   // the context's RCCL communicator for the shard exchange (mrk_comm.cpp)
 
 struct mrk_ctx {
+  std::atomic<int> n_segments{0}, n_batches{0}; // alive through the C-ABI: mrk_ctx_destroy refuses while any is
   mrk_worker* worker = nullptr;
   mrk_comm* comm = nullptr;
   int device = 0;
@@ -34,6 +36,7 @@ struct mrk_ctx {
   int bm_target_items = 1 << 20;  // two-bitmap AND kernel: cap of the work items per launch ...
   int bm_min_windows = 128;       // ... and the least windows per work item (a wave's fixed costs show on short runs)
   int pk_min_items = 2048;        // block-scan kernel: a batch with fewer work items has its block ranges cut finer (>= one block per wave)
+  int item_order = 7;             // work items of different queries interleaved (piece-major): 1 = block scan, 2 = bitmap AND, 4 = bitmap trees; 0 = query-major
   int bt_target_items = 6144;     // ... and the tree kernel over bitmap words
   int bt_cover_inv = 32;          // trees whose candidate cover holds >= 1/bt_cover_inv of the docs run on bitmap words (0 = never)
   int gen_lane_hits = 256;        // generic evaluator: hits (16 B) of per-lane list memory, GEN_GRID * 256 lanes

@@ -215,8 +215,8 @@ __global__ __launch_bounds__(WG) void rank_kernel(ScanArgs a) {
         K = k_, bin_mode = bm_, bin_shift = bs_, bin_lo = (int32_t)bl_, cand_cap = cc_;
         cand = a.cand + co_;
         ghist = a.q_hist + (uint64_t)oq * NBINS;
-        gcount = a.q_cand_n + oq;
-        gtaubin = a.q_tau_bin + oq;
+        gcount = a.q_cand_n + (size_t)oq * QSTRIDE;
+        gtaubin = a.q_tau_bin + (size_t)oq * QSTRIDE;
         tau_bin = 0;
       }
       wave_lds_fence();

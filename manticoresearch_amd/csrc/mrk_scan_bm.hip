@@ -77,8 +77,8 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
   const uint32_t cand_cap = Q->cand_cap;
   uint64_t* __restrict__ cand = a.cand + Q->cand_off;
   uint32_t* __restrict__ ghist = a.q_hist + (uint64_t)oq * NBINS;
-  uint32_t* __restrict__ gcount = a.q_cand_n + oq;
-  uint32_t* __restrict__ gtaubin = a.q_tau_bin + oq;
+  uint32_t* __restrict__ gcount = a.q_cand_n + (size_t)oq * QSTRIDE;
+  uint32_t* __restrict__ gtaubin = a.q_tau_bin + (size_t)oq * QSTRIDE;
   const uint32_t* __restrict__ bmA = a.seg.bm + TA.bm_off;
   const uint32_t* __restrict__ bmB = a.seg.bm + TB.bm_off;
   const uint32_t* __restrict__ dead = a.seg.dead;
@@ -189,7 +189,10 @@ __global__ __launch_bounds__(WG) void scan_bm_kernel(ScanArgs a) {
       if (cn + np > (uint32_t)BM_CBUF) publish();
       if (push) L.cbuf[cn + __popcll(bal & ((1ull << lane) - 1ull))] = key;
       cn += np;
-      if (cn >= (uint32_t)BM_CBUF - 64u) publish();
+      // (a wave that knows no threshold yet publishes its first 16 candidates at once: the sooner the query's histogram holds
+      // K matches the sooner everybody prunes -- a launch whose waves all start together otherwise floods the list with ~100
+      // candidates per wave before the first threshold exists)
+      if (cn >= (tau_bin ? (uint32_t)BM_CBUF - 64u : 16u)) publish();
     }
     } // (the pending round)
     // ... and this round's requests

@@ -113,8 +113,8 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
   const uint32_t cand_cap = Q->cand_cap;
   uint64_t* __restrict__ cand = a.cand + Q->cand_off;
   uint32_t* __restrict__ ghist = a.q_hist + (uint64_t)oq * NBINS;
-  uint32_t* __restrict__ gcount = a.q_cand_n + oq;
-  uint32_t* __restrict__ gtaubin = a.q_tau_bin + oq;
+  uint32_t* __restrict__ gcount = a.q_cand_n + (size_t)oq * QSTRIDE;
+  uint32_t* __restrict__ gtaubin = a.q_tau_bin + (size_t)oq * QSTRIDE;
   const uint32_t* __restrict__ dead = a.seg.dead;
   const uint32_t* __restrict__ attr = a.seg.pk_attr;
 

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(WG) void sel_tau_kernel(SelectArgs a) {
   const DevQuery* __restrict__ Q = a.queries + q;
   const uint32_t K = Q->k ? Q->k : 1u;
   const uint32_t tb = threshold_bin(a.q_hist + (uint64_t)q * NBINS, K);
-  uint32_t n = a.q_cand_n[q];
+  uint32_t n = a.q_cand_n[(size_t)q * QSTRIDE];
   if (n > Q->cand_cap) n = Q->cand_cap;
   if (lane_id() == 0) {
     a.sel_tau[q] = tb;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WG) void sel_filter_kernel(SelectArgs a, uint32_t q
     const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
     const int32_t bin_lo = Q->bin_lo;
     const uint64_t cand_off = Q->cand_off;
-    uint32_t n = a.q_cand_n[q];
+    uint32_t n = a.q_cand_n[(size_t)q * QSTRIDE];
     if (n > Q->cand_cap) n = Q->cand_cap;
     const uint32_t tau_bin = a.sel_tau[q];
     const uint32_t first = j * (uint32_t)SEL_SLICE;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(WG) void sel_sort_kernel(SelectArgs a) {
     if (a.h_cnt) a.h_cnt[q] = m;
     if (a.h_total) a.h_total[q] = a.q_total[q];
     if (a.h_flags) a.h_flags[q] = a.q_flags[q];
-    if (a.h_cand_n) a.h_cand_n[q] = a.q_cand_n[q];
+    if (a.h_cand_n) a.h_cand_n[q] = a.q_cand_n[(size_t)q * QSTRIDE];
   }
 }
 

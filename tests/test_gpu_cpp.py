@@ -64,3 +64,17 @@ def test_shard_exchange_from_a_cpp_host(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "exchange ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_batcher_16_threads_one_query_each(tmp_path):
+    """The batching front (mrk_batcher_*): 16 host threads hand in one query per call; rows equal the plain batch's bit for
+    bit, a malformed / declined query fails alone, mrk_ctx_destroy refuses while a segment / batch / batcher is alive
+    (the round-2 hang), and the threads together reach at least half of the throughput of 256-query batches."""
+    exe = str(tmp_path / "test_batcher")
+    lib = os.path.join(ROOT, "manticoresearch_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "test_batcher.cpp"), "-o", exe,
+                           "-L" + lib, "-lmrk", "-lpthread", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe, "60000000", "16", "64"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "batcher ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+    ratio = float(out.stdout.split("ratio ")[1].split(",")[0])
+    assert ratio >= 0.5, out.stdout
