@@ -370,6 +370,23 @@ void mrk_comm_destroy(mrk_ctx* ctx); /* also done by mrk_ctx_destroy */
 int mrk_comm_allreduce_i64(mrk_ctx* ctx, int64_t* values, uint64_t n);
 int mrk_shard_exchange(mrk_ctx* ctx, mrk_batch* batch, const uint64_t* rows, uint32_t n_queries, uint32_t k, uint64_t* out_rows,
                        uint32_t slot);
+/* The exchange is PARTITIONED BY QUERY (round 3; ctx key "exchange_part", default 1; needs ncclSend / ncclRecv in the loaded
+   RCCL, <= 8 ranks -- else the all-gather form, where every rank receives and merges everything): rank r owns the queries
+   mrk_shard_slice(n_queries, n_ranks, r) = [first, first + count), per = ceil(n_queries / n_ranks) each.  Every rank sends each
+   owner its rows of the owner's queries (one grouped all-to-all of row slices), merges its own slice and writes
+   out_rows[first .. first + count) -- the other rows of out_rows are not touched.  Bytes into a GPU and merge work per GPU are
+   1 / n_ranks of the all-gather form's.  "Some shard flagged a row" (MRK_ROW_RERUN / MRK_ROW_DECLINED) is no longer visible in
+   every rank's rows: two dwords -- any row flagged RERUN / DECLINED, on any rank -- travel through one small all-reduce behind
+   the merge; mrk_shard_flags reads them after mrk_merge_wait (every rank sees the same values and takes the same repair path).
+   mrk_shard_partitioned: 1 if mrk_shard_exchange on this context partitions. */
+int mrk_shard_slice(uint32_t n_queries, int n_ranks, int rank, uint32_t* first, uint32_t* count);
+int mrk_shard_flags(mrk_ctx* ctx, uint32_t slot, uint32_t* rerun_any, uint32_t* declined_any);
+int mrk_shard_partitioned(mrk_ctx* ctx);
+/* what a rank of the partitioned exchange does with its receive buffer, callable on its own (tests; a host with its own
+   transport): rows_recv[n_lists][list_stride][MRK_ROW_WORDS] (device), the rank's `count` queries -> out_rows[first + q].
+   n_lists <= 8.  Synchronous. */
+int mrk_topk_merge_rows_part(mrk_ctx* ctx, const uint64_t* rows_recv, uint32_t n_lists, uint32_t list_stride, uint32_t first, uint32_t count,
+                             uint32_t k, uint64_t* out_rows);
 
 /* merge n_lists sorted partial top-K lists per query (device pointers):
    in_keys[(l*n_queries + q)*MRK_MAX_K + i], in_counts[l*n_queries + q] -> out_keys[q*MRK_MAX_K + i],

@@ -139,6 +139,10 @@ SYMBOLS = [
     ("mrk_comm_destroy", None, [C.c_void_p]),
     ("mrk_comm_allreduce_i64", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("mrk_shard_exchange", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]),
+    ("mrk_shard_slice", C.c_int, [C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("mrk_shard_flags", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("mrk_shard_partitioned", C.c_int, [C.c_void_p]),
+    ("mrk_topk_merge_rows_part", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("mrk_idf", C.c_float, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]),
     ("mrk_index_from_hits", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("mrk_synth_generate", C.c_int, [C.POINTER(SynthParams), C.POINTER(C.c_void_p)]),

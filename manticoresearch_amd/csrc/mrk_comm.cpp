@@ -26,6 +26,10 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -44,6 +48,10 @@ RcclApi* rccl() {
       *(void**)&api.AllGather = dlsym(api.lib, "ncclAllGather");
       *(void**)&api.AllReduce = dlsym(api.lib, "ncclAllReduce");
       *(void**)&api.GetErrorString = dlsym(api.lib, "ncclGetErrorString");
+      *(void**)&api.Send = dlsym(api.lib, "ncclSend"); // (the partitioned exchange; without them the all-gather form remains)
+      *(void**)&api.Recv = dlsym(api.lib, "ncclRecv");
+      *(void**)&api.GroupStart = dlsym(api.lib, "ncclGroupStart");
+      *(void**)&api.GroupEnd = dlsym(api.lib, "ncclGroupEnd");
       if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce || !api.GetErrorString) api.lib = nullptr;
     }
   }
@@ -61,6 +69,10 @@ struct mrk_comm {
   size_t rows_all_bytes[MRK_MERGE_SLOTS] = {};
   void* scratch = nullptr; // all-reduce staging
   size_t scratch_bytes = 0;
+  // the partitioned exchange: per slot two dwords (any merged row flagged RERUN / DECLINED, maximum over the ranks), device + pinned host
+  uint32_t* flags_dev = nullptr;
+  uint32_t* flags_host = nullptr;
+  hipEvent_t merged[MRK_MERGE_SLOTS] = {};
 };
 
 #define HIP_TRY(expr)                                                                          \
@@ -123,6 +135,10 @@ void mrk_comm_destroy_impl(mrk_ctx* ctx) {
     if (c->gathered[i]) (void)hipEventDestroy(c->gathered[i]);
   }
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->flags_dev) (void)hipFree(c->flags_dev);
+  if (c->flags_host) (void)hipHostFree(c->flags_host);
+  for (int i = 0; i < MRK_MERGE_SLOTS; ++i)
+    if (c->merged[i]) (void)hipEventDestroy(c->merged[i]);
   if (c->rows_ready) (void)hipEventDestroy(c->rows_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -169,6 +185,8 @@ int mrk_comm_exchange_impl(mrk_ctx* ctx, const uint64_t* rows, uint32_t n_querie
     HIP_TRY(hipMalloc(&c->rows_all[slot], need));
     c->rows_all_bytes[slot] = need;
   }
+  // (a slot that is reused before mrk_merge_wait: its previous merge still reads rows_all[slot])
+  if (ctx->merge_used[slot] && ctx->merge_done[slot]) HIP_TRY(hipStreamWaitEvent(c->stream, ctx->merge_done[slot], 0));
   if (after) HIP_TRY(hipStreamWaitEvent(c->stream, after, 0));
   RCCL_TRY(api, api->AllGather(rows, c->rows_all[slot], (size_t)n_queries * MRK_ROW_WORDS, ncclUint64, c->comm, c->stream));
   HIP_TRY(hipEventRecord(c->gathered[slot], c->stream));
@@ -177,5 +195,103 @@ int mrk_comm_exchange_impl(mrk_ctx* ctx, const uint64_t* rows, uint32_t n_querie
   return MRK_OK;
 }
 
+// ---- the exchange partitioned by QUERY -------------------------------------------------------------------------------------
+// The all-gather form above hands every rank every shard's rows of every query and every rank merges all of them: N times
+// the bytes into each GPU, N times the merge work, for N identical copies of the answer.  Here rank r owns the queries
+// [r * per, r * per + count), per = ceil(Q / N): every rank sends each owner its rows of the owner's queries (grouped ncclSend /
+// ncclRecv: an all-to-all of row slices), merges its own Q / N queries and writes that slice of the merged rows.  Bytes into a
+// GPU and merge work per GPU drop by N.  What used to be visible in every rank's merged rows -- "some shard flagged a row: all
+// ranks must rerun / report" -- travels as two dwords through one small all-reduce (max) behind the merge.
+void mrk_shard_slice_impl(uint32_t n_queries, int n_ranks, int rank, uint32_t* per_out, uint32_t* first_out, uint32_t* count_out) {
+  const uint32_t n = n_ranks > 0 ? (uint32_t)n_ranks : 1u, per = (n_queries + n - 1) / n;
+  const uint64_t first = (uint64_t)per * (uint32_t)rank;
+  const uint32_t f = first < n_queries ? (uint32_t)first : n_queries;
+  const uint32_t cnt = n_queries - f < per ? n_queries - f : per;
+  if (per_out) *per_out = per;
+  if (first_out) *first_out = f;
+  if (count_out) *count_out = cnt;
+}
+
+bool mrk_comm_can_partition(mrk_ctx* ctx) {
+  RcclApi* api = rccl();
+  return ctx->comm && api && api->Send && api->Recv && api->GroupStart && api->GroupEnd;
+}
+
+// rows -> (all-to-all of row slices) -> recv [n_ranks][per][MRK_ROW_WORDS] of this rank's queries; ordered behind `after`
+int mrk_comm_exchange_part_impl(mrk_ctx* ctx, const uint64_t* rows, uint32_t n_queries, hipEvent_t after, uint32_t slot, const uint64_t** recv_out,
+                                hipEvent_t* gathered_event_out, uint32_t* per_out, uint32_t* first_out, uint32_t* count_out) {
+  mrk_comm* c = ctx->comm;
+  if (!c) return mrk_fail(MRK_E_INVAL, "mrk_shard_exchange: no communicator (mrk_comm_init)");
+  RcclApi* api = rccl();
+  HIP_TRY(hipSetDevice(ctx->device));
+  uint32_t per, first, count;
+  mrk_shard_slice_impl(n_queries, c->n_ranks, c->rank, &per, &first, &count);
+  const size_t need = (size_t)c->n_ranks * per * MRK_ROW_WORDS * 8;
+  if (c->rows_all_bytes[slot] < need) {
+    if (c->rows_all[slot]) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->merge_stream));
+      (void)hipFree(c->rows_all[slot]);
+    }
+    c->rows_all[slot] = nullptr, c->rows_all_bytes[slot] = 0;
+    HIP_TRY(hipMalloc(&c->rows_all[slot], need ? need : 8));
+    c->rows_all_bytes[slot] = need;
+  }
+  // a slot that is reused: its previous merge still reads the receive buffer
+  if (ctx->merge_used[slot] && ctx->merge_done[slot]) HIP_TRY(hipStreamWaitEvent(c->stream, ctx->merge_done[slot], 0));
+  if (after) HIP_TRY(hipStreamWaitEvent(c->stream, after, 0));
+  uint64_t* recv = (uint64_t*)c->rows_all[slot];
+  RCCL_TRY(api, api->GroupStart());
+  for (int p = 0; p < c->n_ranks; ++p) {
+    uint32_t pf, pc;
+    mrk_shard_slice_impl(n_queries, c->n_ranks, p, nullptr, &pf, &pc);
+    if (pc) RCCL_TRY(api, api->Send(rows + (size_t)pf * MRK_ROW_WORDS, (size_t)pc * MRK_ROW_WORDS, ncclUint64, p, c->comm, c->stream));
+    if (count) RCCL_TRY(api, api->Recv(recv + (size_t)p * per * MRK_ROW_WORDS, (size_t)count * MRK_ROW_WORDS, ncclUint64, p, c->comm, c->stream));
+  }
+  RCCL_TRY(api, api->GroupEnd());
+  HIP_TRY(hipEventRecord(c->gathered[slot], c->stream));
+  *recv_out = recv;
+  *gathered_event_out = c->gathered[slot];
+  *per_out = per, *first_out = first, *count_out = count;
+  return MRK_OK;
+}
+
+// the two flag dwords of `slot`: cleared on the merge stream in front of the merge (flags_dev_out), and -- mrk_comm_flags_finish,
+// behind the merge -- maximum over the ranks, copied to pinned host memory, the slot's completion event recorded behind it all
+int mrk_comm_flags_begin(mrk_ctx* ctx, uint32_t slot, uint32_t** flags_dev_out) {
+  mrk_comm* c = ctx->comm;
+  if (!c->flags_dev) {
+    HIP_TRY(hipMalloc((void**)&c->flags_dev, MRK_MERGE_SLOTS * 2 * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void**)&c->flags_host, MRK_MERGE_SLOTS * 2 * sizeof(uint32_t), hipHostMallocDefault));
+    memset(c->flags_host, 0, MRK_MERGE_SLOTS * 2 * sizeof(uint32_t));
+    for (int i = 0; i < MRK_MERGE_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&c->merged[i], hipEventDisableTiming));
+  }
+  HIP_TRY(hipMemsetAsync(c->flags_dev + 2 * slot, 0, 2 * sizeof(uint32_t), ctx->merge_stream));
+  *flags_dev_out = c->flags_dev + 2 * slot;
+  return MRK_OK;
+}
+
+int mrk_comm_flags_finish(mrk_ctx* ctx, uint32_t slot) {
+  mrk_comm* c = ctx->comm;
+  RcclApi* api = rccl();
+  HIP_TRY(hipEventRecord(c->merged[slot], ctx->merge_stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->merged[slot], 0));
+  if (c->n_ranks > 1) RCCL_TRY(api, api->AllReduce(c->flags_dev + 2 * slot, c->flags_dev + 2 * slot, 2, ncclUint32, ncclMax, c->comm, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->flags_host + 2 * slot, c->flags_dev + 2 * slot, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  if (!ctx->merge_done[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->merge_done[slot], hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ctx->merge_done[slot], c->stream)); // behind the merge (the stream waited for it), the all-reduce and the copy
+  ctx->merge_used[slot] = true;
+  return MRK_OK;
+}
+
+int mrk_comm_flags_read(mrk_ctx* ctx, uint32_t slot, uint32_t* rerun_any, uint32_t* declined_any) {
+  mrk_comm* c = ctx->comm;
+  if (!c || !c->flags_host) return mrk_fail(MRK_E_INVAL, "mrk_shard_flags: no partitioned exchange has run on this context");
+  if (rerun_any) *rerun_any = c->flags_host[2 * slot];
+  if (declined_any) *declined_any = c->flags_host[2 * slot + 1];
+  return MRK_OK;
+}
+
 int mrk_comm_ranks(const mrk_ctx* ctx) { return ctx->comm ? ctx->comm->n_ranks : 0; }
+int mrk_comm_rank(const mrk_ctx* ctx) { return ctx->comm ? ctx->comm->rank : 0; }
 hipEvent_t mrk_comm_rows_ready_event(mrk_ctx* ctx) { return ctx->comm ? ctx->comm->rows_ready : nullptr; }

@@ -418,6 +418,20 @@ struct MergeArgs {
   const uint64_t* in_rows;
   uint64_t* out_rows;
 };
+// Merge of the shards' result rows, up to 8 lists per query (mrk_select.hip): every list arrives sorted, so the lists are merged
+// pairwise by bitonic MERGES in LDS (top-K of two sorted K-lists = elementwise max of one against the other reversed, then ten
+// half-cleaner stages) -- three rounds for eight shards instead of sorting 8 K keys from scratch.
+struct MergeRowsArgs {
+  const uint64_t* in_rows; // list l of query q: in_rows[(l * list_stride + q) * ROW_WORDS]
+  uint32_t n_lists;        // <= 8
+  uint32_t list_stride;    // rows between consecutive lists (>= n_queries: a rank's receive buffer is sized for the largest slice)
+  uint32_t n_queries;
+  uint32_t k;
+  uint64_t* out_rows;      // merged row of query q -> out_rows[(out_first + q) * ROW_WORDS] (device or pinned host memory)
+  uint32_t out_first;
+  uint32_t* flags_any;     // device dword pair or NULL: [0] = 1 if any merged row carries MRK_ROW_RERUN, [1] = ... MRK_ROW_DECLINED
+};
+void launch_merge_rows(const MergeRowsArgs& a, void* stream);
 constexpr int ROW_WORDS = MRK_ROW_WORDS;
 constexpr uint64_t ROW_RERUN = MRK_ROW_RERUN, ROW_DECLINED = MRK_ROW_DECLINED, ROW_FLAG_MASK = MRK_ROW_RERUN | MRK_ROW_DECLINED;
 

@@ -267,6 +267,10 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
     c->mq_max_chunks = (int)value;
     return MRK_OK;
   }
+  if (!strcmp(key, "exchange_part")) {
+    c->exchange_part = value != 0;
+    return MRK_OK;
+  }
   if (!strcmp(key, "item_order")) {
     if (value < 0 || value > 7) return mrk_fail(MRK_E_INVAL, "item_order is a mask 0 .. 7");
     c->item_order = (int)value;
@@ -1586,18 +1590,45 @@ static int mrk_batch_export_rows_impl(mrk_batch* b, uint64_t* rows_dst) {
   return MRK_OK;
 }
 
+// rows of n_lists shards -> merged rows; lists [l][list_stride][ROW_WORDS], queries [0, n_queries) of each, out rows at out_first + q
+static void launch_rows_merge(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t list_stride, uint32_t n_queries, uint32_t k,
+                              uint64_t* out_rows, uint32_t out_first, uint32_t* flags_any) {
+  if (n_lists <= 8) {
+    mrk::MergeRowsArgs mr{};
+    mr.in_rows = rows_all, mr.n_lists = n_lists, mr.list_stride = list_stride, mr.n_queries = n_queries, mr.k = k;
+    mr.out_rows = out_rows, mr.out_first = out_first, mr.flags_any = flags_any;
+    launch_merge_rows(mr, ctx->merge_stream);
+    return;
+  }
+  MergeArgs ma{}; // many lists (one GPU serving many segments): the general kernel; same layout only when the stride is the query count
+  ma.in_rows = rows_all;
+  ma.out_rows = out_rows + (size_t)out_first * ROW_WORDS;
+  ma.n_lists = n_lists;
+  ma.n_queries = n_queries;
+  ma.k = k;
+  launch_merge(ma, ctx->merge_stream);
+}
+
 static int mrk_topk_merge_rows_impl(mrk_ctx* ctx, const uint64_t* rows_all, uint32_t n_lists, uint32_t n_queries, uint32_t k,
                                    uint64_t* out_rows) {
   if (!ctx || !rows_all || !out_rows) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows: NULL argument");
   if (k == 0 || k > MRK_MAX_K) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows: k %u outside 1..%d", k, MRK_MAX_K);
   HIP_TRY(hipSetDevice(ctx->device));
-  MergeArgs ma{};
-  ma.in_rows = rows_all;
-  ma.out_rows = out_rows;
-  ma.n_lists = n_lists;
-  ma.n_queries = n_queries;
-  ma.k = k;
-  launch_merge(ma, ctx->merge_stream);
+  launch_rows_merge(ctx, rows_all, n_lists, n_queries, n_queries, k, out_rows, 0, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->merge_stream));
+  return MRK_OK;
+}
+
+// what a rank of the query-partitioned exchange does with its receive buffer: lists [n_lists][list_stride] rows, the rank's
+// `count` queries, merged rows written at out_rows[first + q]
+static int mrk_topk_merge_rows_part_impl(mrk_ctx* ctx, const uint64_t* rows_recv, uint32_t n_lists, uint32_t list_stride, uint32_t first,
+                                        uint32_t count, uint32_t k, uint64_t* out_rows) {
+  if (!ctx || !rows_recv || !out_rows) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows_part: NULL argument");
+  if (k == 0 || k > MRK_MAX_K) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows_part: k %u outside 1..%d", k, MRK_MAX_K);
+  if (n_lists == 0 || n_lists > 8 || count > list_stride) return mrk_fail(MRK_E_INVAL, "mrk_topk_merge_rows_part: %u lists (1..8), %u queries of stride %u", n_lists, count, list_stride);
+  HIP_TRY(hipSetDevice(ctx->device));
+  launch_rows_merge(ctx, rows_recv, n_lists, list_stride, count, k, out_rows, first, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->merge_stream));
   return MRK_OK;
@@ -1611,13 +1642,7 @@ static int mrk_topk_merge_rows_async_impl(mrk_ctx* ctx, const uint64_t* rows_all
   HIP_TRY(hipSetDevice(ctx->device));
   if (!ctx->merge_done[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->merge_done[slot], hipEventDisableTiming));
   if (wait_event) HIP_TRY(hipStreamWaitEvent(ctx->merge_stream, (hipEvent_t)wait_event, 0));
-  MergeArgs ma{};
-  ma.in_rows = rows_all;
-  ma.out_rows = out_rows;
-  ma.n_lists = n_lists;
-  ma.n_queries = n_queries;
-  ma.k = k;
-  launch_merge(ma, ctx->merge_stream);
+  launch_rows_merge(ctx, rows_all, n_lists, n_queries, n_queries, k, out_rows, 0, nullptr);
   HIP_TRY(hipGetLastError());
 
   HIP_TRY(hipEventRecord(ctx->merge_done[slot], ctx->merge_stream));
@@ -1881,6 +1906,10 @@ extern "C" int mrk_topk_merge_rows_async(mrk_ctx* ctx, const uint64_t* rows_all,
                                          uint64_t* out_rows, void* wait_event, uint32_t slot) {
   return on_worker(ctx, [&] { return mrk_topk_merge_rows_async_impl(ctx, rows_all, n_lists, n_queries, k, out_rows, wait_event, slot); });
 }
+extern "C" int mrk_topk_merge_rows_part(mrk_ctx* ctx, const uint64_t* rows_recv, uint32_t n_lists, uint32_t list_stride, uint32_t first, uint32_t count,
+                                        uint32_t k, uint64_t* out_rows) {
+  return on_worker(ctx, [&] { return mrk_topk_merge_rows_part_impl(ctx, rows_recv, n_lists, list_stride, first, count, k, out_rows); });
+}
 extern "C" int mrk_merge_wait(mrk_ctx* ctx, uint32_t slot) {
   return on_worker(ctx, [&] { return mrk_merge_wait_impl(ctx, slot); });
 }
@@ -1924,8 +1953,31 @@ extern "C" int mrk_shard_exchange(mrk_ctx* ctx, mrk_batch* batch, const uint64_t
     }
     const uint64_t* rows_all = nullptr;
     hipEvent_t gathered = nullptr;
+    if (ctx->exchange_part && mrk_comm_can_partition(ctx) && mrk_comm_ranks(ctx) <= 8) {
+      // partitioned by query: this rank receives and merges its slice only (mrk_comm.cpp)
+      uint32_t per = 0, first = 0, count = 0;
+      int rc = mrk_comm_exchange_part_impl(ctx, rows, n_queries, after, slot, &rows_all, &gathered, &per, &first, &count);
+      if (rc != MRK_OK) return rc;
+      if (k == 0 || k > MRK_MAX_K) return mrk_fail(MRK_E_INVAL, "mrk_shard_exchange: k %u outside 1..%d", k, MRK_MAX_K);
+      uint32_t* flags_dev = nullptr;
+      HIP_TRY(hipStreamWaitEvent(ctx->merge_stream, gathered, 0));
+      if ((rc = mrk_comm_flags_begin(ctx, slot, &flags_dev))) return rc;
+      if (count) launch_rows_merge(ctx, rows_all, (uint32_t)mrk_comm_ranks(ctx), per, count, k, out_rows, first, flags_dev);
+      HIP_TRY(hipGetLastError());
+      return mrk_comm_flags_finish(ctx, slot);
+    }
     int rc = mrk_comm_exchange_impl(ctx, rows, n_queries, after, slot, &rows_all, &gathered);
     if (rc != MRK_OK) return rc;
     return mrk_topk_merge_rows_async_impl(ctx, rows_all, (uint32_t)mrk_comm_ranks(ctx), n_queries, k, out_rows, (void*)gathered, slot);
   });
 }
+extern "C" int mrk_shard_slice(uint32_t n_queries, int n_ranks, int rank, uint32_t* first, uint32_t* count) {
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return mrk_fail(MRK_E_INVAL, "mrk_shard_slice: rank %d of %d", rank, n_ranks);
+  mrk_shard_slice_impl(n_queries, n_ranks, rank, nullptr, first, count);
+  return MRK_OK;
+}
+extern "C" int mrk_shard_flags(mrk_ctx* ctx, uint32_t slot, uint32_t* rerun_any, uint32_t* declined_any) {
+  if (!ctx || slot >= MRK_MERGE_SLOTS) return mrk_fail(MRK_E_INVAL, "mrk_shard_flags: bad argument");
+  return mrk_comm_flags_read(ctx, slot, rerun_any, declined_any);
+}
+extern "C" int mrk_shard_partitioned(mrk_ctx* ctx) { return ctx && ctx->exchange_part && mrk_comm_can_partition(ctx) && mrk_comm_ranks(ctx) <= 8 ? 1 : 0; }

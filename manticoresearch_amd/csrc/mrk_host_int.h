@@ -36,6 +36,7 @@ struct mrk_ctx {
   int bm_target_items = 1 << 20;  // two-bitmap AND kernel: cap of the work items per launch ...
   int bm_min_windows = 128;       // ... and the least windows per work item (a wave's fixed costs show on short runs)
   int pk_min_items = 2048;        // block-scan kernel: a batch with fewer work items has its block ranges cut finer (>= one block per wave)
+  int exchange_part = 1;          // mrk_shard_exchange partitions the merge by query (all-to-all of row slices); 0 = all-gather, every rank merges everything
   int item_order = 7;             // work items of different queries interleaved (piece-major): 1 = block scan, 2 = bitmap AND, 4 = bitmap trees; 0 = query-major
   int bt_target_items = 6144;     // ... and the tree kernel over bitmap words
   int bt_cover_inv = 32;          // trees whose candidate cover holds >= 1/bt_cover_inv of the docs run on bitmap words (0 = never)
@@ -93,6 +94,14 @@ int mrk_comm_allreduce_i64_impl(mrk_ctx* ctx, int64_t* values, uint64_t n);
 int mrk_comm_exchange_impl(mrk_ctx* ctx, const uint64_t* rows, uint32_t n_queries, hipEvent_t after, uint32_t slot, const uint64_t** rows_all_out,
                            hipEvent_t* gathered_event_out);
 int mrk_comm_ranks(const mrk_ctx* ctx);
+int mrk_comm_rank(const mrk_ctx* ctx);
+void mrk_shard_slice_impl(uint32_t n_queries, int n_ranks, int rank, uint32_t* per_out, uint32_t* first_out, uint32_t* count_out);
+bool mrk_comm_can_partition(mrk_ctx* ctx);
+int mrk_comm_exchange_part_impl(mrk_ctx* ctx, const uint64_t* rows, uint32_t n_queries, hipEvent_t after, uint32_t slot, const uint64_t** recv_out,
+                                hipEvent_t* gathered_event_out, uint32_t* per_out, uint32_t* first_out, uint32_t* count_out);
+int mrk_comm_flags_begin(mrk_ctx* ctx, uint32_t slot, uint32_t** flags_dev_out);
+int mrk_comm_flags_finish(mrk_ctx* ctx, uint32_t slot);
+int mrk_comm_flags_read(mrk_ctx* ctx, uint32_t slot, uint32_t* rerun_any, uint32_t* declined_any);
 hipEvent_t mrk_comm_rows_ready_event(mrk_ctx* ctx);
 
 namespace mrk {

@@ -715,16 +715,28 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   // The specialised paths first; a shape they decline goes to the generic per-doc evaluator (mrk_keval.h) when the segment
   // has what it reads (packed doclists + hit references), else the decline stands.
   PlanTree T;
-  GenBuild G;
+  GenBuild* Gp = nullptr; // (built only for the shapes that go to the generic evaluator: 0.8 KB to clear)
+  struct GenHolder {
+    alignas(GenBuild) unsigned char raw[sizeof(GenBuild)];
+    bool live = false;
+    ~GenHolder() {
+      if (live) reinterpret_cast<GenBuild*>(raw)->~GenBuild();
+    }
+  } gen_holder;
   int root = -1;
   bool single_word = false, pure_and = false, prox = false;
   uint32_t ranker = 0;
   int n = 0;
+  bool T_used = false;
   auto shape = [&](bool gen) -> int {
-    T = PlanTree();
+    if (T_used) T = PlanTree(); // (the first call finds it fresh)
+    T_used = true;
     int tree_err = MRK_OK;
     if (gen) {
-      G = GenBuild();
+      if (gen_holder.live) reinterpret_cast<GenBuild*>(gen_holder.raw)->~GenBuild();
+      Gp = new (gen_holder.raw) GenBuild();
+      gen_holder.live = true;
+      GenBuild& G = *Gp;
       root = build_gen(seg, q, q.root, T, G, qi, 0, tree_err);
       if (root >= 0 && G.overflow) return mrk_fail(MRK_E_UNSUPPORTED, "query %u: tree too large for the device path", qi);
       if (root >= 0) {
@@ -1035,7 +1047,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
       }
       if (ranker == MRK_RANK_FIELDMASK) rmin = 0, rmax = (1ll << nwf) - 1;
     } else
-      for (uint32_t m = 0; m < 256; ++m) {
+      for (uint32_t m = 0; m < (1u << nwf); ++m) { // (every mask of the segment's fields; bits beyond them change nothing)
         int64_t r = 0;
         if (!m)
           r = 1;
@@ -1149,7 +1161,9 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     }
   }
 
-  const DevQuery base = dq;
+  DevQuery base_copy; // (1.3 KB: only copied when the query runs as several passes)
+  if (cover.size() > 1) base_copy = dq;
+  const DevQuery& base = base_copy;
   for (size_t p = 0; p < cover.size(); ++p) {
     DevQuery* P = &dq;
     uint32_t pass_index = qi;
@@ -1183,7 +1197,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     P->req_mask = P->excl_mask = 0;
     P->tree_flags = (T.phrase ? TF_PHRASE : pure_and ? TF_MULTIAND : T.ph_leaf ? TF_PHRASE_LEAF : 0) | (got_dupes ? TF_DUPES : 0) | (T.termpos ? TF_TERMPOS : 0) | (T.order ? TF_ORDER : 0) | (T.notnear ? TF_NOTNEAR : 0) | (T.gen ? TF_GEN : 0) | (T.gen_nearn ? TF_GEN_NEARN : 0);
     if (T.gen) { // the evaluator's program, keyword slots as this pass orders them
-      GenProg gp = G.prog;
+      GenProg gp = Gp->prog;
       for (uint32_t i = 0; i < gp.n_nodes; ++i) {
         GenNode& g = gp.nodes[i];
         if (g.kind == GN_TERM) g.kid[0] = (uint8_t)slot[g.kid[0]];

@@ -321,6 +321,75 @@ __global__ __launch_bounds__(WG) void prep_kernel(PrepArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// merge of <= 8 sorted result rows per query (the shard exchange's merge step; CSphMatchQueue::MoveTo across chunks,
+// sphinxsort.cpp:681-710): one workgroup per query, all lists in LDS
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void merge_rows_kernel(MergeRowsArgs a, uint32_t P) { // P = power of two >= n_lists
+  extern __shared__ uint64_t mk[]; // [P][KCAP]
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  if (q >= a.n_queries) return;
+  uint64_t total = 0, flags = 0, have = 0;
+  for (uint32_t l = 0; l < P; ++l) {
+    uint32_t cnt = 0;
+    const uint64_t* __restrict__ row = nullptr;
+    if (l < a.n_lists) {
+      row = a.in_rows + ((uint64_t)l * a.list_stride + q) * ROW_WORDS;
+      cnt = (uint32_t)row[KCAP];
+      if (cnt > (uint32_t)KCAP) cnt = KCAP;
+      const uint64_t t = row[KCAP + 1];
+      total += t & ~ROW_FLAG_MASK, flags |= t & ROW_FLAG_MASK, have += cnt;
+    }
+    for (uint32_t i = tid; i < (uint32_t)KCAP; i += WG) mk[l * KCAP + i] = i < cnt ? row[i] : 0ull;
+  }
+  __syncthreads();
+  for (uint32_t step = 1; step < P; step <<= 1) { // this round merges list slot 2 p step with slot (2 p + 1) step
+    const uint32_t pairs = P / (2 * step);
+    for (uint32_t t = tid; t < pairs * KCAP; t += WG) { // top K of A and B as a bitonic sequence, in A's place
+      const uint32_t p = t / KCAP, i = t % KCAP;
+      uint64_t* A = mk + (size_t)(2 * p * step) * KCAP;
+      const uint64_t* B = mk + (size_t)((2 * p + 1) * step) * KCAP;
+      const uint64_t x = A[i], y = B[KCAP - 1 - i];
+      A[i] = x > y ? x : y;
+    }
+    __syncthreads();
+    for (uint32_t j = KCAP / 2; j > 0; j >>= 1) { // ... sorted descending by half-cleaners
+      for (uint32_t t = tid; t < pairs * (KCAP / 2); t += WG) {
+        const uint32_t p = t / (KCAP / 2), i0 = t % (KCAP / 2);
+        uint64_t* A = mk + (size_t)(2 * p * step) * KCAP;
+        const uint32_t i = ((i0 & ~(j - 1)) << 1) | (i0 & (j - 1));
+        const uint64_t x = A[i], y = A[i | j];
+        if (x < y) A[i] = y, A[i | j] = x;
+      }
+      __syncthreads();
+    }
+  }
+  const uint32_t n = have < a.k ? (uint32_t)have : a.k;
+  uint64_t* __restrict__ out = a.out_rows + (uint64_t)(a.out_first + q) * ROW_WORDS;
+  for (uint32_t i = tid; i < (uint32_t)KCAP; i += WG) out[i] = i < n ? mk[i] : 0ull;
+  if (tid == 0) {
+    out[KCAP] = n;
+    out[KCAP + 1] = (total & ~ROW_FLAG_MASK) | flags; // CSphMatchQueue::MoveTo adds the totals up; the shards' flag bits are OR-ed through
+    if (a.flags_any) {
+      if (flags & ROW_RERUN) a.flags_any[0] = 1u;
+      if (flags & ROW_DECLINED) a.flags_any[1] = 1u;
+    }
+  }
+}
+
+void launch_merge_rows(const MergeRowsArgs& a, void* stream) {
+  if (!a.n_queries) return;
+  uint32_t P = 1;
+  while (P < a.n_lists) P <<= 1;
+  const size_t lds = (size_t)P * KCAP * sizeof(uint64_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)merge_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KCAP * (int)sizeof(uint64_t));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(merge_rows_kernel, dim3(a.n_queries), dim3(WG), lds, (hipStream_t)stream, a, P);
+}
+
 void launch_prep(const PrepArgs& a, void* stream) {
   const uint32_t work = (a.n4[0] + a.n4[1] + a.zero_n4) / 4;
   uint32_t grid = (work + WG * 4 - 1) / (WG * 4);

@@ -106,6 +106,10 @@ class ShardMerger:
             ev.record()
         self.attached = [[] for _ in range(n_sets)]
         self.on_host = [False] * n_sets  # where the set's last merge wrote: pinned host rows or device rows
+        self.rank = 0
+        # the library partitions the merge by query: this rank's merged rows are [first, first + count) only
+        self.partitioned = False
+        self.first, self.count = 0, self.nq
         self.timing = {} if __import__("os").environ.get("MRK_DIST_TIMING") else None  # host ms per phase, summed
 
     def attach(self, batches, set_index: int = 0):
@@ -140,6 +144,14 @@ class ShardMerger:
             if after_submit:
                 assert len(self.attached[set_index]) == 1
             bh = self.attached[set_index][0]._h if after_submit else None
+            if lib().mrk_shard_partitioned(self.ctx._h):
+                import ctypes as C
+                import torch.distributed as tdist
+
+                self.partitioned, self.rank = True, (tdist.get_rank() if tdist.is_initialized() else 0)
+                f, c = C.c_uint32(), C.c_uint32()
+                check(lib().mrk_shard_slice(nq, self.world, self.rank, C.byref(f), C.byref(c)))
+                self.first, self.count = f.value, c.value
             check(lib().mrk_shard_exchange(self.ctx._h, bh, self.rows[set_index].data_ptr(), nq, self.k,
                                            (self.host_rows if to_host else self.out_rows)[set_index].data_ptr(), set_index))
             self.on_host[set_index] = to_host
@@ -182,7 +194,17 @@ class ShardMerger:
         results() to report.  Returns the merged rows [nq, ROW_WORDS] as uint64."""
         self.wait(set_index)
         rows = self._merged(set_index)
-        if not self.attached[set_index] or not (rows[:, MRK_MAX_K + 1] & np.uint64(ROW_RERUN)).any():
+        if self.partitioned:
+            # only [first, first + count) of `rows` is this rank's; whether ANY rank saw a flagged row comes through the
+            # all-reduced flag words: every rank reads the same values and takes the same path
+            import ctypes as C
+
+            rerun, decl = C.c_uint32(), C.c_uint32()
+            check(lib().mrk_shard_flags(self.ctx._h, set_index, C.byref(rerun), C.byref(decl)))
+            need_rerun = bool(rerun.value)
+        else:
+            need_rerun = bool((rows[:, MRK_MAX_K + 1] & np.uint64(ROW_RERUN)).any())
+        if not self.attached[set_index] or not need_rerun:
             return rows
         n = self.per_batch
         for i, b in enumerate(self.attached[set_index]):
@@ -191,16 +213,31 @@ class ShardMerger:
         self.merge_attached(len(self.attached[set_index]), set_index, to_host=self.on_host[set_index])
         self.wait(set_index)
         rows = self._merged(set_index)
-        bad = np.flatnonzero(rows[:, MRK_MAX_K + 1] & np.uint64(ROW_RERUN))
+        if self.partitioned:
+            rows_mine = rows[self.first:self.first + self.count]
+            bad = self.first + np.flatnonzero(rows_mine[:, MRK_MAX_K + 1] & np.uint64(ROW_RERUN))
+        else:
+            bad = np.flatnonzero(rows[:, MRK_MAX_K + 1] & np.uint64(ROW_RERUN))
         if bad.size:
             raise _lib.MrkError(_lib.MRK_E_UNSUPPORTED, f"queries {bad.tolist()[:8]}: a shard's candidate list overflowed again on the rerun")
         return rows
+
+    def results_slice(self, set_index: int = 0, allow_declined: bool = False):
+        """(first query, decoded results) of the queries THIS rank merged (the partitioned exchange; all of them with one rank)."""
+        world, self.world = self.world, 1
+        try:
+            res = self.results(set_index, allow_declined=allow_declined)
+        finally:
+            self.world = world
+        return self.first, res[self.first:self.first + self.count]
 
     def results(self, set_index: int = 0, nq=None, allow_declined: bool = False):
         """Decoded (global docid, weight) lists per query + total_found.  A query some shard declined raises MrkError
         (allow_declined=True: its entry is None instead)."""
         rows = self.finish(set_index)
         out = []
+        if self.partitioned and self.world > 1:
+            raise RuntimeError("partitioned exchange: this rank holds the queries of results_slice() only")
         for q in range(nq if nq is not None else self.nq):
             cnt, tot = int(rows[q, MRK_MAX_K]), int(rows[q, MRK_MAX_K + 1])
             if tot & ROW_DECLINED:

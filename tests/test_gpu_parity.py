@@ -795,7 +795,28 @@ def test_sharded_equals_unsharded(orc, dev):
         docid = ~k.astype(np.uint32)
         assert int(host[qi, 1025]) == w.total_found, qi
         assert np.array_equal(docid, w.rowid) and np.array_equal(weight, w.weight), qi
-    for p in (rows_all, out_rows):
+    # the exchange partitioned by query (round 3), emulated on one device: "rank" r of 3 receives every shard's rows of ITS
+    # queries (mrk_shard_slice) -- here a device copy stands in for the all-to-all -- and merges that slice only; the slices
+    # together must be the rows the all-gather form merged above, bit for bit (keys, counts, totals)
+    part_rows = dmalloc(nq * RW * 8)
+    assert hip.hipMemset(part_rows, 0xEE, C.c_size_t(nq * RW * 8)) == 0
+    per = (nq + 2) // 3
+    recv = dmalloc(3 * per * RW * 8)
+    covered = 0
+    for r in range(3):
+        f, c = C.c_uint32(), C.c_uint32()
+        _lib.check(_lib.lib().mrk_shard_slice(nq, 3, r, C.byref(f), C.byref(c)))
+        assert f.value == covered and c.value <= per
+        covered += c.value
+        for s in range(3):
+            assert hip.hipMemcpy(C.c_void_p(recv.value + s * per * RW * 8), C.c_void_p(rows_all.value + (s * nq + f.value) * RW * 8),
+                                 C.c_size_t(c.value * RW * 8), 3) == 0
+        _lib.check(_lib.lib().mrk_topk_merge_rows_part(ctx._h, recv, 3, per, f.value, c.value, 1024, part_rows))
+    assert covered == nq
+    host2 = np.zeros((nq, RW), np.uint64)
+    assert hip.hipMemcpy(C.c_void_p(host2.ctypes.data), part_rows, C.c_size_t(host2.nbytes), 2) == 0
+    assert np.array_equal(host2, host)
+    for p in (rows_all, out_rows, part_rows, recv):
         hip.hipFree(p)
 
 
