@@ -3,8 +3,9 @@
 
 Workload (BASELINE.json metric): 2-term AND, SPH_RANK_BM25, top-1000 over a synthetic Zipf
 corpus (default 100 M docs), queries stratified into common x common / selective x common /
-selective x selective thirds.  A "step" = one pass over the whole query set: one batch
-(kernel launch) per stratum.  Index segments are resident in HBM before the timed region.
+selective x selective thirds.  The query file holds 10 000 queries (seed 0x5EED0002),
+cut into sets of 3 x 256; a "step" = one set: one batch (kernel launch) per stratum, the sets taken
+in turn.  Index segments are resident in HBM before the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--docs D] [--queries Q]
 
@@ -38,6 +39,7 @@ COMMON = (0.03, 0.3)       # document-probability band of "common" terms
 SELECTIVE = (1e-4, 3e-3)   # ... of "selective" terms
 QUERY_SEED = 0x5EED0002
 CORPUS_SEED = 0x5EED0001
+QUERY_FILE = 10_000        # queries per config; the steps cycle through them
 
 
 def zipf_c() -> float:
@@ -81,8 +83,8 @@ def make_queries(c: float, q_per_stratum: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=52)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--docs", type=int, default=100_000_000, help="documents in the whole corpus")
     ap.add_argument("--queries", type=int, default=256, help="queries per stratum per step")
     ap.add_argument("--item-bytes", type=int, default=0)
@@ -95,6 +97,9 @@ def main() -> None:
     ap.add_argument("--attr-nibbles", action="store_true", help="build the one-byte tf/field plane (ctx key attr_nibbles)")
     ap.add_argument("--ctx", action="append", default=[], metavar="KEY=VALUE", help="context tunable (mrk_ctx_set), e.g. attr_seq=0")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra 3-term AND/OR mix leg (BASELINE config 3)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the extra Zipf-mix leg with PHRASE + field weights, 1024 queries per launch (BASELINE config 5, one GPU's share)")
+    ap.add_argument("--config5-docs", type=int, default=125_000_000, help="docs of the config-5 leg's corpus (one eighth of 1 B)")
+    ap.add_argument("--query-file", type=int, default=QUERY_FILE, help="queries in the query file the steps cycle through")
     ap.add_argument("--sets", type=int, default=0, help="steps kept in flight (sets of batches used in turn); 0 = 2 on one GPU, 4 sharded")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = --docs in total, split N ways (default); weak = --docs per GPU (BASELINE config 4: 8 x 100 M)")
@@ -133,7 +138,14 @@ def main() -> None:
 
     t_setup = time.time()
     c = zipf_c()
-    ranks, strata = make_queries(c, args.queries)
+    # the query file: QUERY_FILE queries in three strata, cut into sets of 3 x args.queries; step i runs set i mod n_qsets
+    n_qsets = max(1, (args.query_file // 3) // args.queries)
+    ranks, strata_all = make_queries(c, n_qsets * args.queries)
+    strata = {k: v[: args.queries] for k, v in strata_all.items()}  # set 0 (the latency sample, config 3 and the CPU baseline draw from it)
+
+    def qset(s_, k_):
+        return strata_all[s_][k_ * args.queries:(k_ + 1) * args.queries]
+
     probs = [min(0.5, c / r) for r in ranks]
     # rowid-range shards of ONE corpus (postings are keyed on the global rowid): rank r holds rows [row0, row0 + shard_docs)
     corpus_docs = args.docs * world if args.scaling == "weak" else args.docs
@@ -172,13 +184,13 @@ def main() -> None:
                        local_docs={a: int(global_docs[a]), b: int(global_docs[b])})
 
     names = [x for x in ["cc", "sc", "ss"] if x in args.strata.split(",")]
-    prepared = {s: m.prepare([mkq(a, b) for a, b in strata[s]]) for s in names}
+    prepared = {s: [m.prepare([mkq(a, b) for a, b in qset(s, k_)]) for k_ in range(n_qsets)] for s in names}
     nq = args.queries
     # Work groups of a step.  One GPU: one batch per stratum (the cc launch is timed on its own for the roofline).
     # Sharded: the step's queries go down as ONE batch per rank, so a step costs one scan launch, one selection,
     # one RCCL all-gather of result rows and one merge.
     if sharded:
-        prepared["all"] = m.prepare([mkq(a, b) for s in names for a, b in strata[s]])
+        prepared["all"] = [m.prepare([mkq(a, b) for s in names for a, b in qset(s, k_)]) for k_ in range(n_qsets)]
         groups = [("all", len(names) * nq)]
     else:
         groups = [(s, nq) for s in names]
@@ -200,8 +212,9 @@ def main() -> None:
     def record_stats(s, st) -> None:
         per[s]["scan_ms"] += st["scan_ms"]
         per[s]["merge_ms"] += st["merge_ms"]
-        per[s].update(algo_bytes=st["algo_bytes"], dev_bytes=st["dev_bytes"], packed=st["packed"], n_items=st["n_items"],
-                      n_cands=st["n_cands"], n_items_bm=st["n_items_bm"])
+        per[s].update(packed=st["packed"], n_items=st["n_items"], n_cands=st["n_cands"], n_items_bm=st["n_items_bm"])
+        per[s]["algo_bytes"] = per[s].get("algo_bytes", 0) + st["algo_bytes"]  # (summed like scan_ms: the sets differ)
+        per[s]["dev_bytes"] = per[s].get("dev_bytes", 0) + st["dev_bytes"]
         per[s]["plan_ms"] = per[s].get("plan_ms", 0.0) + st["plan_ms"]
         per[s]["submit_ms"] = per[s].get("submit_ms", 0.0) + st["submit_ms"]
         per[s]["n"] += 1
@@ -220,6 +233,7 @@ def main() -> None:
 
     def step(record: bool) -> None:
         idx = state["i"] % n_sets
+        qk = state["i"] % n_qsets  # the query set of this step
         state["i"] += 1
         t_s = time.perf_counter()
         if merger is not None:
@@ -233,7 +247,7 @@ def main() -> None:
                     record_stats("all", sets[idx]["all"].stats())
             host_ms["wait"] += (time.perf_counter() - t_w) * 1e3
             t_s = time.perf_counter()
-            sets[idx]["all"].submit_prepared(seg, prepared["all"], len(names) * nq)
+            sets[idx]["all"].submit_prepared(seg, prepared["all"][qk], len(names) * nq)
             host_ms["submit"] += (time.perf_counter() - t_s) * 1e3
             t_m = time.perf_counter()
             merger.merge_attached(1, set_index=idx, to_host=True, after_submit=True)
@@ -243,7 +257,7 @@ def main() -> None:
             state["rec"][idx] = record
             return
         for g, n in groups:
-            sets[idx][g].submit_prepared(seg, prepared[g], n)
+            sets[idx][g].submit_prepared(seg, prepared[g][qk], n)
         host_ms["submit"] += (time.perf_counter() - t_s) * 1e3
         host_ms["n"] += 1
         state["pending"].append((idx, record))
@@ -292,20 +306,20 @@ def main() -> None:
 
     # sharded runs scan all strata in one launch: time the cc launch on its own (outside the timed region) for the
     # roofline fields
-    if sharded and "cc" in names:
-        for _ in range(3):
-            batch.submit_prepared(seg, prepared["cc"], nq)
+    if "cc" not in names:
+        prepared["cc"] = [m.prepare([mkq(a, b) for a, b in qset("cc", k_)]) for k_ in range(n_qsets)]
+        per.setdefault("cc", {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0})
+    if sharded or "cc" not in names:
+        for k_ in range(min(n_qsets, 4)):
+            batch.submit_prepared(seg, prepared["cc"][k_], nq)
             batch.wait()
             record_stats("cc", batch.stats())
-    # output bytes of the cc stratum: 8 B per returned match
-    if "cc" not in names:
-        names_backup = names
-        prepared["cc"] = m.prepare([mkq(a, b) for a, b in strata["cc"]])
-        per.setdefault("cc", {"scan_ms": 0.0, "merge_ms": 0.0, "algo_bytes": 0, "n": 0})
-    batch.submit_prepared(seg, prepared["cc"], nq)
-    batch.wait()
-    res_cc = batch.results()
-    out_bytes = sum(8 * len(r.rowid) for r in res_cc)
+    # every cc set once more for its results: 8 B per returned match are output bytes, total_found checks the host-side count
+    res_cc_sets = []
+    for k_ in range(n_qsets):
+        batch.submit_prepared(seg, prepared["cc"][k_], nq)
+        batch.wait()
+        res_cc_sets.append(batch.results())
 
     # single-query latency (batch of one), p50 over a stratified sample
     lat = []
@@ -337,23 +351,39 @@ def main() -> None:
     #              128-byte lines of tf / field words the MATCHED docs' slots touch in each keyword's packed array
     #              (counted on the host from the two doclists, mrk_host_index_pair_stats) + 8 B per returned match
     algo_detail = None
+    out_bytes = sum(8 * len(r.rowid) for rs in res_cc_sets for r in rs) / max(1, len(res_cc_sets))
     if kernel_tag == "bm" and rank == 0:
+        # per launch = the AVERAGE over the query file's cc sets (every one of them was timed in the loop, the same number of times
+        # when --steps is a multiple of the set count)
         t_ps = time.time()
-        ps = m.pair_stats(hi, strata["cc"])
         nwin = (shard_docs + 2047) // 2048
-        b_ref = [int(hi.dict[a]["doclist_len"]) + int(hi.dict[b]["doclist_len"]) + 8 * len(r.rowid) for (a, b), r in zip(strata["cc"], res_cc)]
-        line = [(p[5] + p[6]) if args.attr_nibbles else (p[3] + p[4]) for p in ps]
-        b_dev = [2 * nwin * 256 + 128 * ln + 8 * len(r.rowid) for ln, r in zip(line, res_cc)]
-        if not os.environ.get("MRK_LIB_PATH"):  # (kernel-experiment libraries may skip the scoring step)
-            assert all(p[0] == r.total_found for p, r in zip(ps, res_cc)), "host intersection and device total_found disagree"
-        algo = sum(min(x, y) for x, y in zip(b_ref, b_dev))
-        full_attr = sum(((p[1] + 127) // 128 + (p[2] + 127) // 128) * (128 if args.attr_nibbles else 256) for p in ps)
-        algo_detail = {"sum_min_per_query": int(algo), "sum_B_ref": int(sum(b_ref)), "sum_B_dev": int(sum(b_dev)),
-                       "queries_where_ref_is_smaller": int(sum(x < y for x, y in zip(b_ref, b_dev))),
-                       "bitmap_bytes": int(2 * nwin * 256 * len(ps)), "attr_line_bytes_touched": int(128 * sum(line)),
-                       "attr_bytes_if_every_word_were_read": int(full_attr), "host_count_s": round(time.time() - t_ps, 1)}
+        seq_plane = not args.attr_nibbles and not any(kv.startswith("attr_seq=0") for kv in args.ctx)
+        tot = {"algo": 0, "ref": 0, "dev": 0, "ref_smaller": 0, "bitmap": 0, "lines": 0, "full": 0}
+        for k_ in range(n_qsets):
+            pairs_k, res_k = qset("cc", k_), res_cc_sets[k_]
+            ps = m.pair_stats(hi, pairs_k)
+            b_ref = [int(hi.dict[a]["doclist_len"]) + int(hi.dict[b]["doclist_len"]) + 8 * len(r.rowid) for (a, b), r in zip(pairs_k, res_k)]
+            # the 128-byte lines the matched docs' slots touch in the plane the launched kernel gathers from: the slot-ordered
+            # two-byte plane (default), the one-byte plane (--attr-nibbles) or the block decoder's interleaved words (attr_seq=0)
+            line = [(p[5] + p[6]) if args.attr_nibbles else (p[7] + p[8]) if seq_plane else (p[3] + p[4]) for p in ps]
+            b_dev = [2 * nwin * 256 + 128 * ln + 8 * len(r.rowid) for ln, r in zip(line, res_k)]
+            if not os.environ.get("MRK_LIB_PATH"):  # (kernel-experiment libraries may skip the scoring step)
+                assert all(p[0] == r.total_found for p, r in zip(ps, res_k)), "host intersection and device total_found disagree"
+            tot["algo"] += sum(min(x, y) for x, y in zip(b_ref, b_dev))
+            tot["ref"] += sum(b_ref)
+            tot["dev"] += sum(b_dev)
+            tot["ref_smaller"] += sum(x < y for x, y in zip(b_ref, b_dev))
+            tot["bitmap"] += 2 * nwin * 256 * len(ps)
+            tot["lines"] += 128 * sum(line)
+            tot["full"] += sum(((p[1] + 127) // 128 + (p[2] + 127) // 128) * (128 if args.attr_nibbles else 256) for p in ps)
+        algo = tot["algo"] / n_qsets
+        algo_detail = {"sets_averaged": n_qsets, "sum_min_per_query": int(algo), "sum_B_ref": int(tot["ref"] / n_qsets), "sum_B_dev": int(tot["dev"] / n_qsets),
+                       "queries_where_ref_is_smaller_per_set": round(tot["ref_smaller"] / n_qsets, 1),
+                       "bitmap_bytes": int(tot["bitmap"] / n_qsets), "attr_line_bytes_touched": int(tot["lines"] / n_qsets),
+                       "attr_plane": "one byte per posting" if args.attr_nibbles else "two bytes per posting, slot order" if seq_plane else "interleaved block words",
+                       "attr_bytes_if_every_word_were_read": int(tot["full"] / n_qsets), "host_count_s": round(time.time() - t_ps, 1)}
     else:
-        algo = min(cc["algo_bytes"], cc.get("dev_bytes", cc["algo_bytes"])) + out_bytes
+        algo = min(cc["algo_bytes"], cc.get("dev_bytes", cc["algo_bytes"])) / max(1, cc["n"]) + out_bytes
     achieved = algo / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic, traffic_src, measured_strata = None, None, {}
     kernel_name = {"bm": "mrk::scan_bm_kernel", "pk": "mrk::scan_pk_kernel", "vlb": "mrk::scan_kernel"}[kernel_tag]
@@ -361,15 +391,21 @@ def main() -> None:
                      "pk": "packed 128-doc blocks (bit-packed rowid offsets + tf/field bytes)",
                      "vlb": "reference .spd VLB"}[kernel_tag]
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+    ksha = kernel_sources_sha()
     if os.path.exists(tr_path):
         try:
             tj = json.load(open(tr_path))
             if (tj.get("docs") == args.docs and tj.get("queries") == nq and tj.get("skiplist_block") == args.skiplist_block
                     and tj.get("kernel_tag") == kernel_tag and not args.attr_nibbles):
-                traffic = tj.get("traffic_bytes_per_launch")
-                traffic_src = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this configuration (tools/traffic.sh), "
-                               "calibrated on known-size kernels in this kernel's access patterns; a PMC pass cannot run inside this process")
-                measured_strata = tj.get("strata", {})
+                if tj.get("kernel_sources_sha") == ksha:
+                    traffic = tj.get("traffic_bytes_per_launch")
+                    traffic_src = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this configuration and of THESE kernel sources "
+                                   f"(sha {ksha}; tools/traffic.sh), calibrated on known-size kernels in this kernel's access patterns; "
+                                   "a PMC pass cannot run inside this process")
+                    measured_strata = tj.get("strata", {})
+                else:  # measured on other kernel sources: not this run's kernel -- say so instead of reporting it
+                    traffic_src = (f"profiles/traffic.json was measured at kernel sources {tj.get('kernel_sources_sha')}, this run has {ksha}: "
+                                   "stale, not reported (re-run tools/traffic.sh)")
         except Exception:
             traffic = None
 
@@ -388,12 +424,13 @@ def main() -> None:
         "data": "synthetic",
         "config": {
             "workload": f"{corpus_docs // 1_000_000}M docs (Zipf s=1, V=2^20, {AVG_TERMS_PER_DOC:.0f} terms/doc), 2-term AND, "
-                        f"SPH_RANK_BM25, top-{K}, {3 * nq} queries/step in 3 strata (cc/sc/ss), "
+                        f"SPH_RANK_BM25, top-{K}, {3 * nq} queries/step in 3 strata (cc/sc/ss) out of a {n_qsets * 3 * nq}-query file, "
                         f"skiplist_block_size={args.skiplist_block}, inline hits",
             "docs": corpus_docs,
             "shards": world,
             "queries_per_step": 3 * nq,
             "k": K,
+            "query_file": f"{n_qsets * 3 * nq} queries (seed {QUERY_SEED:#x}) in {n_qsets} sets of 3 x {nq}; step i runs set i mod {n_qsets}",
         },
         "roofline": {
             "bound": "hbm",
@@ -406,8 +443,9 @@ def main() -> None:
             "kernel": f"{kernel_name} (common x common stratum launch)",
             "algo_bytes_per_launch": int(algo),
             "algo_bytes_detail": algo_detail,
-            "ref_format_bytes_per_launch": int(cc["algo_bytes"]),
-            "device_format_bytes_per_launch": int(cc.get("dev_bytes", 0)),
+            "ref_format_bytes_per_launch": int(cc["algo_bytes"] / max(1, cc["n"])),
+            "device_format_bytes_per_launch": int(cc.get("dev_bytes", 0) / max(1, cc["n"])),
+            "kernel_sources_sha": ksha,
             "device_format": device_format,
             "launch_ms": round(scan_ms, 4),
             "timed": ("cc launch timed after the loop: the sharded loop scans all strata in one launch per rank" if sharded
@@ -417,11 +455,11 @@ def main() -> None:
         # algorithmic rate may exceed the HBM peak and is never folded into the headline; measured bytes next to it
         "strata": {
             s: {"label": "headline (no skipping possible: algorithmic ~ read bytes)" if s == "cc" else "skip-assisted" if s in ("sc", "ss") else "all strata in one launch",
-                "algo_GBps": round(min(per[s]["algo_bytes"], per[s].get("dev_bytes", per[s]["algo_bytes"])) / max(1e-9, per[s]["scan_ms"] / max(1, per[s]["n"]) * 1e-3) / 1e9, 1),
+                "algo_GBps": round(min(per[s]["algo_bytes"], per[s].get("dev_bytes", per[s]["algo_bytes"])) / max(1e-9, per[s]["scan_ms"] * 1e-3) / 1e9, 1),
                 "measured_MB": (round(measured_strata[s]["measured_bytes_per_launch"] / 1e6, 2) if s in measured_strata else None),
                 "scan_ms": round(per[s]["scan_ms"] / max(1, per[s]["n"]), 4),
                 "merge_ms": round(per[s]["merge_ms"] / max(1, per[s]["n"]), 4),
-                "algo_MB": round(per[s]["algo_bytes"] / 1e6, 2), "dev_MB": round(per[s].get("dev_bytes", 0) / 1e6, 2), "items": per[s].get("n_items", 0), "cands": per[s].get("n_cands", 0),
+                "algo_MB": round(per[s]["algo_bytes"] / max(1, per[s]["n"]) / 1e6, 2), "dev_MB": round(per[s].get("dev_bytes", 0) / max(1, per[s]["n"]) / 1e6, 2), "items": per[s].get("n_items", 0), "cands": per[s].get("n_cands", 0),
                 "host_plan_ms": round(per[s].get("plan_ms", 0.0) / max(1, per[s]["n"]), 4),
                 "host_submit_ms": round(per[s].get("submit_ms", 0.0) / max(1, per[s]["n"]), 4)} for s in (names + ["all"]) if per[s]["n"]},
         "strata_run": names,
@@ -456,6 +494,27 @@ def main() -> None:
                           "ok": int(sum(r.status == 0 for r in res3)), "matches": int(sum(r.total_found for r in res3))}
         for bb in b3:
             bb.close()
+    # HBM footprint of what this run holds: the materialised query terms only (the corpus' other ~10^6 terms were never generated)
+    if rank == 0:
+        postings = int(hi.dict["docs"].astype(np.int64).sum())
+        dev_b = int(seg.device_bytes)
+        out["footprint"] = {
+            "device_bytes": dev_b, "terms_materialised": int(len(hi.dict)), "postings_materialised": postings,
+            "device_bytes_per_posting": round(dev_b / max(1, postings), 2),
+            "reference_format_bytes": int(hi.spd.size + hi.spp.size + hi.spe.size),
+            "holds": "reference .spd/.spp verbatim + 128-doc block index + packed blocks (rowid offsets, tf/field words, hit references) + "
+                     "for keywords in >= 1/64 of the docs a doc-set bitmap, rank directory and the slot-ordered tf/field plane",
+            "full_vocabulary_projection_bytes": int(dev_b / max(1, postings) * AVG_TERMS_PER_DOC * shard_docs),
+            "projection_note": f"bytes per posting x {AVG_TERMS_PER_DOC:.0f} postings per doc x {shard_docs} docs: an upper estimate (the materialised terms "
+                               "are the query terms: dense keywords, whose bitmaps and second tf/field plane cost most per posting, are over-represented)",
+        }
+    # BASELINE config 5 on one GPU's share (1 B docs / 8): Zipf query mix incl. PHRASE, field weights (10,5,2,1), SPH_RANK_PROXIMITY_BM25,
+    # 1024 queries per launch.  Its own corpus (4 fields, field-end markers); outside the timed region.  Extra information only.
+    if rank == 0 and world == 1 and not sharded and not args.no_config5 and args.path == 0 and set(names) == {"cc", "sc", "ss"}:
+        try:
+            out["config5"] = config5_leg(m, ctx, args, c, K)
+        except Exception as e:  # (the headline line must not die with the extra leg)
+            out["config5"] = {"error": f"{type(e).__name__}: {e}"}
     if merger is not None and merger.timing:
         out["dist_timing_ms_per_call"] = {k_: round(v / max(1, merger.timing["calls"]), 4) for k_, v in merger.timing.items() if k_ != "calls"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -474,6 +533,84 @@ def main() -> None:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def config5_queries(m, strata, n, K, total_docs, global_docs, fw):
+    """BASELINE config 5's mix: 60 % 2-term AND, 20 % 3-term AND / OR mixes, 20 % 2-3-word PHRASE; field weights; PROXIMITY_BM25.
+    Keywords from the same Zipf strata as the headline queries."""
+    kw = m.XQNode.keyword
+    OR_, ANDNOT_, PHR = m.SPH_QUERY_OR, m.SPH_QUERY_ANDNOT, m.SPH_QUERY_PHRASE
+    rng = np.random.default_rng(QUERY_SEED + 5)
+    pools = [strata["cc"], strata["sc"], strata["ss"]]
+    out = []
+    for i in range(n):
+        a_, b_ = pools[i % 3][(i // 3) % len(pools[i % 3])]
+        c_ = strata["cc"][(i * 7) % len(strata["cc"])][0]
+        if c_ in (a_, b_):
+            c_ = strata["cc"][(i * 7) % len(strata["cc"])][1]
+        u = rng.random()
+        if u < 0.6:
+            root, used = m.XQNode.AND(kw(a_, 1), kw(b_, 2)), (a_, b_)
+        elif u < 0.8:
+            ka, kb, kc = kw(a_, 1), kw(b_, 2), kw(c_, 3)
+            root = [m.XQNode.AND(ka, kb, kc), m.XQNode.AND(m.XQNode(OR_, [ka, kb]), kc), m.XQNode.AND(ka, m.XQNode(OR_, [kb, kc])),
+                    m.XQNode(ANDNOT_, [m.XQNode.AND(ka, kb), kc])][i % 4]
+            used = (a_, b_, c_)
+        else:  # phrases of common words (a phrase of two rare words matches nothing in a synthetic corpus)
+            p_, q_ = strata["cc"][i % len(strata["cc"])]
+            words = [p_, q_] + ([c_] if (i % 2 and c_ not in (p_, q_)) else [])
+            root, used = m.XQNode(PHR, [kw(w, j + 1) for j, w in enumerate(words)]), tuple(words)
+        out.append(m.Query(root, ranker=m.SPH_RANK_PROXIMITY_BM25, max_matches=K, total_docs=int(total_docs), field_weights=list(fw),
+                           local_docs={t: int(global_docs[t]) for t in used}))
+    return out
+
+
+def config5_leg(m, ctx, args, c, K):
+    t0 = time.time()
+    nq5, fw = 1024, (10, 5, 2, 1)
+    ranks, strata = make_queries(c, 342)
+    probs = [min(0.5, c / r) for r in ranks]
+    hi5 = m.synth_index(args.config5_docs, probs, seed=CORPUS_SEED + 5, n_fields=4, end_markers=True, skiplist_block_size=args.skiplist_block)
+    t_gen = time.time() - t0
+    seg5 = m.Segment(ctx, hi5)
+    gd = hi5.dict["docs"].astype(np.int64)
+    qs = config5_queries(m, strata, nq5, K, args.config5_docs, gd, fw)
+    cq = m.prepare(qs)
+    bs = [m.Batch(ctx, nq5), m.Batch(ctx, nq5)]
+    for bb in bs:
+        bb.submit_prepared(seg5, cq, nq5)
+        bb.wait()
+    t1 = time.perf_counter()
+    reps = 6
+    for i in range(reps):
+        bs[i % 2].wait()
+        bs[i % 2].submit_prepared(seg5, cq, nq5)
+    for bb in bs:
+        bb.wait()
+    dt = time.perf_counter() - t1
+    st, res = bs[0].stats(), bs[0].results()
+    out = {"workload": f"{args.config5_docs // 1_000_000}M docs (one eighth of 1 B), 4 fields with weights {fw}, {nq5} queries/launch: 60 % 2-term AND, 20 % 3-term "
+                       f"AND/OR mixes, 20 % 2-3-word PHRASE, SPH_RANK_PROXIMITY_BM25, top-{K}",
+           "queries_per_s": round(reps * nq5 / dt, 1), "ms_per_launch": round(dt / reps * 1e3, 3), "scan_ms": round(st["scan_ms"], 4),
+           "select_ms": round(st["merge_ms"], 4), "doclist_MB": round(st["algo_bytes"] / 1e6, 2), "ok": int(sum(r.status == 0 for r in res)),
+           "declined": int(sum(r.status != 0 for r in res)), "matches": int(sum(r.total_found for r in res)),
+           "device_bytes": int(seg5.device_bytes), "postings": int(gd.sum()), "setup_s": {"generate": round(t_gen, 1), "total": round(time.time() - t0, 1)}}
+    for bb in bs:
+        bb.close()
+    seg5.close()
+    return out
+
+
+def kernel_sources_sha() -> str:
+    """Short hash of the sources that shape the headline launch (kernel, its helpers, the work-item cut in the host code):
+    profiles/traffic.json carries the one it was measured at."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("mrk_scan_bm.hip", "mrk_kprune.h", "mrk_kcommon.h", "mrk_dev.h", "mrk_host.cpp", "mrk_host_int.h", "mrk_pack.cpp"):
+        with open(os.path.join(ROOT, "manticoresearch_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def config3_queries(m, strata, nq, K, total_docs, global_docs):

@@ -435,9 +435,11 @@ const mrk_dict_entry* mrk_host_index_dict(const mrk_host_index* h, uint32_t* n_t
    (pairs[2i], pairs[2i+1]): common docs, each keyword's doc count, and the distinct 128-byte lines of each keyword's packed
    tf / field words (64 words per 128-doc block, in doclist order) that the common docs touch -- what the two-bitmap AND
    kernel's gathers have to fetch, instead of "every tf / field word of both doclists" -- and the distinct 128-doc
-   blocks touched (= 128-byte lines of the one-byte-per-doc "attr_nibbles" plane). */
+   blocks touched (= 128-byte lines of the one-byte-per-doc "attr_nibbles" plane); lines128s_*: the same count for the
+   slot-ordered two-byte plane ("attr_seq": 64 consecutive docs per 128-byte line), which is what the kernel gathers from by
+   default. */
 typedef struct {
-  uint64_t matches, docs_a, docs_b, lines128_a, lines128_b, blocks_a, blocks_b;
+  uint64_t matches, docs_a, docs_b, lines128_a, lines128_b, blocks_a, blocks_b, lines128s_a, lines128s_b;
 } mrk_pair_stats;
 int mrk_host_index_pair_stats(const mrk_host_index* h, uint32_t hit_format, const uint32_t* pairs, uint32_t n_pairs,
                               uint32_t n_threads, mrk_pair_stats* out);

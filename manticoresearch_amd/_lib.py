@@ -91,7 +91,7 @@ class AttrInfo(C.Structure):
 
 class PairStats(C.Structure):
     _fields_ = [("matches", C.c_uint64), ("docs_a", C.c_uint64), ("docs_b", C.c_uint64), ("lines128_a", C.c_uint64), ("lines128_b", C.c_uint64),
-                ("blocks_a", C.c_uint64), ("blocks_b", C.c_uint64)]
+                ("blocks_a", C.c_uint64), ("blocks_b", C.c_uint64), ("lines128s_a", C.c_uint64), ("lines128s_b", C.c_uint64)]
 
 
 class SynthParams(C.Structure):

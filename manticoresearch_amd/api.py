@@ -167,13 +167,13 @@ def _wrap_file_index(h) -> HostIndex:
 
 
 def pair_stats(hi: HostIndex, pairs: Sequence[Sequence[int]], n_threads: int = 0):
-    """[(matches, docs_a, docs_b, lines128_a, lines128_b, blocks_a, blocks_b)] per keyword pair: common docs, the distinct
-    128-byte lines of each keyword's packed tf / field words they touch, and the distinct 128-doc blocks
-    (mrk_host_index_pair_stats; roofline accounting only)."""
+    """[(matches, docs_a, docs_b, lines128_a, lines128_b, blocks_a, blocks_b, lines128s_a, lines128s_b)] per keyword pair: common
+    docs, the distinct 128-byte lines of each keyword's packed tf / field words they touch, the distinct 128-doc blocks, and the
+    lines of the slot-ordered two-byte plane (mrk_host_index_pair_stats; roofline accounting only)."""
     arr = np.ascontiguousarray(np.asarray(pairs, dtype=np.uint32).reshape(-1, 2))
     out = (_lib.PairStats * len(arr))()
     check(lib().mrk_host_index_pair_stats(hi._owner.h, hi.hit_format, arr.ctypes.data, len(arr), n_threads, out))
-    return [(int(o.matches), int(o.docs_a), int(o.docs_b), int(o.lines128_a), int(o.lines128_b), int(o.blocks_a), int(o.blocks_b)) for o in out]
+    return [(int(o.matches), int(o.docs_a), int(o.docs_b), int(o.lines128_a), int(o.lines128_b), int(o.blocks_a), int(o.blocks_b), int(o.lines128s_a), int(o.lines128s_b)) for o in out]
 
 
 def index_from_hits(wordid: np.ndarray, rowid: np.ndarray, hitpos: np.ndarray, n_terms: int, total_docs: int,

@@ -241,6 +241,15 @@ int mrk_comm_exchange_part_impl(mrk_ctx* ctx, const uint64_t* rows, uint32_t n_q
   if (ctx->merge_used[slot] && ctx->merge_done[slot]) HIP_TRY(hipStreamWaitEvent(c->stream, ctx->merge_done[slot], 0));
   if (after) HIP_TRY(hipStreamWaitEvent(c->stream, after, 0));
   uint64_t* recv = (uint64_t*)c->rows_all[slot];
+  if (c->n_ranks == 1 && !ctx->exchange_self_rccl) {
+    // one rank: nothing to exchange -- the shard's own rows ARE the receive buffer (RCCL's send-to-self of 6 MB was seen to take
+    // 0.2 ms on MI355X; ctx key "exchange_self_rccl" = 1 keeps it, to rehearse the collective's code path with one rank)
+    HIP_TRY(hipEventRecord(c->gathered[slot], c->stream));
+    *recv_out = rows;
+    *gathered_event_out = c->gathered[slot];
+    *per_out = per, *first_out = first, *count_out = count;
+    return MRK_OK;
+  }
   RCCL_TRY(api, api->GroupStart());
   for (int p = 0; p < c->n_ranks; ++p) {
     uint32_t pf, pc;

@@ -348,6 +348,9 @@ struct ScanArgs {
   uint32_t* q_flags;   // [n_queries]
   uint32_t* q_tau_bin; // [n_queries * QSTRIDE] running pruning threshold (bin index), atomicMax
   uint64_t* cand;      // candidate arena
+  // hit-ranked queries: histogram of the matches' LOWER weight bounds and its threshold bin (mrk_kprune.h, prox_bounds); NULL = no pruning in front of the hit pass
+  uint32_t* q_hist_lb; // [n_queries][NBINS]
+  uint32_t* q_tau_lb;  // [n_queries * QSTRIDE]
   MatchQueue mq[3];    // [0] plain boolean trees, [1] queries with PHRASE / PROXIMITY / BEFORE nodes or position modifiers, [2] TF_GEN
   GenArgs gen;
 };
@@ -387,6 +390,8 @@ struct SelectArgs {
   uint64_t* h_total;       // pinned host [n_queries] or NULL
   uint32_t* h_flags;       // pinned host [n_queries] or NULL
   uint32_t* h_cand_n;      // pinned host [n_queries] or NULL
+  uint64_t* rows_dst;      // device [n_queries][ROW_WORDS] or NULL: the exchange rows (keys zero-padded | count | total_found or MRK_ROW_RERUN)
+  const uint32_t* declined; // unused by the kernel (declined queries' rows are rewritten by pack_rows_kernel)
 };
 
 // One launch instead of two copies and a memset in front of every scan: query and work-item descriptors are read from the

@@ -77,7 +77,7 @@ extern "C" int mrk_host_index_pair_stats(const mrk_host_index* h, uint32_t hit_f
         bad = true;
         continue;
       }
-      ta.assign((ra.size() + 127) / 128, 0);
+      ta.assign((ra.size() + 127) / 128, 0); // per block: bits 0-1 = lines of the interleaved words, bits 2-3 = lines of the slot-ordered plane
       tb.assign((rb.size() + 127) / 128, 0);
       uint64_t m = 0;
       size_t x = 0, y = 0;
@@ -88,17 +88,17 @@ extern "C" int mrk_host_index_pair_stats(const mrk_host_index* h, uint32_t hit_f
           ++y;
         else {
           ++m;
-          ta[x >> 7] |= (uint8_t)(1u << ((x & 63) >> 5));
-          tb[y >> 7] |= (uint8_t)(1u << ((y & 63) >> 5));
+          ta[x >> 7] |= (uint8_t)((1u << ((x & 63) >> 5)) | (4u << ((x & 127) >> 6)));
+          tb[y >> 7] |= (uint8_t)((1u << ((y & 63) >> 5)) | (4u << ((y & 127) >> 6)));
           ++x, ++y;
         }
       }
       mrk_pair_stats& o = out[i];
       o.matches = m;
       o.docs_a = ra.size(), o.docs_b = rb.size();
-      o.lines128_a = o.lines128_b = o.blocks_a = o.blocks_b = 0;
-      for (uint8_t v : ta) o.lines128_a += (v & 1u) + (v >> 1), o.blocks_a += v != 0;
-      for (uint8_t v : tb) o.lines128_b += (v & 1u) + (v >> 1), o.blocks_b += v != 0;
+      o.lines128_a = o.lines128_b = o.blocks_a = o.blocks_b = o.lines128s_a = o.lines128s_b = 0;
+      for (uint8_t v : ta) o.lines128_a += (v & 1u) + ((v >> 1) & 1u), o.lines128s_a += ((v >> 2) & 1u) + ((v >> 3) & 1u), o.blocks_a += v != 0;
+      for (uint8_t v : tb) o.lines128_b += (v & 1u) + ((v >> 1) & 1u), o.lines128s_b += ((v >> 2) & 1u) + ((v >> 3) & 1u), o.blocks_b += v != 0;
     }
   };
   std::vector<std::thread> th;

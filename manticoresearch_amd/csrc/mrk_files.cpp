@@ -598,7 +598,12 @@ int rt_open(const char* path_prefix, mrk_rt_ram* rt) {
     if ((rc = rt_vector(r, 1, "ram-doclist", rname.c_str(), docs)) || (rc = rt_vector(r, 1, "ram-hitlist", rname.c_str(), hits)) ||
         (rc = rt_vector(r, 4, "ram-attributes", rname.c_str(), rowdata)))
       return rc;
-    std::vector<uint32_t> dead((rows + 31) / 32, 0u); // DeadRowMap_Ram_c::Load (killlist.cpp:120-129)
+    // DeadRowMap_Ram_c::Load (killlist.cpp:120-129).  `rows` is an untrusted dword: the word count in 64 bits ((rows + 31) / 32 wraps
+    // to 0 for rows >= 0xFFFFFFE1 -- an empty map, then an out-of-bounds read in the popcount below), checked against the bytes
+    // that are left BEFORE anything is allocated from it
+    const uint64_t dead_words = ((uint64_t)rows + 31) / 32;
+    if (r.bad || dead_words * 4 > (uint64_t)(r.n - r.at)) return mrk_fail(MRK_E_FORMAT, "%s: dead-row map of %u rows past the file", rname.c_str(), rows);
+    std::vector<uint32_t> dead((size_t)dead_words, 0u);
     if (!r.need(dead.size() * 4)) return mrk_fail(MRK_E_FORMAT, "%s: dead-row map of %u rows past the file", rname.c_str(), rows);
     if (!dead.empty()) memcpy(dead.data(), r.p + r.at, dead.size() * 4);
     r.at += dead.size() * 4;
@@ -700,7 +705,11 @@ int rt_open(const char* path_prefix, mrk_rt_ram* rt) {
       for (size_t i = 0; i < h->dict.size() && i < wordids.size(); ++i) h->dict[i].wordid = wordids[i];
     h->blobs = blobs;
     h->dead = dead;
-    for (uint32_t x = 0; x < rows; ++x) h->info.n_dead += (dead[x >> 5] >> (x & 31u)) & 1u;
+    for (size_t wi = 0; wi < dead.size(); ++wi) { // popcount over the words that are there, the tail beyond `rows` masked
+      uint32_t wv = dead[wi];
+      if (wi + 1 == dead.size() && (rows & 31u)) wv &= (1u << (rows & 31u)) - 1u;
+      h->info.n_dead += (uint64_t)__builtin_popcount(wv);
+    }
     if (rows && rowdata.size() % ((size_t)rows * 4) == 0) { // CSphRowitem rows, the schema's stride
       h->attr_stride = (uint32_t)(rowdata.size() / 4 / rows);
       h->docinfo_rows = rows;

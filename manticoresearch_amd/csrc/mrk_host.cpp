@@ -140,6 +140,7 @@ struct mrk_batch {
   DevBuf<uint32_t> d_list_first, d_list_n, d_kq;
   DevBuf<uint64_t> d_out_keys;
   DevBuf<uint32_t> d_out_cnt;
+  DevBuf<uint32_t> d_lb;  // hit-ranked queries: histograms of the matches' lower weight bounds [n][NBINS], then their threshold words [n * QSTRIDE]
   DevBuf<uint32_t> d_sel; // selection scratch: threshold bin | slices in use per query, then the survivors per slice
   // packed path: pruning histograms, candidate lists
   View<uint32_t> d_q_hist, d_q_cand_n, d_q_flags, d_q_tau_bin;
@@ -267,12 +268,20 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
     c->mq_max_chunks = (int)value;
     return MRK_OK;
   }
+  if (!strcmp(key, "prox_prune")) {
+    c->prox_prune = value != 0;
+    return MRK_OK;
+  }
+  if (!strcmp(key, "exchange_self_rccl")) {
+    c->exchange_self_rccl = value != 0;
+    return MRK_OK;
+  }
   if (!strcmp(key, "exchange_part")) {
     c->exchange_part = value != 0;
     return MRK_OK;
   }
   if (!strcmp(key, "item_order")) {
-    if (value < 0 || value > 7) return mrk_fail(MRK_E_INVAL, "item_order is a mask 0 .. 7");
+    if (value < 0 || value > 15) return mrk_fail(MRK_E_INVAL, "item_order is a mask 0 .. 15");
     c->item_order = (int)value;
     return MRK_OK;
   }
@@ -806,6 +815,7 @@ static void mrk_batch_destroy_impl(mrk_batch* b) {
   b->d_out_keys.release();
   b->d_out_cnt.release();
   b->d_sel.release();
+  b->d_lb.release();
 
   b->h_cand_n.release();
   b->d_cand.release();
@@ -1077,7 +1087,7 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   // to different queries (the planner emits a query's items back to back; only the VLB path needs them that way)
   // (not for batches whose matches travel through the match queue to the hit pass: config 3 measured 6.6 ms query-major, 7.1 ms
   // interleaved -- the rank kernel likes a query's chunks in rowid order)
-  if (use_packed && items.size() > 1 && (b->ctx->item_order & 1) && !any_prox) {
+  if (use_packed && items.size() > 1 && (b->ctx->item_order & 1) && (!any_prox || (b->ctx->item_order & 8))) {
     std::vector<DevItem> rr;
     rr.reserve(items.size());
     std::vector<size_t> run_begin, run_end; // runs of items of one pass
@@ -1114,7 +1124,7 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
     // atomics on one address serialize at the memory side (~70 ns each), about 0.1 ms per query whatever the shard size --
     // hidden behind 100 M docs, the whole launch at 12.5 M (12288 work items: 0.85 ms; 4096: 0.39 ms, same bytes).
     const size_t before = items.size();
-    if (!(b->ctx->item_order & (kind == 0 ? 2 : 4)) || (kind == 1 && any_prox)) { // query-major (experiments; trees that feed the match queue)
+    if (!(b->ctx->item_order & (kind == 0 ? 2 : 4)) || (kind == 1 && any_prox && !(b->ctx->item_order & 8))) { // query-major (experiments; trees that feed the match queue)
       for (const DevItem& whole : items_bm)
         if (whole.kind == kind)
           for (uint64_t w = whole.blk_begin; w < whole.blk_end; w += wpi) {
@@ -1215,6 +1225,13 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   sa.q_tau_bin = b->d_q_tau_bin.p;
   sa.cand = b->d_cand.p;
   bool any_nearn = false;
+  if (use_packed && any_prox && b->ctx->prox_prune) { // pruning in front of the hit pass (mrk_kprune.h, prox_bounds)
+    const size_t words = (size_t)n * (NBINS + mrk::QSTRIDE);
+    if ((rc = b->d_lb.reserve(words))) return rc;
+    HIP_TRY(hipMemsetAsync(b->d_lb.p, 0, words * 4, st));
+    sa.q_hist_lb = b->d_lb.p;
+    sa.q_tau_lb = b->d_lb.p + (size_t)n * NBINS;
+  }
   if ((rc = bind_match_queues(b, mq_chunks, sa))) return rc;
   if (mq_chunks[0] || mq_chunks[1] || mq_chunks[2]) HIP_TRY(hipMemsetAsync(b->d_mq_count.p, 0, 3 * mrk::MQ_SHARDS * 4, st));
   if (!b->gen_progs.empty()) {
@@ -1288,6 +1305,9 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
     se.h_flags = b->h_flags.p;
     se.h_cand_n = b->h_cand_n.p;
     if (!b->rows_dst) se.h_keys = b->h_keys.p, se.h_cnt = b->h_cnt.p, se.h_total = b->h_total.p;
+    // a standing rows destination (shard exchange): the sort pass writes the exchange rows itself
+    se.rows_dst = b->rows_dst;
+    se.declined = nullptr;
     launch_select(se, st2);
   } else
     launch_merge(ma, st2);
@@ -1302,7 +1322,7 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
     }
     b->decl_dirty = any;
   }
-  if (b->rows_dst) { // standing export for the shard exchange
+  if (b->rows_dst && (!use_packed || b->any_declined)) { // standing export for the shard exchange (the packed path's sort pass wrote the rows already, unless a query was declined: those rows are marked here)
     PackRowsArgs pa{};
     pa.keys = b->d_out_keys.p;
     pa.cnt = b->d_out_cnt.p;

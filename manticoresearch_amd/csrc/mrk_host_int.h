@@ -37,12 +37,14 @@ struct mrk_ctx {
   int bm_min_windows = 128;       // ... and the least windows per work item (a wave's fixed costs show on short runs)
   int pk_min_items = 2048;        // block-scan kernel: a batch with fewer work items has its block ranges cut finer (>= one block per wave)
   int exchange_part = 1;          // mrk_shard_exchange partitions the merge by query (all-to-all of row slices); 0 = all-gather, every rank merges everything
+  int prox_prune = 1;             // proximity rankers: matches whose weight upper bound cannot reach the top K skip the hit pass (counted, not ranked)
+  int exchange_self_rccl = 0;     // one rank: still send the rows to itself through RCCL (rehearsal of the collective path)
   int item_order = 7;             // work items of different queries interleaved (piece-major): 1 = block scan, 2 = bitmap AND, 4 = bitmap trees; 0 = query-major
   int bt_target_items = 6144;     // ... and the tree kernel over bitmap words
   int bt_cover_inv = 32;          // trees whose candidate cover holds >= 1/bt_cover_inv of the docs run on bitmap words (0 = never)
   int gen_lane_hits = 256;        // generic evaluator: hits (16 B) of per-lane list memory, GEN_GRID * 256 lanes
   int gen_spill_mb = 1024;        // ... and the shared area for lists beyond a lane's slice (exhausted: the query fails loudly)
-  int mq_max_chunks = 1 << 20;    // cap of a batch's match queue, in 64-entry chunks of 1792 B (a fuller queue flags its queries: rerun alone)
+  int mq_max_chunks = 1 << 22;    // cap of a batch's match queue, in 64-entry chunks of 1792 B (a fuller queue flags its queries: rerun alone)
 };
 
 struct HostTerm {

@@ -17,9 +17,12 @@ struct MqWriter {
 __device__ __forceinline__ uint32_t mq_take(const MatchQueue& MQ, MqWriter& W) {
   if (!W.left) {
     // own shard first, then whichever still has room: together the shards hold every chunk the batch can produce, but a
-    // single busy workgroup may need more than its own shard's share
+    // single busy workgroup may need more than its own shard's share.  A shard that is known to be full is passed over with a
+    // plain load: once the whole queue is full every further reservation used to cost 64 returning atomics (a config-5 launch
+    // of 1024 queries that outgrew its queue took 0.9 s in the scan alone).
     for (uint32_t k = 0; k < (uint32_t)MQ_SHARDS && !W.left; ++k) {
       const uint32_t shard = (blockIdx.x + k) & (MQ_SHARDS - 1);
+      if (__hip_atomic_load(MQ.count + shard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= MQ.cap) continue;
       uint32_t got = 0;
       if (lane_id() == 0) got = atomicAdd(MQ.count + shard, (uint32_t)MQ_BATCH);
       got = rdlane(got, 0);

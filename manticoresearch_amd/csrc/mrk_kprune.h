@@ -81,6 +81,62 @@ __device__ __forceinline__ void hist_add_keys(uint32_t* __restrict__ gh, const u
   }
 }
 
+// the same for one bin per lane (v = the lane holds one)
+__device__ __forceinline__ void hist_add_bins(uint32_t* __restrict__ gh, bool v, uint32_t bin) {
+  const uint32_t lane = lane_id();
+  const uint32_t mine = v ? bin : 0xFFFFFFFFu;
+  uint64_t left = __ballot(v);
+  while (left) {
+    const uint32_t l = (uint32_t)__builtin_ctzll(left);
+    const uint32_t b = rdlane(mine, l);
+    const uint64_t same = __ballot(mine == b);
+    if (lane == l) atomicAdd(gh + b, (uint32_t)__popcll(same));
+    left &= ~same;
+  }
+}
+
+// position of the n-th (0-based) set bit of a wave-uniform 64-bit mask, n per lane (n < popcount)
+__device__ __forceinline__ uint32_t nth_set_bit64(uint64_t m, uint32_t n) {
+  uint32_t pos = 0, w = (uint32_t)m;
+  uint32_t c = (uint32_t)__popc(w);
+  if (n >= c) n -= c, pos = 32u, w = (uint32_t)(m >> 32);
+  c = (uint32_t)__popc(w & 0xFFFFu);
+  if (n >= c) n -= c, pos += 16u, w >>= 16;
+  c = (uint32_t)__popc(w & 0xFFu);
+  if (n >= c) n -= c, pos += 8u, w >>= 8;
+  c = (uint32_t)__popc(w & 0xFu);
+  if (n >= c) n -= c, pos += 4u, w >>= 4;
+  c = (uint32_t)__popc(w & 0x3u);
+  if (n >= c) n -= c, pos += 2u, w >>= 2;
+  if (n >= (w & 1u)) pos += 1u;
+  return pos;
+}
+
+// Bounds of a match's weight under the proximity rankers BEFORE its hits are read (round 3).  RankerState_Proximity_fn
+// (sphinxsearch.cpp:1320-1438) adds 1000 x sum_f LCS[f] x w[f] to the BM25 part; LCS[f] is the longest run of hits of
+// field f whose query positions advance with their positions.  Without repeated keywords such a run holds every keyword at
+// most once, and a single hit already makes a run of one: with cnt_f = the number of hit-emitting keywords that have field f
+// in their (queried) field mask -- both known from the doclists --, 1 <= LCS[f] <= cnt_f wherever cnt_f > 0.  The scan keeps a
+// histogram of the LOWER bounds: K docs whose lower bound reaches bin T prove that the K-th best weight reaches it, and a doc
+// whose UPPER bound stays below T cannot enter the top K -- it is counted (total_found) and never travels to the hit pass.
+__device__ __forceinline__ void prox_bounds(uint32_t ranker, float acc, uint32_t emit, const uint32_t* kf, int nk, const int32_t* fw, uint32_t nw,
+                                            uint32_t index_weight, uint32_t& wlo, uint32_t& whi) {
+  int lo = 0, hi = 0;
+  for (uint32_t f = 0; f < nw; ++f) {
+    int cnt = 0;
+    for (int k = 0; k < nk; ++k) cnt += (int)(((emit >> k) & 1u) & ((kf[k] >> f) & 1u));
+    const int w = fw[f], one = cnt ? 1 : 0;
+    lo += w >= 0 ? w * one : w * cnt;
+    hi += w >= 0 ? w * cnt : w * one;
+  }
+  const int32_t bm = (int32_t)((acc + 0.5f) * 1000.0f);
+  if (ranker == MRK_RANK_PROXIMITY_BM25)
+    wlo = (uint32_t)bm + (uint32_t)lo * 1000u, whi = (uint32_t)bm + (uint32_t)hi * 1000u;
+  else
+    wlo = (uint32_t)lo, whi = (uint32_t)hi;
+  wlo *= index_weight, whi *= index_weight;
+}
+
 // exact hit count of a doc whose packed tf saturated (>= 255)
 static __device__ uint32_t exc_tf(const DevSegment& seg, const DevTerm& T, uint32_t rowid) {
   const uint64_t* __restrict__ e = seg.pk_exc + T.exc_first;

@@ -40,7 +40,10 @@ constexpr int BT_WORDS = 64;          // words per window
 constexpr int BT_BURST = 4;           // windows whose bitmap words are requested back to back (one memory round trip per burst)
 
 struct __align__(16) BtWaveLds {
-  uint64_t cbuf[BT_CBUF];
+  union { // a pass either weighs its matches itself (candidate buffer) or hands them to the hit pass (pending queue chunk)
+    uint64_t cbuf[BT_CBUF];
+    uint32_t pend[MQ_PLANES * 64]; // survivors of the pruning in front of the hit pass, plane-major, until 64 make a chunk
+  };
   uint32_t q_row[BT_QCAP];
   uint32_t q_pm[BT_QCAP]; // keywords present in the doc
   uint32_t q_rank[BT_KW][BT_QCAP];
@@ -53,6 +56,7 @@ struct __align__(16) BtSmem {
   uint32_t hist_lock;
   uint32_t rank[256];
   float tfidf[BT_KW][256];
+  int32_t fw[8]; // the field weights (prox_bounds)
 };
 
 // the two docs lane l owns of block kj of a keyword (rowids, INF past the block's end) and the first possible rowid of the
@@ -81,12 +85,16 @@ __device__ __forceinline__ void bt_load_block(const DevSegment& seg, const DevTe
   e1 = ok1 ? r1 : INF_ROWID;
 }
 
-__global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
+// PRUNE: the instance that bounds hit-ranked matches' weights and keeps the hopeless ones out of the match queue (launched when the
+// batch has the lower-bound histograms: ScanArgs::q_hist_lb)
+template <bool PRUNE>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void scan_bt_kernel(ScanArgs a) {
   __shared__ BtSmem s;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= a.n_items) return;
   const DevItem item = a.items[blockIdx.x];
   const DevQuery* __restrict__ Q = a.queries + item.query;
+  if (__hip_atomic_load(a.q_flags + Q->out_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & QF_OVERFLOW) return; // (rerun alone by the host anyway: see scan_pk_kernel)
   const uint32_t nterms = Q->n_terms < (uint32_t)BT_KW ? Q->n_terms : (uint32_t)BT_KW;
   const uint32_t K = Q->k, ranker = Q->ranker, oq = Q->out_q, n_nodes = Q->n_nodes;
   const uint32_t nw = Q->n_weights < 8u ? Q->n_weights : 8u;
@@ -107,7 +115,13 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
         if (tid & (1u << f)) rk += (uint32_t)Q->weights[f];
     s.rank[tid] = rk;
     if (!tid) s.hist_lock = 0;
+    if (tid < 8) s.fw[tid] = tid < nw ? Q->weights[tid] : 0;
   }
+  // prune in front of the hit pass (mrk_kprune.h, prox_bounds): proximity rankers over distinct keywords, nothing that needs the exact weight of every match
+  const bool prune_prox = PRUNE && need_hits && a.q_hist_lb && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && !(Q->tree_flags & TF_DUPES) &&
+                          Q->n_wfilters == 0 && Q->bin_mode == BIN_WEIGHT;
+  uint32_t* __restrict__ ghist_lb = prune_prox ? a.q_hist_lb + (uint64_t)oq * NBINS : nullptr;
+  uint32_t* __restrict__ gtau_lb = prune_prox ? a.q_tau_lb + (size_t)oq * QSTRIDE : nullptr;
   const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
   const int32_t bin_lo = Q->bin_lo;
   const uint32_t cand_cap = Q->cand_cap;
@@ -154,6 +168,19 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
 
   uint32_t total = 0, tau_bin = 0, cn = 0, qn = 0;
   MqWriter mqw;
+  // pruned hit-ranked matches: the survivors of a scoring round are compacted into the wave's pending chunk (LDS) until 64 are there
+  uint32_t tau_lb = 0, lb_rounds = 0, lb_added = 0, pend_n = 0;
+  auto write_chunk = [&](const uint32_t* v, uint32_t n) { // one chunk of the HBM match queue from registers: lane l = entry l, n entries
+    const MatchQueue& MQ = a.mq[0];
+    const uint32_t c = mq_take(MQ, mqw);
+    if (c != 0xFFFFFFFFu) {
+      uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
+#pragma unroll
+      for (int i = 0; i < MQ_PLANES; ++i) d[64 * i] = v[i];
+      if (lane == 0) MQ.hdr[c] = item.query | (n << 24);
+    } else if (lane == 0)
+      atomicOr(a.q_flags + oq, QF_OVERFLOW);
+  };
 
   auto publish = [&]() {
     if (cn) {
@@ -264,27 +291,62 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
       total += valid ? 1u : 0u;
       return;
 #endif
-      const MatchQueue& MQ = a.mq[0];
-#if MRK_BTEXP == 6 // stores without the allocator: a private slot per wave
-      const uint32_t c = (blockIdx.x * WAVES + wave) % (MQ.cap * MQ_SHARDS);
-      total += valid ? 1u : 0u;
-#else
-      const uint32_t c = mq_take(MQ, mqw);
-#endif
-#if MRK_BTEXP == 5 // the allocator without the stores
-      total += valid ? 1u : 0u;
-      return;
-#endif
-      if (c != 0xFFFFFFFFu) {
-        uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
-        d[0] = row;
-        d[64] = __float_as_uint(v0);
-        d[128] = (f0 & 0xffu) | (a0 << 8);
+      uint32_t vals[MQ_PLANES];
+      vals[0] = row, vals[1] = __float_as_uint(v0), vals[2] = (f0 & 0xffu) | (a0 << 8);
 #pragma unroll
-        for (int t = 0; t < MAX_PROX_TERMS; ++t) d[192 + 64 * t] = href[t];
-        if (lane == 0) MQ.hdr[c] = item.query | (n << 24);
-      } else if (lane == 0)
-        atomicOr(a.q_flags + oq, QF_OVERFLOW);
+      for (int t = 0; t < MAX_PROX_TERMS; ++t) vals[3 + t] = href[t];
+      if (!prune_prox) {
+        write_chunk(vals, n);
+        return;
+      }
+      // bounds of the weight from what the doclists say; the lower bounds feed the query's histogram, the upper bound is tested
+      uint32_t wlo, whi;
+      prox_bounds(ranker, v0, a0, kf, BT_KW, s.fw, nw, index_weight, wlo, whi);
+      // (only lower bounds that reach the current threshold can raise it: the others are never counted -- an undercounted
+      // histogram only makes the threshold lower than it could be -- and once the threshold stands almost no round adds anything)
+      const uint32_t blo = bin_of(BIN_WEIGHT, bin_lo, bin_shift, (int32_t)wlo, 0u);
+      const bool counts = valid && blo >= tau_lb;
+      lb_added += (uint32_t)__popcll(__ballot(counts));
+      hist_add_bins(ghist_lb, counts, blo);
+      if (lb_added >= 256u || (lb_rounds & 63u) == 0u) { // the wave added enough to matter / now and then: recompute
+        if (lb_added >= 256u) {
+          const uint32_t tb = threshold_bin(ghist_lb, K);
+          if (tb > tau_lb) {
+            tau_lb = tb;
+            if (lane == 0) atomicMax(gtau_lb, tb);
+          }
+          lb_added = 0;
+        }
+      }
+      if ((lb_rounds++ & 3u) == 0u) {
+        const uint32_t gt = __hip_atomic_load(gtau_lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gt > tau_lb) tau_lb = gt;
+      }
+      const bool keep = valid && bin_of(BIN_WEIGHT, bin_lo, bin_shift, (int32_t)whi, 0u) >= tau_lb;
+      total += (valid && !keep) ? 1u : 0u; // a match all the same (CSphMatchQueue::PushT counts every push): rank_kernel counts the ones it sees
+      const uint64_t km = __ballot(keep);
+      const uint32_t kcnt = (uint32_t)__popcll(km);
+      if (!kcnt) return;
+      // survivors -> slots [pend_n, pend_n + kcnt) of the pending chunk; a full chunk leaves for the queue
+      const uint32_t slot = pend_n + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+      if (keep && slot < 64u) {
+#pragma unroll
+        for (int i = 0; i < MQ_PLANES; ++i) L.pend[i * 64 + slot] = vals[i];
+      }
+      if (pend_n + kcnt >= 64u) {
+        wave_lds_fence();
+        uint32_t full[MQ_PLANES];
+#pragma unroll
+        for (int i = 0; i < MQ_PLANES; ++i) full[i] = L.pend[i * 64 + lane];
+        write_chunk(full, 64u);
+        wave_lds_fence();
+        if (keep && slot >= 64u) {
+#pragma unroll
+          for (int i = 0; i < MQ_PLANES; ++i) L.pend[i * 64 + slot - 64u] = vals[i];
+        }
+        pend_n = pend_n + kcnt - 64u;
+      } else
+        pend_n += kcnt;
       return;
     }
     bool push = false;
@@ -443,6 +505,13 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
     } // windows of the burst
   }
   if (qn) score(0, qn);
+  if (PRUNE && pend_n) {
+    wave_lds_fence();
+    uint32_t part[MQ_PLANES];
+#pragma unroll
+    for (int i = 0; i < MQ_PLANES; ++i) part[i] = L.pend[i * 64 + lane];
+    write_chunk(part, pend_n);
+  }
   if (need_hits) mq_close(a.mq[0], mqw, item.query);
   if (cn) publish();
   {
@@ -454,7 +523,10 @@ __global__ __launch_bounds__(WG) void scan_bt_kernel(ScanArgs a) {
 
 void launch_scan_bt(const ScanArgs& a, void* stream) {
   if (!a.n_items) return;
-  hipLaunchKernelGGL(scan_bt_kernel, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
+  if (a.q_hist_lb)
+    hipLaunchKernelGGL(scan_bt_kernel<true>, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(scan_bt_kernel<false>, dim3(a.n_items), dim3(WG), 0, (hipStream_t)stream, a);
 }
 
 } // namespace mrk

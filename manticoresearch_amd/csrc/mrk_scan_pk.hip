@@ -72,6 +72,9 @@ __global__ __launch_bounds__(WG) void scan_pk_kernel(ScanArgs a) {
   if (blockIdx.x >= a.n_items) return;
   const DevItem item = a.items[blockIdx.x];
   const DevQuery* __restrict__ Q = a.queries + item.query;
+  // a query that already overflowed (candidate list or match queue) is rerun alone by the host whatever else this launch finds for it:
+  // its remaining work items are not worth their time -- least of all when the queue they would write to is full
+  if (__hip_atomic_load(a.q_flags + Q->out_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & QF_OVERFLOW) return;
   const uint32_t nterms = Q->n_terms, K = Q->k, ranker = Q->ranker;
   const uint32_t nw = Q->n_weights < 8u ? Q->n_weights : 8u;
   const uint32_t index_weight = Q->index_weight;

@@ -291,6 +291,16 @@ __global__ __launch_bounds__(WG) void sel_sort_kernel(SelectArgs a) {
   for (uint32_t i = tid; i < m; i += WG) a.out_keys[(uint64_t)q * KCAP + i] = s.cand[i];
   if (a.h_keys)
     for (uint32_t i = tid; i < m; i += WG) a.h_keys[(uint64_t)q * KCAP + i] = s.cand[i];
+  if (a.rows_dst) { // the row of the shard exchange: a query whose candidate list overflowed leaves empty with MRK_ROW_RERUN (pack_rows_kernel's rule)
+    const bool bad = (a.q_flags[q] & (QF_OVERFLOW | QF_FSM)) != 0;
+    const uint32_t nr = bad ? 0u : m;
+    uint64_t* __restrict__ row = a.rows_dst + (uint64_t)q * ROW_WORDS;
+    for (uint32_t i = tid; i < (uint32_t)KCAP; i += WG) row[i] = i < nr ? s.cand[i] : 0ull;
+    if (tid == 0) {
+      row[KCAP] = nr;
+      row[KCAP + 1] = bad ? ROW_RERUN : (a.q_total[q] & ~ROW_FLAG_MASK);
+    }
+  }
   if (tid == 0) {
     a.out_cnt[q] = m;
     if (a.h_cnt) a.h_cnt[q] = m;

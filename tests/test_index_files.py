@@ -370,6 +370,31 @@ def test_rt_ram_rejects_damage(tmp_path):
     assert n_err > 100
 
 
+def test_rt_ram_row_count_that_wraps_the_dead_map_size(tmp_path):
+    """A RAM segment's row count is an untrusted dword: (rows + 31) / 32 wraps to 0 words for rows >= 0xFFFFFFE1 -- the dead-row map
+    came out empty and the count of dead rows read past it (advisor, round 2: SIGSEGV with rows = 0xFFFFFFF0 and the 4-byte map
+    removed).  Such a file must end in an error code, with the map in place and with any 4 bytes behind the header removed."""
+    import manticoresearch_amd as m
+
+    meta = open(os.path.join(IDX, "t406_index.meta"), "rb").read()
+    ram = open(os.path.join(IDX, "t406_index.ram"), "rb").read()
+    p = str(tmp_path / "x")
+    open(p + ".meta", "wb").write(meta)
+    n = 0
+    for rows in (0xFFFFFFF0, 0xFFFFFFFF, 0xFFFFFFE1, 0x80000000):
+        cuts = [None] + list(range(12, len(ram) - 4, 4))
+        for cut in cuts:
+            rb = bytearray(ram)
+            rb[8:12] = struct.pack("<I", rows)
+            if cut is not None:
+                del rb[cut:cut + 4]
+            open(p + ".ram", "wb").write(rb)
+            with pytest.raises(m.MrkError):
+                m.open_rt_ram(p)
+            n += 1
+    assert n > 20
+
+
 def test_blob_pool_of_reference_files():
     """The blob pool travels with the index: the string attribute of test_233's index (the used part of its .spb: the first qword
     is the used size) and of the release-3.2.0 RT segment decode to the values the tests' model.bin shows."""

@@ -100,5 +100,22 @@ for _ in range(n_iter):
         L.mrk_rt_ram_free(rt)
     else:
         err += 1
-print("RT RAM chunks: opened", ok, "rejected", err, "-- no sanitizer report")
+# fixed cases (round 3): a segment's row count chosen so that (rows + 31) / 32 wraps in 32 bits, with the dead-row map in place and with
+# every 4-byte piece behind the header removed in turn
+fixed = 0
+for name in ("t406_idx320", "t406_index"):
+    meta, ram = open(src + name + ".meta", "rb").read(), open(src + name + ".ram", "rb").read()
+    open(w + "/z.meta", "wb").write(meta)
+    for rows in (0xFFFFFFF0, 0xFFFFFFFF, 0xFFFFFFE1, 0x80000000, 0x7FFFFFFF):
+        for cut in [None] + list(range(12, len(ram) - 4, 4)):
+            rb = bytearray(ram)
+            rb[8:12] = struct.pack("<I", rows)
+            if cut is not None:
+                del rb[cut:cut + 4]
+            open(w + "/z.ram", "wb").write(bytes(rb))
+            rt = C.c_void_p()
+            if L.mrk_rt_ram_open((w + "/z").encode(), C.byref(rt)) == 0:
+                L.mrk_rt_ram_free(rt)
+            fixed += 1
+print("RT RAM chunks: opened", ok, "rejected", err, "+", fixed, "fixed row-count cases -- no sanitizer report")
 PY

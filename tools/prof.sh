@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --docs $DOCS --steps 2 --warmup 1 --no-cpu-baseline --no-config3 --latency-samples 0 --strata $STRATA $EXTRA"
+ARGS="$ROOT/bench.py --docs $DOCS --steps 2 --warmup 1 --no-cpu-baseline --no-config3 --no-config5 --latency-samples 0 --strata $STRATA $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $OUT/pmc1 -o p -- python3 $ARGS > $OUT/pmc1.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $OUT/pmc2 -o p -- python3 $ARGS > $OUT/pmc2.log 2>&1

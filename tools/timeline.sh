@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # DIST=1: the sharded path with ONE rank (env rendezvous: no launcher process between the profiler and the program)
 if [ -n "$DIST" ]; then export MRK_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533; EXTRA_ARGS="--gpus 1"; fi
-rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/raw -o t -- python3 $ROOT/bench.py --docs $DOCS --steps 12 --warmup 3 --no-cpu-baseline --no-config3 --latency-samples 0 $EXTRA_ARGS "$@" > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/raw -o t -- python3 $ROOT/bench.py --docs $DOCS --steps 12 --warmup 3 --no-cpu-baseline --no-config3 --no-config5 --latency-samples 0 $EXTRA_ARGS "$@" > $OUT/bench.json 2> $OUT/bench.err
 python3 - <<PY
 import csv, glob, collections
 out = "$OUT"

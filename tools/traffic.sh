@@ -17,7 +17,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline --no-config3 --latency-samples 0 --strata cc"
+ARGS="$ROOT/bench.py --docs $DOCS --steps 4 --warmup 1 --no-cpu-baseline --no-config3 --no-config5 --latency-samples 0 --strata cc"
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/calib -o c -- $ROOT/tools/calib/fetch_calib 4 3 > $OUT/calib.json 2> $OUT/calib.log
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o w -- python3 $ARGS > $OUT/write.log 2>&1
@@ -29,7 +29,9 @@ for S in sc ss; do
   rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch_$S -o f -- python3 ${ARGS/--strata cc/--strata $S} > $OUT/fetch_$S.log 2>&1
 done
 python3 - <<PY
-import csv, json, glob, re
+import csv, json, glob, re, sys
+sys.path.insert(0, "$ROOT")
+import bench
 def launches(d, name, pat):
     v = {}
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % d, recursive=True):
@@ -74,7 +76,7 @@ for S in ("sc", "ss"):
     n = max(cand, key=lambda k: mean(cand[k]))
     strata[S] = {"kernel": n, "FETCH_SIZE_bytes_raw": mean(cand[n]), "launches": len(cand[n]),
                  "measured_bytes_per_launch": int(mean(cand[n]) / c_gather), "correction": "FETCH_SIZE / c_gather4_dense (block words and probes are 4 B/lane accesses)"}
-out = {"docs": $DOCS, "queries": 256, "skiplist_block": 128, "kernel": big, "kernel_tag": "bm" if "scan_bm" in big else "pk",
+out = {"docs": $DOCS, "queries": 256, "skiplist_block": 128, "kernel": big, "kernel_sources_sha": bench.kernel_sources_sha(), "kernel_tag": "bm" if "scan_bm" in big else "pk",
        "FETCH_SIZE_bytes_raw": fm, "WRITE_SIZE_bytes_raw": wm, "FETCH_SIZE_bytes_raw_streams_only": sm,
        "launches": {"fetch": len(f), "write": len(w), "fetch_streams_only": len(s)},
        "strata": strata, "calibration": calib, "c_stream4": c_stream4, "c_gather4_dense": c_gather,
