@@ -502,6 +502,28 @@ int mrk_rt_ram_open(const char* path_prefix, mrk_rt_ram** out);
 uint32_t mrk_rt_ram_segments(const mrk_rt_ram* rt);
 int mrk_rt_ram_take(mrk_rt_ram* rt, uint32_t i, mrk_host_index** out);
 void mrk_rt_ram_free(mrk_rt_ram* rt);
+/* A LIVE RAM segment handed over in memory (round 3): the byte vectors of an RtSegment_t (sphinxrt.h:140-149) -- m_dWords (the
+   dictionary: keywords front-coded / word-id deltas, restarted every words_checkpoint entries), m_dDocs, m_dHits in the RT codecs --
+   decoded and re-emitted in the disk format exactly as mrk_rt_ram_open does for the segments of a .ram file (same code).  The
+   result is an ordinary mrk_host_index (mrk_host_index_spd / _dict / _find_word ...): mrk_segment_create it once when the segment
+   appears (RAM segments are immutable once committed), hand its dead-row map and attribute rows over with
+   mrk_segment_set_dead_rows / _set_attrs, and let the ranker binding pick it when RtIndex_c rebinds the ranker to that segment
+   (ISphRanker::Reset, sphinxrt.cpp:6313-6314).  rows = RtSegment_t::m_uRows; words_checkpoint = RtIndex_c::m_iWordsCheckpoint. */
+typedef struct {
+  const uint8_t* words;
+  uint64_t words_len;
+  const uint8_t* docs;
+  uint64_t docs_len;
+  const uint8_t* hits;
+  uint64_t hits_len;
+  uint32_t rows;
+  uint32_t word_dict;        /* 1 = dict=keywords, 0 = dict=crc */
+  uint32_t words_checkpoint;
+  uint32_t skiplist_block_size; /* of the re-encoded doclists; 0 = 128 */
+  uint32_t hit_format;       /* MRK_HITFMT_* of the re-encoded doclists */
+  uint32_t n_fields;
+} mrk_rt_segment_desc;
+int mrk_rt_segment_open(const mrk_rt_segment_desc* desc, mrk_host_index** out);
 
 /* ---- query text -> tree (host only) ------------------------------------------------------------------------------------
    The caller side of the path: the extended query syntax (sphParseExtendedQuery: sphinxquery.y:57-125 grammar; the lexer
@@ -522,6 +544,11 @@ void mrk_rt_ram_free(mrk_rt_ram* rt);
 typedef struct mrk_parsed_query mrk_parsed_query;
 int mrk_query_parse(const char* text, const char* const* field_names, uint32_t n_fields, uint32_t min_word_len,
                     mrk_parsed_query** out);
+/* sphTransformExtendedQuery (sphinx.cpp:15345-15359), the part every query goes through between the parser and the ranker:
+   a quorum with threshold 1 -> the OR of its words (TransformQuorum); AND groups among a NEAR node's operands are replaced by their
+   children, '(a b c) NEAR/N d' -> 'a NEAR/N b NEAR/N c NEAR/N d' (TransformNear).  In place.  Not restated: TransformBigrams (needs
+   a bigram_index index) and the boolean simplifier (sphOptimizeBoolean: OPTION boolean_simplify, off by default). */
+int mrk_parsed_transform(mrk_parsed_query* q);
 void mrk_parsed_free(mrk_parsed_query* q);
 int32_t mrk_parsed_n_nodes(const mrk_parsed_query* q);
 int32_t mrk_parsed_root(const mrk_parsed_query* q); /* -1: the query holds no keyword (matches nothing) */

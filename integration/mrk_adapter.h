@@ -43,6 +43,13 @@ struct MrkIndexBinding_t
 	bool					m_bWordDict = true;		///< dict=keywords (lookup by m_sDictWord) or dict=crc (lookup by word id)
 };
 
+/// RT RAM segments (round 3): PerformFullTextSearch rebinds the ONE ranker to every RAM segment (ISphRanker::Reset, sphinxrt.cpp:6313-6314).
+/// The host keeps a device segment per RtSegment_t (mrk_rt_segment_open over the segment's m_dWords / m_dDocs / m_dHits once, when the
+/// segment is committed -- RAM segments never change afterwards --, then mrk_segment_create; dead rows and attribute rows handed over
+/// with mrk_segment_set_dead_rows / _set_attrs) and tells the adapter how to find it from the setup object Reset() receives.
+/// nullptr = that segment has no device copy (the caller must then not have offered the query to the device at all).
+typedef const MrkIndexBinding_t * (*MrkSegmentLookup_fn) ( const ISphQwordSetup & tSetup, void * pUser );
+
 /// a flattened query: the arrays mrk_query points into
 struct MrkFlatQuery_t
 {
@@ -438,6 +445,15 @@ public:
 		Bind ( tSetup );
 	}
 
+	/// what Reset() needs to run the same query against the next RAM segment: the parsed query and its context (they outlive the ranker:
+	/// DoFullTextSearch holds them, sphinxrt.cpp:6387-6441) and the host's segment lookup
+	void EnableRebind ( const XQQuery_t & tXQ, const CSphQuery & tQuery, const CSphQueryContext & tCtx, const ISphSchema & tIndexSchema, int iIndexWeight,
+		MrkSegmentLookup_fn fnLookup, void * pUser )
+	{
+		m_pXQ = &tXQ; m_pQuery = &tQuery; m_pQueryCtx = &tCtx; m_pIndexSchema = &tIndexSchema; m_iIndexWeight = iIndexWeight;
+		m_fnLookup = fnLookup; m_pLookupUser = pUser;
+	}
+
 	/// run the query on the device; false = the device declined (MRK_E_UNSUPPORTED) or failed: the caller falls back to ExtRanker_*.
 	/// With a batcher the query joins whatever the other workers have queued: one mrk_batch_submit for
 	/// all of them, the calling coroutine's thread sleeps on a condition variable meanwhile (no HIP on its 128 KB stack); the rows
@@ -490,12 +506,37 @@ public:
 			m_tReplay.Finish ( m_pSorter );
 	}
 
-	/// RT rebinding to the next RAM segment (sphinxrt.cpp:6313-6314) does not come here: RAM segments are not on the device
-	/// path (MrkCreateRanker is only offered disk chunks); kept for interface completeness
+	/// RT rebinding to the next RAM segment (PerformFullTextSearch, sphinxrt.cpp:6313-6314): the sorter keeps collecting, the ranker moves
+	/// on.  What the previous segment still owed the sorter's total is settled first; then the query is flattened against the NEXT
+	/// segment's dictionary (keyword ids are per dictionary) and run on that segment's device copy.  A segment without a device copy, or
+	/// a failure, ends this segment's stream empty and leaves a warning: the host only offers the device RT queries whose segments all
+	/// have one (MrkCreateRanker's contract).
 	void Reset ( const ISphQwordSetup & tSetup ) final
 	{
+		m_tReplay.Finish ( m_pSorter );
 		Bind ( tSetup );
 		m_tReplay.Exhaust();
+		if ( !m_fnLookup )
+			return;
+		const MrkIndexBinding_t * pNext = m_fnLookup ( tSetup, m_pLookupUser );
+		CSphString sWhy;
+		if ( pNext && pNext->m_pSegment && pNext->m_pFiles )
+		{
+			m_tIndex = *pNext;
+			CSphScopedPtr<MrkFlatQuery_t> pFlat ( new MrkFlatQuery_t );
+			if ( FlattenXQ ( *m_pXQ, *m_pQuery, *m_pQueryCtx, tSetup, m_tIndex, *m_pIndexSchema, m_iIndexWeight, *pFlat.Ptr(), sWhy ) )
+			{
+				m_pFlat = pFlat.LeakPtr();
+				if ( Run ( sWhy ) )
+					return;
+			}
+		} else
+			sWhy = "RAM segment without a device copy";
+		mrk_result tNone;
+		memset ( &tNone, 0, sizeof(tNone) );
+		m_tReplay.Start ( tNone, 1 );
+		if ( tSetup.m_pWarning )
+			tSetup.m_pWarning->SetSprintf ( "device ranker: %s", sWhy.cstr() );
 	}
 
 	bool IsCache() const final { return false; }
@@ -522,6 +563,13 @@ private:
 	const CSphIndex *			m_pIndex = nullptr;
 	CSphQueryContext *			m_pCtx = nullptr;
 	MrkFrameReplay_T<CSphMatch>	m_tReplay;
+	const XQQuery_t *			m_pXQ = nullptr;			///< EnableRebind
+	const CSphQuery *			m_pQuery = nullptr;
+	const CSphQueryContext *	m_pQueryCtx = nullptr;
+	const ISphSchema *			m_pIndexSchema = nullptr;
+	int							m_iIndexWeight = 1;
+	MrkSegmentLookup_fn			m_fnLookup = nullptr;
+	void *						m_pLookupUser = nullptr;
 	CSphVector<uint32_t>		m_dRowIDs;		///< the batcher copies the query's rows here (a shared batch is resubmitted at once)
 	CSphVector<int32_t>			m_dWeights;
 	CSphMatch					m_dMatches[FRAME];

@@ -71,6 +71,13 @@ class BatchStats(C.Structure):
                 ("n_items_bm", C.c_uint64), ("plan_ms", C.c_float), ("submit_ms", C.c_float)]
 
 
+class RtSegmentDesc(C.Structure):
+    """mrk_rt_segment_desc (include/mrk.h)"""
+    _fields_ = [("words", C.c_void_p), ("words_len", C.c_uint64), ("docs", C.c_void_p), ("docs_len", C.c_uint64), ("hits", C.c_void_p), ("hits_len", C.c_uint64),
+                ("rows", C.c_uint32), ("word_dict", C.c_uint32), ("words_checkpoint", C.c_uint32), ("skiplist_block_size", C.c_uint32),
+                ("hit_format", C.c_uint32), ("n_fields", C.c_uint32)]
+
+
 class BatcherStats(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("queries", C.c_uint64), ("max_batch", C.c_uint32), ("submit_ms", C.c_double), ("collect_ms", C.c_double),
                 ("flight_ms", C.c_double)]
@@ -167,7 +174,9 @@ SYMBOLS = [
     ("mrk_rt_ram_segments", C.c_uint32, [C.c_void_p]),
     ("mrk_rt_ram_take", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("mrk_rt_ram_free", None, [C.c_void_p]),
+    ("mrk_rt_segment_open", C.c_int, [C.POINTER(RtSegmentDesc), C.POINTER(C.c_void_p)]),
     ("mrk_query_parse", C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mrk_parsed_transform", C.c_int, [C.c_void_p]),
     ("mrk_parsed_free", None, [C.c_void_p]),
     ("mrk_parsed_n_nodes", C.c_int32, [C.c_void_p]),
     ("mrk_parsed_root", C.c_int32, [C.c_void_p]),

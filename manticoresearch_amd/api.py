@@ -122,6 +122,17 @@ def open_rt_ram(path_prefix: str) -> List[HostIndex]:
         L.mrk_rt_ram_free(rt)
 
 
+def open_rt_segment(words: bytes, docs: bytes, hits: bytes, rows: int, word_dict: bool = True, words_checkpoint: int = 64,
+                    skiplist_block_size: int = 128, hit_format: int = 1, n_fields: int = 1) -> HostIndex:
+    """A LIVE RAM segment handed over in memory (mrk_rt_segment_open): the three byte vectors of an RtSegment_t."""
+    wb, db, hb = (np.frombuffer(bytes(x), np.uint8) if len(x) else np.zeros(0, np.uint8) for x in (words, docs, hits))
+    d = _lib.RtSegmentDesc(wb.ctypes.data if wb.size else None, wb.size, db.ctypes.data if db.size else None, db.size, hb.ctypes.data if hb.size else None, hb.size,
+                           rows, int(word_dict), words_checkpoint, skiplist_block_size, hit_format, n_fields)
+    h = C.c_void_p()
+    check(lib().mrk_rt_segment_open(C.byref(d), C.byref(h)))
+    return _wrap_file_index(h)
+
+
 def _wrap_file_index(h) -> HostIndex:
     L = lib()
     info = _lib.IndexInfo()
@@ -248,16 +259,19 @@ class XQNode:
 
 
 def parse_query(text: str, field_names: Sequence[str] = (), min_word_len: int = 1,
-                lookup: "Union[None, HostIndex, Callable[[str], int]]" = None) -> Optional[XQNode]:
+                lookup: "Union[None, HostIndex, Callable[[str], int]]" = None, transform: bool = False) -> Optional[XQNode]:
     """The extended query syntax -> XQNode tree (mrk_query_parse: the sphinxquery.y grammar + XQParser_t lexer restated in
     csrc/mrk_query.cpp).  lookup resolves a keyword's text to its dictionary slot: a HostIndex opened from files
     (dict=keywords), or a callable; without it every term_id is -1 and XQKeyword.text carries the word.  None = a query
-    without keywords.  A syntax error raises MrkError with the reference's wording."""
+    without keywords.  A syntax error raises MrkError with the reference's wording.  transform=True also applies what every query
+    goes through between the parser and the ranker (mrk_parsed_transform: sphTransformExtendedQuery's quorum / NEAR rewrites)."""
     L = lib()
     names = (C.c_char_p * max(1, len(field_names)))(*[f.encode() for f in field_names])
     pq = C.c_void_p()
     check(L.mrk_query_parse(text.encode("utf-8"), names, len(field_names), min_word_len, C.byref(pq)))
     try:
+        if transform:
+            check(L.mrk_parsed_transform(pq))
         if isinstance(lookup, HostIndex):
             check(L.mrk_parsed_resolve(pq, lookup._owner.h))
         n, root = L.mrk_parsed_n_nodes(pq), L.mrk_parsed_root(pq)
@@ -651,7 +665,7 @@ def idf(term_docs: int, total_docs: int, plain: bool = False, normalized: bool =
     return float(lib().mrk_idf(term_docs, total_docs, int(plain), int(normalized), n_qwords, boost))
 
 
-__all__ = ["open_rt_ram", "SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
+__all__ = ["open_rt_ram", "open_rt_segment", "SPH_RANK_PROXIMITY_BM25", "SPH_RANK_BM25", "SPH_RANK_NONE", "SPH_RANK_WORDCOUNT", "SPH_RANK_PROXIMITY",
            "SPH_RANK_MATCHANY", "SPH_RANK_FIELDMASK", "SPH_RANK_SPH04",
            "parse_query", "SPH_QUERY_TERM", "SPH_QUERY_AND", "SPH_QUERY_OR", "SPH_QUERY_MAYBE", "SPH_QUERY_ANDNOT", "SPH_QUERY_PHRASE", "SPH_QUERY_PROXIMITY", "SPH_QUERY_QUORUM", "SPH_QUERY_BEFORE", "SPH_QUERY_NEAR", "SPH_QUERY_NOTNEAR", "SPH_QUERY_SENTENCE", "SPH_QUERY_PARAGRAPH",
            "SPH_HIT_FORMAT_PLAIN", "SPH_HIT_FORMAT_INLINE", "ALL_FIELDS", "DICT_DTYPE", "HostIndex", "open_index", "index_from_hits", "synth_index", "XQKeyword", "XQNode", "Query", "Filter", "Matches", "Context",

@@ -554,6 +554,79 @@ int rt_vector(Reader& r, size_t elem, const char* what, const char* name, std::v
   return MRK_OK;
 }
 
+// One RAM segment's dictionary, doclists and hitlists (the three byte vectors of RtSegment_t, sphinxrt.h:140-149, in the RT codecs:
+// LSB-first varints, sphinxrt.cpp:98-157) -> the postings as (word, rowid, hit) triples; shared by the .ram file reader and by
+// mrk_rt_segment_open (a live segment's vectors handed over in memory)
+static int rt_decode_segment(const uint8_t* words, size_t words_len, const uint8_t* docs, size_t docs_len, const uint8_t* hits, size_t hits_len, uint32_t rows,
+                             bool word_dict, uint32_t words_checkpoint, const char* name, uint32_t si, std::vector<uint64_t>& W, std::vector<uint32_t>& Rw,
+                             std::vector<uint32_t>& H, std::vector<char>& wtext, std::vector<uint32_t>& woff, std::vector<uint64_t>& wordids, uint32_t& term) {
+    // ---- walk the segment's dictionary: RtWordReader_t::UnzipWord (:528-575)
+    RtBytes wr{words, words_len};
+    uint8_t packed[260];
+    packed[0] = 0;
+    uint64_t wordid = 0, doc_off = 0;
+    uint32_t n_in_cp = 0;
+    term = 0;
+    while (wr.at < wr.n) {
+      if (++n_in_cp == words_checkpoint) doc_off = 0, n_in_cp = 1, wordid = word_dict ? wordid : 0;
+      if (word_dict) {
+        uint32_t match, delta;
+        const uint8_t pk = wr.p[wr.at++];
+        if (pk & 0x80u)
+          delta = ((pk >> 4) & 7u) + 1u, match = pk & 15u;
+        else {
+          delta = pk & 127u;
+          if (wr.at >= wr.n) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: truncated keyword", name, si);
+          match = wr.p[wr.at++];
+        }
+        if (match > packed[0] || match + delta > 255u || wr.n - wr.at < delta) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: bad front-coded keyword", name, si);
+        packed[0] = (uint8_t)(match + delta);
+        memcpy(packed + 1 + match, wr.p + wr.at, delta);
+        wr.at += delta;
+        woff.push_back((uint32_t)wtext.size());
+        wtext.insert(wtext.end(), packed + 1, packed + 1 + packed[0]);
+        wtext.push_back(0);
+      } else {
+        wordid += wr.zip();
+        wordids.push_back(wordid);
+      }
+      const uint64_t n_docs = wr.zip(), n_hits = wr.zip();
+      doc_off += wr.zip();
+      if (wr.bad || doc_off > docs_len || n_docs > docs_len || n_hits > hits_len + n_docs)
+        return mrk_fail(MRK_E_FORMAT, "%s: segment %u: dictionary entry %u points past the doclists", name, si, term);
+      // ---- its docs: RtDocReader_t::UnzipDoc (:397-421); rowid deltas start from INVALID_ROWID (~0: the first delta wraps)
+      RtBytes dr{docs, docs_len, (size_t)doc_off};
+      uint32_t rowid = 0xFFFFFFFFu;
+      for (uint64_t d = 0; d < n_docs; ++d) {
+        rowid += (uint32_t)dr.zip();
+        dr.zip(); // field mask (recomputed from the hits by the writer below)
+        const uint64_t dh = dr.zip();
+        uint32_t hit1 = 0;
+        uint64_t hoff = 0;
+        if (dh == 1) {
+          const uint64_t a = dr.zip(), b = dr.zip();
+          hit1 = (uint32_t)(a + (b << 24));
+        } else
+          hoff = dr.zip();
+        if (dr.bad || rowid >= rows || dh == 0 || (dh != 1 && hoff > hits_len))
+          return mrk_fail(MRK_E_FORMAT, "%s: segment %u: word %u: bad doclist entry", name, si, term);
+        if (dh == 1) {
+          W.push_back(term + 1), Rw.push_back(rowid), H.push_back(hit1);
+          continue;
+        }
+        RtBytes hr{hits, hits_len, (size_t)hoff}; // RtHitReader_t::UnzipHit (:612-622)
+        uint32_t last = 0;
+        for (uint64_t k = 0; k < dh; ++k) {
+          last += (uint32_t)hr.zip();
+          if (hr.bad) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: word %u: hitlist runs past the segment", name, si, term);
+          W.push_back(term + 1), Rw.push_back(rowid), H.push_back(last);
+        }
+      }
+      ++term;
+    }
+    return MRK_OK;
+}
+
 int rt_open(const char* path_prefix, mrk_rt_ram* rt) {
   const std::string base(path_prefix), mname = base + ".meta", rname = base + ".ram";
   std::vector<uint8_t> meta, ram;
@@ -619,74 +692,15 @@ int rt_open(const char* path_prefix, mrk_rt_ram* rt) {
     }
     if ((rc = rt_vector(r, 8, "ram-infixes", rname.c_str(), infix))) return rc;
 
-    // ---- walk the segment's dictionary: RtWordReader_t::UnzipWord (:528-575)
     std::vector<uint64_t> W;
     std::vector<uint32_t> Rw, H;
     std::vector<char> wtext;
     std::vector<uint32_t> woff;
     std::vector<uint64_t> wordids;
-    RtBytes wr{words.data(), words.size()};
-    uint8_t packed[260];
-    packed[0] = 0;
-    uint64_t wordid = 0, doc_off = 0;
-    uint32_t n_in_cp = 0, term = 0;
-    while (wr.at < wr.n) {
-      if (++n_in_cp == words_checkpoint) doc_off = 0, n_in_cp = 1, wordid = word_dict ? wordid : 0;
-      if (word_dict) {
-        uint32_t match, delta;
-        const uint8_t pk = wr.p[wr.at++];
-        if (pk & 0x80u)
-          delta = ((pk >> 4) & 7u) + 1u, match = pk & 15u;
-        else {
-          delta = pk & 127u;
-          if (wr.at >= wr.n) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: truncated keyword", rname.c_str(), si);
-          match = wr.p[wr.at++];
-        }
-        if (match > packed[0] || match + delta > 255u || wr.n - wr.at < delta) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: bad front-coded keyword", rname.c_str(), si);
-        packed[0] = (uint8_t)(match + delta);
-        memcpy(packed + 1 + match, wr.p + wr.at, delta);
-        wr.at += delta;
-        woff.push_back((uint32_t)wtext.size());
-        wtext.insert(wtext.end(), packed + 1, packed + 1 + packed[0]);
-        wtext.push_back(0);
-      } else {
-        wordid += wr.zip();
-        wordids.push_back(wordid);
-      }
-      const uint64_t n_docs = wr.zip(), n_hits = wr.zip();
-      doc_off += wr.zip();
-      if (wr.bad || doc_off > docs.size() || n_docs > docs.size() || n_hits > hits.size() + n_docs)
-        return mrk_fail(MRK_E_FORMAT, "%s: segment %u: dictionary entry %u points past the doclists", rname.c_str(), si, term);
-      // ---- its docs: RtDocReader_t::UnzipDoc (:397-421); rowid deltas start from INVALID_ROWID (~0: the first delta wraps)
-      RtBytes dr{docs.data(), docs.size(), (size_t)doc_off};
-      uint32_t rowid = 0xFFFFFFFFu;
-      for (uint64_t d = 0; d < n_docs; ++d) {
-        rowid += (uint32_t)dr.zip();
-        dr.zip(); // field mask (recomputed from the hits by the writer below)
-        const uint64_t dh = dr.zip();
-        uint32_t hit1 = 0;
-        uint64_t hoff = 0;
-        if (dh == 1) {
-          const uint64_t a = dr.zip(), b = dr.zip();
-          hit1 = (uint32_t)(a + (b << 24));
-        } else
-          hoff = dr.zip();
-        if (dr.bad || rowid >= rows || dh == 0 || (dh != 1 && hoff > hits.size()))
-          return mrk_fail(MRK_E_FORMAT, "%s: segment %u: word %u: bad doclist entry", rname.c_str(), si, term);
-        if (dh == 1) {
-          W.push_back(term + 1), Rw.push_back(rowid), H.push_back(hit1);
-          continue;
-        }
-        RtBytes hr{hits.data(), hits.size(), (size_t)hoff}; // RtHitReader_t::UnzipHit (:612-622)
-        uint32_t last = 0;
-        for (uint64_t k = 0; k < dh; ++k) {
-          last += (uint32_t)hr.zip();
-          if (hr.bad) return mrk_fail(MRK_E_FORMAT, "%s: segment %u: word %u: hitlist runs past the segment", rname.c_str(), si, term);
-          W.push_back(term + 1), Rw.push_back(rowid), H.push_back(last);
-        }
-      }
-      ++term;
-    }
+    uint32_t term = 0;
+    if ((rc = rt_decode_segment(words.data(), words.size(), docs.data(), docs.size(), hits.data(), hits.size(), rows, word_dict, words_checkpoint, rname.c_str(), si, W, Rw,
+                                H, wtext, woff, wordids, term)))
+      return rc;
     // ---- the same postings in the disk format
     mrk_host_index* h = nullptr;
     rc = mrk_index_from_hits(W.data(), Rw.data(), H.data(), W.size(), term, proto.info.skiplist_block_size ? proto.info.skiplist_block_size : 128u,
@@ -743,6 +757,50 @@ extern "C" int mrk_rt_ram_open(const char* path_prefix, mrk_rt_ram** out) {
   *out = rt;
   return MRK_OK;
 }
+// A LIVE RAM segment, no file in between: the three byte vectors of an RtSegment_t (sphinxrt.h:140-149: m_dWords, m_dDocs, m_dHits) as
+// the running index holds them.  PerformFullTextSearch (sphinxrt.cpp:6302-6384) rebinds the one ranker to every RAM segment
+// (ISphRanker::Reset, :6313-6314); a device binding keeps one mrk_segment per RtSegment_t instead -- segments are immutable once
+// committed, so decode + re-encode happens once per segment, when it appears -- and the adapter's Reset() picks that segment's.
+extern "C" int mrk_rt_segment_open(const mrk_rt_segment_desc* d, mrk_host_index** out) {
+  if (!d || !out) return mrk_fail(MRK_E_INVAL, "mrk_rt_segment_open: null argument");
+  *out = nullptr;
+  if ((!d->words && d->words_len) || (!d->docs && d->docs_len) || (!d->hits && d->hits_len)) return mrk_fail(MRK_E_INVAL, "mrk_rt_segment_open: null vector");
+  if (d->words_checkpoint < 2 || d->words_checkpoint > (1u << 20)) return mrk_fail(MRK_E_INVAL, "mrk_rt_segment_open: words checkpoint %u", d->words_checkpoint);
+  if (d->n_fields < 1 || d->n_fields > 32) return mrk_fail(MRK_E_UNSUPPORTED, "mrk_rt_segment_open: %u fields (RT doclists carry a 32-bit field mask)", d->n_fields);
+  if (d->hit_format != MRK_HITFMT_INLINE && d->hit_format != MRK_HITFMT_PLAIN) return mrk_fail(MRK_E_INVAL, "mrk_rt_segment_open: bad hit_format %u", d->hit_format);
+  try {
+    std::vector<uint64_t> W;
+    std::vector<uint32_t> Rw, H;
+    std::vector<char> wtext;
+    std::vector<uint32_t> woff;
+    std::vector<uint64_t> wordids;
+    uint32_t term = 0;
+    int rc = rt_decode_segment(d->words, (size_t)d->words_len, d->docs, (size_t)d->docs_len, d->hits, (size_t)d->hits_len, d->rows, d->word_dict != 0, d->words_checkpoint,
+                               "live RAM segment", 0, W, Rw, H, wtext, woff, wordids, term);
+    if (rc != MRK_OK) return rc;
+    mrk_host_index* h = nullptr;
+    rc = mrk_index_from_hits(W.data(), Rw.data(), H.data(), W.size(), term, d->skiplist_block_size ? d->skiplist_block_size : 128u, d->hit_format, &h);
+    if (rc != MRK_OK) return rc;
+    h->from_files = true;
+    h->info.total_docs = d->rows;
+    h->info.n_fields = d->n_fields;
+    h->info.word_dict = d->word_dict ? 1u : 0u;
+    h->info.skiplist_block_size = d->skiplist_block_size ? d->skiplist_block_size : 128u;
+    h->info.hit_format = d->hit_format;
+    for (uint32_t f = 0; f < d->n_fields; ++f) h->fields.push_back("field" + std::to_string(f)); // (the schema stays with the caller)
+    h->words = wtext;
+    h->word_off = woff;
+    if (!d->word_dict)
+      for (size_t i = 0; i < h->dict.size() && i < wordids.size(); ++i) h->dict[i].wordid = wordids[i];
+    *out = h;
+    return MRK_OK;
+  } catch (const std::bad_alloc&) {
+    return mrk_fail(MRK_E_NOMEM, "mrk_rt_segment_open: out of memory");
+  } catch (const std::exception& e) {
+    return mrk_fail(MRK_E_FORMAT, "mrk_rt_segment_open: %s", e.what());
+  }
+}
+
 extern "C" uint32_t mrk_rt_ram_segments(const mrk_rt_ram* rt) { return rt ? (uint32_t)rt->seg.size() : 0u; }
 extern "C" int mrk_rt_ram_take(mrk_rt_ram* rt, uint32_t i, mrk_host_index** out) {
   if (!rt || !out || i >= rt->seg.size() || !rt->seg[i]) return mrk_fail(MRK_E_INVAL, "mrk_rt_ram_take: no segment %u (or taken already)", i);

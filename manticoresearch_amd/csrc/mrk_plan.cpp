@@ -959,8 +959,29 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
   dq.ranker = ranker;
   dq.n_qwords = (uint32_t)words.size(); // ExtRanker_c::m_iQwords (sphinxsearch.cpp:730-731)
   dq.max_qpos = 0;                      // ... m_iMaxQpos = GetQwords() (:4294-4296, 4372)
-  for (const PlanKw& k : T.kws)
-    if (!k.hidden) dq.max_qpos = std::max<uint32_t>(dq.max_qpos, (uint32_t)std::max(k.atom_pos, 0));
+  {
+    // ... over the keywords the query does not EXCLUDE: TagExcluded (sphinx.cpp:15107-15129) marks the words on the right of an
+    // ANDNOT, toggling with every nesting, and an excluded word's GetQwords() answers -1 (searchnode.cpp:2039, 2053).  (The tree
+    // was walked by build_tree / build_gen above: it is a tree of at most PLAN_CAP nodes.)
+    std::vector<uint8_t> ex((size_t)q.n_nodes, 0);
+    struct Walk {
+      const mrk_query& q;
+      std::vector<uint8_t>& ex;
+      void go(int32_t ni, bool neg, int depth) {
+        if (ni < 0 || ni >= q.n_nodes || depth > 16) return;
+        const mrk_node& nd = q.nodes[ni];
+        if (nd.op == MRK_OP_TERM) {
+          ex[(size_t)ni] = neg ? 1 : 0;
+          return;
+        }
+        if (nd.n_children < 0 || nd.first_child < 0) return;
+        for (int i = 0; i < nd.n_children; ++i) go(q.children[nd.first_child + i], (nd.op == MRK_OP_ANDNOT && i == 1) ? !neg : neg, depth + 1);
+      }
+    } walk{q, ex};
+    walk.go(q.root, false, 0);
+    for (const PlanKw& k : T.kws)
+      if (!k.hidden && !(k.node >= 0 && k.node < q.n_nodes && ex[(size_t)k.node])) dq.max_qpos = std::max<uint32_t>(dq.max_qpos, (uint32_t)std::max(k.atom_pos, 0));
+  }
   dq.k = (uint32_t)q.max_matches;
   dq.n_weights = seg->n_fields;
   dq.index_weight = (uint32_t)(q.index_weight ? q.index_weight : 1);

@@ -542,6 +542,63 @@ extern "C" int mrk_query_parse(const char* text, const char* const* field_names,
   }
 }
 
+// sphTransformExtendedQuery (sphinx.cpp:15345-15359) as every query goes through it before the ranker is built -- the part that is not an
+// option: TransformQuorum (:14700-14727: a quorum with threshold 1 becomes the OR of its words), TransformNear (:15049-15105:
+// '(a b c) NEAR/N d' becomes 'a NEAR/N b NEAR/N c NEAR/N d' -- every AND group among a NEAR node's operands is replaced by its
+// children, in place and in order, again and again until none is left; OR groups and phrases stay operands).  TagExcluded
+// (:15107-15129) marks the keywords on the right of an ANDNOT: the planner derives that from the tree itself.  TransformBigrams
+// needs an index built with bigram_index (declined at open) and sphOptimizeBoolean is an option (OPTION boolean_simplify, off by
+// default): neither is restated.
+static void transform_nodes(mrk_parsed_query* q) {
+  // the child lists as vectors, rewritten, then laid out again
+  const size_t n = q->nodes.size();
+  std::vector<std::vector<int32_t>> kids(n);
+  for (size_t i = 0; i < n; ++i) {
+    const mrk_node& nd = q->nodes[i];
+    if (nd.op != MRK_OP_TERM && nd.n_children > 0) kids[i].assign(q->children.begin() + nd.first_child, q->children.begin() + nd.first_child + nd.n_children);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    mrk_node& nd = q->nodes[i];
+    if (nd.op == MRK_OP_QUORUM && nd.opt == 1) {
+      bool plain = true; // (the reference's quorum node holds words, never nodes: only a quorum over plain keywords is one)
+      for (int32_t c : kids[i]) plain = plain && c >= 0 && (size_t)c < n && q->nodes[c].op == MRK_OP_TERM;
+      if (plain) nd.op = MRK_OP_OR, nd.opt = 0;
+    }
+    if (nd.op == MRK_OP_NEAR) {
+      for (bool again = true; again;) {
+        again = false;
+        std::vector<int32_t> flat;
+        for (int32_t c : kids[i]) {
+          if (c >= 0 && (size_t)c < n && q->nodes[c].op == MRK_OP_AND && !kids[c].empty()) {
+            flat.insert(flat.end(), kids[c].begin(), kids[c].end());
+            again = true;
+          } else
+            flat.push_back(c);
+        }
+        kids[i].swap(flat);
+      }
+    }
+  }
+  q->children.clear();
+  for (size_t i = 0; i < n; ++i) {
+    mrk_node& nd = q->nodes[i];
+    if (nd.op == MRK_OP_TERM) continue;
+    nd.first_child = (int32_t)q->children.size();
+    nd.n_children = (int32_t)kids[i].size();
+    q->children.insert(q->children.end(), kids[i].begin(), kids[i].end());
+  }
+}
+
+extern "C" int mrk_parsed_transform(mrk_parsed_query* q) {
+  if (!q) return mrk_fail(MRK_E_INVAL, "mrk_parsed_transform: NULL argument");
+  try {
+    transform_nodes(q);
+  } catch (const std::bad_alloc&) {
+    return mrk_fail(MRK_E_NOMEM, "mrk_parsed_transform: out of memory");
+  }
+  return MRK_OK;
+}
+
 extern "C" void mrk_parsed_free(mrk_parsed_query* q) { delete q; }
 extern "C" int32_t mrk_parsed_n_nodes(const mrk_parsed_query* q) { return q ? (int32_t)q->nodes.size() : 0; }
 extern "C" int32_t mrk_parsed_root(const mrk_parsed_query* q) { return q ? q->root : -1; }

@@ -2448,6 +2448,18 @@ typedef struct {
   int max_qpos;
 } sph04_state;
 
+/* TagExcluded (sphinx.cpp:15107-15129): ex[node] = 1 for keywords the query excludes */
+static void tag_excluded(const orc_query* q, int ni, int neg, unsigned char* ex, int depth) {
+  if (ni < 0 || ni >= q->n_nodes || depth > 32) return;
+  const orc_node* n = &q->nodes[ni];
+  if (n->op == ORC_OP_TERM) {
+    ex[ni] = (unsigned char)neg;
+    return;
+  }
+  for (int i = 0; i < n->n_children; i++)
+    tag_excluded(q, q->children[n->first_child + i], (n->op == ORC_OP_ANDNOT && i == 1) ? !neg : neg, ex, depth + 1);
+}
+
 static void sph04_init(sph04_state* s, int max_qpos) {
   memset(s, 0, sizeof *s);
   s->exp_delta = -INT_MAX;
@@ -2698,9 +2710,16 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
   prox_state ps;
   prox_init(&ps);
   /* m_iMaxQpos = GetQwords() (max query position over all keywords), m_iQwords = distinct words (:4294-4296, 730-731) */
+  /* ... over the keywords that are not EXCLUDED: TagExcluded (sphinx.cpp:15107-15129) marks the words on the right of an ANDNOT
+     (toggling with every nesting) and an excluded word's GetQwords() answers -1 (searchnode.cpp:2039, 2053) */
   int max_qpos = 0;
-  for (int k = 0; k < q->n_nodes; k++)
-    if (q->nodes[k].op == ORC_OP_TERM && q->nodes[k].atom_pos > max_qpos) max_qpos = q->nodes[k].atom_pos;
+  {
+    unsigned char* ex = (unsigned char*)calloc((size_t)(q->n_nodes > 0 ? q->n_nodes : 1), 1);
+    tag_excluded(q, q->root, 0, ex, 0);
+    for (int k = 0; k < q->n_nodes; k++)
+      if (q->nodes[k].op == ORC_OP_TERM && !ex[k] && q->nodes[k].atom_pos > max_qpos) max_qpos = q->nodes[k].atom_pos;
+    free(ex);
+  }
   sph04_state s4;
   sph04_init(&s4, max_qpos);
   matchany_state ms;

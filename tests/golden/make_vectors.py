@@ -334,9 +334,7 @@ for spam, exp in [(10, [[1, 25], [2, 15], [3, 15]]), (0, [[1, 5], [2, 5], [3, 5]
                        "field_weights": [1, 2, spam], "expect": exp})
 
 
-# test_115: NEAR over keywords and phrases (ExtNWay_T<FSMmultinear_c>; the test's cases with AND / OR GROUPS as operands are left out:
-# the reference answers them like a NEAR over all the group's keywords, which the restatement does not reproduce -- parity unpinned
-# for that shape, which oracle and device both decline); keywords keep the positions the
+# test_115: NEAR over keywords and phrases (ExtNWay_T<FSMmultinear_c>); keywords keep the positions the
 # query parser numbers them with, left to right; 'a NEAR/2 b NEAR/5 c NEAR/2 d' nests (different distances do not merge)
 def NEAR(n, *kids):
     return OP("near", *kids, opt=n)
@@ -359,6 +357,19 @@ for name, query, expect in [
 ]:
     G["cases"].append({"name": "115 " + name, "corpus": "test_115", "query": query, "ranker": "proximity_bm25", "expect": expect,
                        "total_found": len(expect)})
+# ... and the test's cases with an AND GROUP as a NEAR operand (round 3).  sphTransformExtendedQuery (sphinx.cpp:15345-15359) runs
+# TransformNear (:15049-15105) over every query before the ranker is built: '(a b c) NEAR/3 d' IS 'a NEAR/3 b NEAR/3 c NEAR/3 d' by then
+# (which is why the reference "answers them like a NEAR over all the group's keywords").  The tree stored here is the one the ranker
+# sees ("transformed": the parser's own output has the group; mrk_parsed_transform flattens it), keywords numbered left to right.
+for name, query, expect in [
+    ("(a b c) NEAR/3 d", NEAR(3, A_, B_, C_, D_), W4444([1, 2, 3, 4, 5, 12, 13, 14])),
+    ("burden NEAR/2 (financial share)", NEAR(2, T("burden", 1), T("financial", 2), T("share", 3)), [[15, 3836]]),
+    ("burden NEAR/2 (share financial)", NEAR(2, T("burden", 1), T("share", 2), T("financial", 3)), [[15, 3836]]),
+    ("(share financial) NEAR/2 burden", NEAR(2, T("share", 1), T("financial", 2), T("burden", 3)), [[15, 3836]]),
+    ("(financial share) NEAR/2 burden", NEAR(2, T("financial", 1), T("share", 2), T("burden", 3)), [[15, 3836]]),
+]:
+    G["cases"].append({"name": "115 " + name, "corpus": "test_115", "query": query, "ranker": "proximity_bm25", "expect": expect,
+                       "total_found": len(expect), "transformed": True})
 # the same test's SphinxQL section lists matching rows only (the statements carry an id filter, applied here by expect_in)
 for name, query, row, hit in [("bet NEAR/2 he", NEAR(2, T("bet", 1), T("he", 2)), 17, False),
                               ("oy NEAR/1 vey", NEAR(1, T("oy", 1), T("vey", 2)), 22, True),

@@ -900,7 +900,8 @@ def test_golden_vectors_on_device(dev, from_text):
             text = query_text(c["name"]) if from_text else None
             if text is None:
                 return tree(v, c["query"])
-            return m.parse_query(text, FIELDS.get(name, []), corpus["min_word_len"], lookup=lambda w: v.get(w, -1))
+            # (transform: what every query goes through between the parser and the ranker, sphTransformExtendedQuery's always-on part)
+            return m.parse_query(text, FIELDS.get(name, []), corpus["min_word_len"], lookup=lambda w: v.get(w, -1), transform=True)
 
         qs = [m.Query(root(c), ranker=rankers[c["ranker"]], field_weights=c.get("field_weights"), plain_idf=bool(c.get("plain_idf")),
                       total_docs=c.get("total_docs", 0), local_docs={v[w]: n for w, n in c["local_docs"].items() if w in v} if "local_docs" in c else None)

@@ -370,6 +370,57 @@ def test_rt_ram_rejects_damage(tmp_path):
     assert n_err > 100
 
 
+def _ram_segments(ram: bytes, word_dict: bool):
+    """The vectors of a .ram file's segments, cut out as data (RtIndex_c::SaveRamChunk's layout, sphinxrt.cpp:4034-4100: per segment
+    rows, alive rows, a dword, then length-prefixed vectors words [checkpoints] docs hits attributes, the dead-row map, blobs ...)."""
+    at = 8
+    n_seg = struct.unpack_from("<I", ram, 4)[0]
+    out = []
+
+    def vec(elem):
+        nonlocal at
+        n = struct.unpack_from("<I", ram, at)[0]
+        at += 4
+        v = ram[at:at + n * elem]
+        at += n * elem
+        return v
+
+    for _ in range(n_seg):
+        rows = struct.unpack_from("<I", ram, at)[0]
+        at += 12
+        words = vec(1)
+        if word_dict:
+            vec(1)
+        n_cp = struct.unpack_from("<I", ram, at)[0]
+        at += 4 + 16 * n_cp
+        docs, hits = vec(1), vec(1)
+        vec(4)  # attribute rows
+        at += ((rows + 31) // 32) * 4
+        vec(1)  # blobs
+        out.append((rows, words, docs, hits))
+        break  # (what follows -- docstore, infixes -- depends on the meta version: the first segment is enough here)
+    return out
+
+
+def test_live_rt_segment_in_memory_equals_the_file_reader():
+    """mrk_rt_segment_open: a RAM segment's three byte vectors handed over in memory (a live RtSegment_t: no .ram file in between)
+    give the same disk-format postings, dictionary and keywords as mrk_rt_ram_open reading them from the reference's .ram file."""
+    import manticoresearch_amd as m
+
+    for name in ("t406_index", "t406_idx320"):
+        from_file = m.open_rt_ram(os.path.join(IDX, name))[0]
+        ram = open(os.path.join(IDX, name + ".ram"), "rb").read()
+        rows, words, docs, hits = _ram_segments(ram, bool(from_file.info["word_dict"]))[0]
+        live = m.open_rt_segment(words, docs, hits, rows, word_dict=bool(from_file.info["word_dict"]), words_checkpoint=64,
+                                 skiplist_block_size=from_file.skiplist_block_size, hit_format=from_file.hit_format, n_fields=from_file.n_fields)
+        assert live.total_docs == from_file.total_docs == rows
+        assert bytes(live.spd) == bytes(from_file.spd) and bytes(live.spp) == bytes(from_file.spp) and bytes(live.spe) == bytes(from_file.spe)
+        assert np.array_equal(live.dict, from_file.dict) and live.words == from_file.words
+        m.validate_index(live)
+    with pytest.raises(m.MrkError):  # damaged vectors end in an error code
+        m.open_rt_segment(words[:-1] + b"\xff", docs[: len(docs) // 2], hits, rows, n_fields=from_file.n_fields)
+
+
 def test_rt_ram_row_count_that_wraps_the_dead_map_size(tmp_path):
     """A RAM segment's row count is an untrusted dword: (rows + 31) / 32 wraps to 0 words for rows >= 0xFFFFFFE1 -- the dead-row map
     came out empty and the count of dead rows read past it (advisor, round 2: SIGSEGV with rows = 0xFFFFFFF0 and the 4-byte map

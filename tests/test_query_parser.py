@@ -116,8 +116,28 @@ def test_most_goldens_carry_their_text():
 @pytest.mark.parametrize("case,text", TEXT_CASES, ids=[c["name"] for c, _ in TEXT_CASES])
 def test_parsed_text_equals_the_golden_tree(case, text):
     corpus = GOLD["corpora"][case["corpus"]]
-    tree = api.parse_query(text, FIELDS.get(case["corpus"], []), corpus["min_word_len"])
+    # ("transformed": the stored tree is the one the ranker sees, behind sphTransformExtendedQuery's always-on rewrites)
+    tree = api.parse_query(text, FIELDS.get(case["corpus"], []), corpus["min_word_len"], transform=bool(case.get("transformed")))
     assert as_golden(tree) == strip_op_masks(case["query"])
+
+
+def test_transform_near_groups_and_quorum_one():
+    """mrk_parsed_transform = the always-on part of sphTransformExtendedQuery (sphinx.cpp:15345-15359): TransformNear flattens AND
+    groups among a NEAR node's operands in place and in order (nested groups too; OR groups and phrases stay operands), TransformQuorum
+    turns a quorum of threshold 1 into the OR of its words; everything else is left alone."""
+    def shape(n):
+        if n.word is not None:
+            return n.word.text
+        return (OPNAME[n.op], n.opt, [shape(k) for k in n.children])
+
+    F = ["title", "body"]
+    assert shape(api.parse_query("(a b c) NEAR/3 d", F, transform=True)) == ("near", 3, ["a", "b", "c", "d"])
+    assert shape(api.parse_query("x NEAR/2 (a (b c)) NEAR/2 (d | e)", F, transform=True)) == ("near", 2, ["x", "a", "b", "c", ("or", 0, ["d", "e"])])
+    assert shape(api.parse_query('(a b) NEAR/4 "c d"', F, transform=True)) == ("near", 4, ["a", "b", ("phrase", 0, ["c", "d"])])
+    assert shape(api.parse_query("(a b c) NEAR/3 d", F)) == ("near", 3, [("and", 0, ["a", "b", "c"]), "d"])  # the parser's own output keeps the group
+    assert shape(api.parse_query('"a b c"/1', F, transform=True)) == ("or", 0, ["a", "b", "c"])
+    assert shape(api.parse_query('"a b c"/2', F, transform=True)) == ("quorum", 2, ["a", "b", "c"])
+    assert shape(api.parse_query("a (b c) | d", F, transform=True)) == shape(api.parse_query("a (b c) | d", F))
 
 
 # ---------------------------------------------------------------- syntax the goldens do not reach
