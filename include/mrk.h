@@ -226,8 +226,14 @@ int mrk_ctx_destroy(mrk_ctx* ctx);
    "attr_nibbles" (1 = segments with <= 4 fields also get a one-byte tf/field plane for the bitmap kernel's gathers:
    28 % fewer bytes per dense x dense query, +14 % queries/s on the 100 M-doc bench, +1 byte per posting; default 0 --
    see DESIGN.md section 6; read at segment load);
-   "bm_target_items" / "bt_target_items" (work items per launch the window ranges of the two-bitmap AND kernel / of the tree kernel over
-   bitmap words are cut into, defaults 8960 / 6144; the AND kernel's items never run under 256 windows);
+   "bm_target_items" / "bt_target_items" (cap of the work items per launch the window ranges of the two-bitmap AND kernel / of the tree
+   kernel over bitmap words are cut into, defaults 2^20 / 6144) and "bm_min_windows" (windows per work item of the AND kernel, default
+   128: since work items of different queries interleave -- "item_order", a mask: 1 block scan, 2 bitmap AND, 4 bitmap trees, 8 also in
+   batches that feed the hit pass; default 7 -- small items are the fast ones); "pk_min_items" (a batch with fewer block-scan work items
+   has its block ranges cut finer, default 2048);
+   "prox_prune" (1 = proximity rankers: matches whose weight upper bound cannot reach the top K skip the hit pass, default);
+   "exchange_part" (1 = mrk_shard_exchange partitions the merge by query, default), "exchange_self_rccl" (1 = a one-rank exchange
+   still goes through RCCL, default 0);
    "bt_cover_inv" (boolean trees whose candidate cover -- the keywords whose doc lists together hold every possible match --
    names >= 1/bt_cover_inv of the segment's docs are evaluated on doc-set bitmap words, 2048 rowids per step, instead of
    block by block; default 32, 0 = never; read at submit);

@@ -263,3 +263,50 @@ def test_full_size_properties(orc):
         batch.close()
         seg.close()
         ctx.close()
+
+
+# ------------------------------------------------------------------ BASELINE config 5's mix in ONE 1024-query launch
+def test_config5_mix_1024_queries_per_launch(orc):
+    """BASELINE config 5 at parity-test size: 10 M docs, FOUR fields with weights (10, 5, 2, 1), the Zipf query mix -- 60 % 2-term AND,
+    20 % 3-term AND / OR mixes, 20 % 2-3-word PHRASE -- under SPH_RANK_PROXIMITY_BM25, all 1024 queries in one launch (the shape
+    bench.py's config5 leg times at 125 M docs).  Every query answers (none declined, none truncated), the launch with the pruning in
+    front of the hit pass (prox_prune, default) equals the launch without it bit for bit -- a match the bounds kept out of the hit
+    pass is still counted --, results obey the sorter's order, and every fourth query equals the oracle."""
+    import manticoresearch_amd as m
+
+    import bench
+
+    n_docs = int(os.environ.get("MRK_C5_DOCS", 10_000_000))
+    c = bench.zipf_c()
+    ranks, strata = bench.make_queries(c, 128)
+    probs = [min(0.5, c / r) for r in ranks]
+    hi = m.synth_index(n_docs, probs, seed=bench.CORPUS_SEED + 5, n_fields=4, end_markers=True)
+    gd = hi.dict["docs"].astype(np.int64)
+    qs = bench.config5_queries(m, strata, 1024, 1000, n_docs, gd, (10, 5, 2, 1))
+    assert len(qs) == 1024
+    kinds = {"phrase": sum(q.root.op == m.SPH_QUERY_PHRASE for q in qs)}
+    assert 150 < kinds["phrase"] < 260
+    res = {}
+    for prune in (1, 0):
+        ctx = m.Context(0)
+        ctx.set("prox_prune", prune)
+        seg = m.Segment(ctx, hi)
+        batch = m.Batch(ctx, len(qs))
+        try:
+            res[prune] = batch.search(seg, qs)
+        finally:
+            batch.close()
+            seg.close()
+            ctx.close()
+    oi = orc_index_of(orc, hi)
+    n_matches = 0
+    for i, (q, g, h) in enumerate(zip(qs, res[1], res[0])):
+        assert g.status == 0 and h.status == 0, (i, q.root)
+        assert g.total_found == h.total_found and (g.rowid == h.rowid).all() and (g.weight == h.weight).all(), i
+        check_order(g)
+        n_matches += g.total_found
+        if i % 4 == 0:
+            want = to_orc(orc, q).run(oi)
+            assert g.total_found == want.total_found, (i, g.total_found, want.total_found)
+            assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all(), i
+    assert n_matches > 1_000_000
