@@ -75,6 +75,41 @@ def exchange_rows(rows):
     return rows_all
 
 
+def shard_slice(n_queries: int, world: int, rank: int):
+    """(per, first, count) of the queries rank `rank` merges under the partitioned exchange: mrk_shard_slice's arithmetic
+    (per = ceil(Q / N); the last ranks may get fewer, or none)."""
+    per = (n_queries + world - 1) // world
+    first = min(per * rank, n_queries)
+    return per, first, min(per, n_queries - first)
+
+
+def exchange_rows_partitioned(rows):
+    """The exchange partitioned by QUERY over torch.distributed (gloo on CPU tensors, RCCL on device tensors): every rank sends each
+    owner its rows of the owner's queries and receives every shard's rows of its own -> (recv [world, per, ROW_WORDS], first, count).
+    The same all-to-all of row slices mrk_shard_exchange issues through the library's communicator (grouped ncclSend / ncclRecv)."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    nq = rows.shape[0]
+    per, first, count = shard_slice(nq, world, rank)
+    recv = torch.zeros((world, per) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    ops = []
+    for p in range(world):
+        _, pf, pc = shard_slice(nq, world, p)
+        if p == rank:
+            recv[p, :count] = rows[first:first + count]
+            continue
+        if pc:
+            ops.append(dist.P2POp(dist.isend, rows[pf:pf + pc].contiguous(), p))
+        if count:
+            ops.append(dist.P2POp(dist.irecv, recv[p, :count], p))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return recv, first, count
+
+
 class ShardMerger:
     """Device-side merge of per-shard results.  One row per query carries the partial top-K keys, their count and
     total_found, so a step costs one collective and one merge launch.  attach() gives each batch a standing slice

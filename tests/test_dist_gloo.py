@@ -61,6 +61,16 @@ def _worker(rank, world, port, q):
     assert rows_all.shape == (world, len(pairs), mdist.ROW_WORDS)
     assert torch.equal(rows_all[:, :, :1024], keys_all) and torch.equal(rows_all[:, :, 1024], counts_all.to(torch.int64))
     assert torch.equal(rows_all[:, :, 1025].sum(0), totals) and torch.equal(rows_all[rank], rows)
+    # the exchange partitioned by query (round 3): each rank receives every shard's rows of ITS queries only -- three queries over two
+    # ranks = slices of 2 and 1 -- and what it receives is the all-gather's rows of those queries
+    recv, first, count = mdist.exchange_rows_partitioned(rows)
+    per = (len(pairs) + world - 1) // world
+    assert recv.shape == (world, per, mdist.ROW_WORDS) and (first, count) == ((0, 2), (2, 1))[rank]
+    assert torch.equal(recv[:, :count], rows_all[:, first:first + count])
+    # ... and the two flag words every rank must agree on travel as one all-reduce (max)
+    flags = torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    assert flags.tolist() == [1, 0]
     if rank == 0:
         q.put((keys_all.numpy().view(np.uint64), counts_all.numpy(), totals.numpy(), gdocs, total))
     dist.barrier()
