@@ -1494,6 +1494,18 @@ static int mrk_batch_wait_impl(mrk_batch* b) {
   HIP_TRY(hipStreamSynchronize(b->stream));
   if (wait_timing) fprintf(stderr, "mrk wait   %p end   (abs %.3f)\n", (void*)b, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
   b->in_flight = false;
+  if (wait_timing && b->d_mq_count.p) { // how full the hit pass's queues got, and how many queries will run again
+    uint32_t cnt[3 * mrk::MQ_SHARDS];
+    if (hipMemcpy(cnt, b->d_mq_count.p, sizeof cnt, hipMemcpyDeviceToHost) == hipSuccess) {
+      uint64_t sum[3] = {0, 0, 0};
+      for (int i = 0; i < 3 * mrk::MQ_SHARDS; ++i) sum[i / mrk::MQ_SHARDS] += cnt[i];
+      uint32_t over = 0;
+      if (b->packed_run)
+        for (uint32_t i = 0; i < b->n_queries; ++i) over += (b->h_flags.p[i] & QF_OVERFLOW) != 0;
+      fprintf(stderr, "mrk wait   %p match-queue chunks reserved %llu / %llu / %llu, queries to rerun %u\n", (void*)b, (unsigned long long)sum[0],
+              (unsigned long long)sum[1], (unsigned long long)sum[2], over);
+    }
+  }
   float ms = 0;
   if (hipEventElapsedTime(&ms, b->ev_scan0, b->ev_scan1) == hipSuccess) b->stats.scan_ms = ms;
   if (hipEventElapsedTime(&ms, b->ev_scan1, b->ev_merge1) == hipSuccess) b->stats.merge_ms = ms;

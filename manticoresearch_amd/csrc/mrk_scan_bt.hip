@@ -27,6 +27,9 @@
 #include "mrk_kpk.h"
 #include "mrk_kmq.h"
 
+#ifndef MRK_BT_WAVES
+#define MRK_BT_WAVES 4 // waves per SIMD the register allocation is made for
+#endif
 #ifndef MRK_BTEXP
 #define MRK_BTEXP 0 // ablations for profiling: 1 no match-queue write, 2 no scoring, 3 no match extraction, 4 no sparse keywords
 #endif
@@ -37,7 +40,7 @@ constexpr int BT_KW = MAX_PROX_TERMS; // keywords per query on this path
 constexpr int BT_CBUF = 128;          // candidates a wave collects before it publishes them
 constexpr int BT_QCAP = 128;          // match queue entries per wave (scored in batches of 64)
 constexpr int BT_WORDS = 64;          // words per window
-constexpr int BT_BURST = 4;           // windows whose bitmap words are requested back to back (one memory round trip per burst)
+constexpr int BT_SPAN = 4;            // windows per step: lane l holds 128 consecutive rowids = four bitmap words per keyword
 
 struct __align__(16) BtWaveLds {
   union { // a pass either weighs its matches itself (candidate buffer) or hands them to the hit pass (pending queue chunk)
@@ -47,7 +50,7 @@ struct __align__(16) BtWaveLds {
   uint32_t q_row[BT_QCAP];
   uint32_t q_pm[BT_QCAP]; // keywords present in the doc
   uint32_t q_rank[BT_KW][BT_QCAP];
-  uint32_t abm[BT_KW][BT_WORDS]; // the window words of sparse keywords while they are assembled
+  uint32_t abm[BT_SPAN * BT_WORDS]; // the step's words of ONE sparse keyword while they are assembled
 };
 
 struct __align__(16) BtSmem {
@@ -88,7 +91,7 @@ __device__ __forceinline__ void bt_load_block(const DevSegment& seg, const DevTe
 // PRUNE: the instance that bounds hit-ranked matches' weights and keeps the hopeless ones out of the match queue (launched when the
 // batch has the lower-bound histograms: ScanArgs::q_hist_lb)
 template <bool PRUNE>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void scan_bt_kernel(ScanArgs a) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES))) void scan_bt_kernel(ScanArgs a) {
   __shared__ BtSmem s;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= a.n_items) return;
@@ -380,36 +383,42 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void sc
     }
   };
 
-  for (uint32_t wb = w0; wb < w1; wb += BT_BURST) {
-    // the dense keywords' words (and the dead-row words) of BT_BURST windows, requested back to back; the query's shared
-    // pruning threshold rides along
-    uint32_t wv[BT_BURST][BT_KW], dvv[BT_BURST];
+  // the dense keywords' words (and the dead-row words) of one step: lane l holds rowids [128 l, 128 l + 128) of it, FOUR consecutive
+  // bitmap words per keyword in one 16-byte load
+  auto load_step = [&](uint32_t wb, uint4 (&kw)[BT_KW], uint4& dw) {
+    const uint32_t wl = wb + (lane >> 4);   // the window the lane's words belong to
+    const bool inr = wl < w1;               // (the wave's range need not be a multiple of BT_SPAN windows)
+    const uint64_t woff = (uint64_t)(inr ? wl : w0) * BT_WORDS + (lane & 15u) * 4u;
 #pragma unroll
-    for (int i = 0; i < BT_BURST; ++i) {
-      const uint32_t w = wb + i < w1 ? wb + i : w1 - 1;
-#pragma unroll
-      for (int k = 0; k < BT_KW; ++k) {
-        wv[i][k] = 0;
-        if ((uint32_t)k < nterms && dense[k]) wv[i][k] = a.seg.bm[Q->t[k].bm_off + (uint64_t)w * BT_WORDS + lane];
+    for (int k = 0; k < BT_KW; ++k) {
+      kw[k] = make_uint4(0, 0, 0, 0);
+      if ((uint32_t)k < nterms && dense[k]) {
+        const uint4 v = *(const uint4*)(a.seg.bm + Q->t[k].bm_off + woff);
+        if (inr) kw[k] = v;
       }
-      dvv[i] = dead ? dead[(uint64_t)w * BT_WORDS + lane] : 0u;
     }
-    // the query's shared pruning threshold: only a pass that weighs its matches itself prunes, and every 4th burst is often enough
+    dw = make_uint4(0, 0, 0, 0);
+    if (dead) dw = *(const uint4*)(dead + woff);
+  };
+  for (uint32_t wb = w0; wb < w1; wb += BT_SPAN) {
+    // one step = BT_SPAN windows = 8192 rowids (a step used to be one window, one word per lane: the tree program, the prefix sums
+    // and the loop around them cost the same per step whatever the lane holds, and at 14 matches per window they, not the matches,
+    // were the kernel).  (Requesting the NEXT step's words ahead of this one's work bought nothing: measured, 1.42 vs 1.39 ms.)
+    uint4 nkw[BT_KW], ndw;
+    load_step(wb, nkw, ndw);
+    uint64_t klo[BT_KW], khi[BT_KW]; // rowids [0, 64) and [64, 128) of the lane, per keyword
+#pragma unroll
+    for (int k = 0; k < BT_KW; ++k) klo[k] = nkw[k].x | ((uint64_t)nkw[k].y << 32), khi[k] = nkw[k].z | ((uint64_t)nkw[k].w << 32);
+    const uint64_t dlo = ndw.x | ((uint64_t)ndw.y << 32), dhi = ndw.z | ((uint64_t)ndw.w << 32);
+    // the query's shared pruning threshold: only a pass that weighs its matches itself prunes, and every 4th step is often enough
     // (all waves of the query read the one word; see scan_bm_kernel)
-    if (!need_hits && ((wb - w0) / BT_BURST & 3u) == 0) {
+    if (!need_hits && ((wb - w0) / BT_SPAN & 3u) == 0) {
       const uint32_t gt = __hip_atomic_load(gtaubin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (gt > tau_bin) tau_bin = gt;
     }
-#pragma unroll
-    for (int bi = 0; bi < BT_BURST; ++bi) {
-    const uint32_t w = wb + bi;
-    if (w >= w1) break;
-    const uint32_t lo = w * 2048u, hi_m1 = lo + 2047u; // window = rowids [lo, hi_m1]
-    uint32_t word[BT_KW];
-#pragma unroll
-    for (int k = 0; k < BT_KW; ++k) word[k] = wv[bi][k];
-    const uint32_t dv = dvv[bi];
-    // sparse keywords: the cursor's docs that fall into the window
+    const uint32_t lo = wb * 2048u;
+    const uint32_t hi_m1 = (wb + BT_SPAN < w1 ? wb + BT_SPAN : w1) * 2048u - 1u; // the step = rowids [lo, hi_m1]
+    // sparse keywords: the cursor's docs that fall into the step, assembled in LDS (one keyword at a time) and read back as the lane's four words
 #pragma unroll
     for (int k = 0; k < BT_KW; ++k) {
       if (MRK_BTEXP != 4 && (uint32_t)k < nterms && !dense[k] && kj[k] != 0xFFFFFFFFu) {
@@ -419,51 +428,59 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void sc
           const bool in0 = e0[k] >= lo && e0[k] <= hi_m1, in1 = e1[k] >= lo && e1[k] <= hi_m1;
           if (__ballot(in0 || in1)) {
             if (!zeroed) {
-              L.abm[k][lane] = 0;
+              *(uint4*)(L.abm + lane * 4u) = make_uint4(0, 0, 0, 0);
               wave_lds_fence();
               zeroed = true;
             }
-            if (in0) atomicOr(&L.abm[k][(e0[k] >> 5) & 63u], 1u << (e0[k] & 31u));
-            if (in1) atomicOr(&L.abm[k][(e1[k] >> 5) & 63u], 1u << (e1[k] & 31u));
+            if (in0) atomicOr(&L.abm[(e0[k] - lo) >> 5], 1u << (e0[k] & 31u));
+            if (in1) atomicOr(&L.abm[(e1[k] - lo) >> 5], 1u << (e1[k] & 31u));
           }
-          // the next block starts at bnext: beyond the window -> this block served it
+          // the next block starts at bnext: beyond the step -> this block served it
           if (bnext[k] > hi_m1) break;
           ++kj[k];
           bt_load_block(a.seg, T, kj[k], e0[k], e1[k], bnext[k]);
         }
         if (zeroed) {
           wave_lds_fence();
-          word[k] = L.abm[k][lane];
+          const uint4 v = *(const uint4*)(L.abm + lane * 4u);
+          klo[k] = v.x | ((uint64_t)v.y << 32), khi[k] = v.z | ((uint64_t)v.w << 32);
+          wave_lds_fence(); // (the next sparse keyword zeroes the same words)
         }
       }
     }
-    // the tree on 32 rowids per lane
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    // the tree on 128 rowids per lane
+    uint64_t s0l = 0, s1l = 0, s2l = 0, s3l = 0, s0h = 0, s1h = 0, s2h = 0, s3h = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       if ((uint32_t)i < n_nodes) {
         const uint32_t ins = prog[i], op = ins & 0xffu, kw = ins >> 24;
         if (op == PN_TERM) {
-          s3 = s2, s2 = s1, s1 = s0;
-          s0 = kw == 0 ? word[0] : kw == 1 ? word[1] : kw == 2 ? word[2] : word[3];
+          s3l = s2l, s2l = s1l, s1l = s0l;
+          s3h = s2h, s2h = s1h, s1h = s0h;
+          s0l = kw == 0 ? klo[0] : kw == 1 ? klo[1] : kw == 2 ? klo[2] : klo[3];
+          s0h = kw == 0 ? khi[0] : kw == 1 ? khi[1] : kw == 2 ? khi[2] : khi[3];
         } else {
-          const uint32_t r = op == PN_AND ? (s1 & s0) : op == PN_OR ? (s1 | s0) : op == PN_MAYBE ? s1 : (s1 & ~s0);
-          s0 = r, s1 = s2, s2 = s3;
+          const uint64_t rl = op == PN_AND ? (s1l & s0l) : op == PN_OR ? (s1l | s0l) : op == PN_MAYBE ? s1l : (s1l & ~s0l);
+          const uint64_t rh = op == PN_AND ? (s1h & s0h) : op == PN_OR ? (s1h | s0h) : op == PN_MAYBE ? s1h : (s1h & ~s0h);
+          s0l = rl, s1l = s2l, s2l = s3l;
+          s0h = rh, s1h = s2h, s2h = s3h;
         }
       }
     }
-    uint32_t m = s0 & ~dv;
+    uint64_t mlo = s0l & ~dlo, mhi = s0h & ~dhi;
 #if MRK_BTEXP == 3
-    total += (uint32_t)__popc(m);
-    m = 0;
+    total += (uint32_t)__popcll(mlo) + (uint32_t)__popcll(mhi);
+    mlo = mhi = 0;
 #endif
-    // ranks of the lane's first bit: one prefix sum carries two keywords' popcounts
-    uint32_t r0[BT_KW];
+    // ranks of the lane's first rowid: one prefix sum carries two keywords' popcounts (a step holds at most 8192 docs of a keyword)
+    uint32_t r0[BT_KW], plo[BT_KW];
+#pragma unroll
+    for (int k = 0; k < BT_KW; ++k) plo[k] = (uint32_t)__popcll(klo[k]);
 #pragma unroll
     for (int k = 0; k < BT_KW; k += 2) {
       r0[k] = r0[k + 1] = 0;
       if ((uint32_t)k < nterms) {
-        const uint32_t pc = (uint32_t)__popc(word[k]) | ((uint32_t)__popc(word[k + 1]) << 16);
+        const uint32_t pc = (plo[k] + (uint32_t)__popcll(khi[k])) | ((plo[k + 1] + (uint32_t)__popcll(khi[k + 1])) << 16);
         const uint32_t incl = wave_incl_scan(pc);
         const uint32_t excl = incl - pc;
         r0[k] = base[k] + (excl & 0xFFFFu);
@@ -473,25 +490,34 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void sc
         base[k + 1] += tot >> 16;
       }
     }
-    const uint32_t rowbase = lo + lane * 32u;
+    const uint32_t rowbase = lo + lane * 128u;
     uint64_t bal;
-    while ((bal = __ballot(m != 0)) != 0) {
-      const bool has = m != 0;
-      const uint32_t bit = has ? (uint32_t)__builtin_ctz(m) : 0u;
-      const uint32_t below = (1u << bit) - 1u;
+    while ((bal = __ballot((mlo | mhi) != 0)) != 0) {
+      const bool has = (mlo | mhi) != 0;
+      const bool up = mlo == 0; // the lane's next match is in its upper 64 rowids
+      const uint64_t cur = up ? mhi : mlo;
+      const uint32_t bit = has ? (uint32_t)__builtin_ctzll(cur) : 0u;
+      const uint64_t below = (1ull << bit) - 1ull;
       const uint32_t pos = qn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
       if (has) {
         uint32_t pm = 0;
 #pragma unroll
         for (int k = 0; k < BT_KW; ++k) {
-          pm |= ((word[k] >> bit) & 1u) << k;
-          if ((uint32_t)k < nterms) L.q_rank[k][pos] = r0[k] + (uint32_t)__popc(word[k] & below);
+          if ((uint32_t)k < nterms) {
+            const uint64_t sel = up ? khi[k] : klo[k];
+            pm |= (uint32_t)((sel >> bit) & 1ull) << k;
+            L.q_rank[k][pos] = r0[k] + (up ? plo[k] : 0u) + (uint32_t)__popcll(sel & below);
+          }
         }
-        L.q_row[pos] = rowbase + bit;
+        L.q_row[pos] = rowbase + (up ? 64u : 0u) + bit;
         L.q_pm[pos] = pm;
       }
       qn += (uint32_t)__popcll(bal);
-      m &= m - 1u;
+      const uint64_t nx = cur & (cur - 1ull);
+      if (up)
+        mhi = nx;
+      else
+        mlo = nx;
       if (qn >= 64u) {
 #if MRK_BTEXP != 2
         score(qn - 64u, 64u);
@@ -502,7 +528,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void sc
         wave_lds_fence(); // the scored entries' slots may be rewritten
       }
     }
-    } // windows of the burst
   }
   if (qn) score(0, qn);
   if (PRUNE && pend_n) {
