@@ -230,7 +230,7 @@ def test_full_size_properties(orc):
         b3 = m.Batch(ctx, len(q3))
         try:
             out = {}
-            for name, inv in (("bt", 32), ("blocks", 0)):
+            for name, inv in (("bt", 1024), ("blocks", 0)):
                 ctx.set("bt_cover_inv", inv)
                 r1 = b3.search(seg, q3)
                 r2 = b3.search(seg, q3)
@@ -255,7 +255,7 @@ def test_full_size_properties(orc):
                     g = out["bt"][i]
                     assert g.total_found == want.total_found and (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
         finally:
-            ctx.set("bt_cover_inv", 32)
+            ctx.set("bt_cover_inv", 1024)
             b3.close()
     finally:
         ctx.set("path", 0)
