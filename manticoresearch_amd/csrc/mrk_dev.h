@@ -350,7 +350,8 @@ struct ScanArgs {
   uint64_t* cand;      // candidate arena
   // hit-ranked queries: histogram of the matches' LOWER weight bounds and its threshold bin (mrk_kprune.h, prox_bounds); NULL = no pruning in front of the hit pass
   uint32_t* q_hist_lb; // [n_queries][NBINS]
-  uint32_t* q_tau_lb;  // [n_queries * QSTRIDE]
+  uint32_t* q_hist_lb2; // [n_queries][NBINS]: the matches inside the threshold bin by (weight offset, rowid slice), mrk_kprune.h
+  uint32_t* q_tau_lb;  // [n_queries * QSTRIDE]: (threshold bin << 10) | threshold slot of the second level
   MatchQueue mq[3];    // [0] plain boolean trees, [1] queries with PHRASE / PROXIMITY / BEFORE nodes or position modifiers, [2] TF_GEN
   GenArgs gen;
 };

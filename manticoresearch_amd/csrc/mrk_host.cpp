@@ -140,7 +140,7 @@ struct mrk_batch {
   DevBuf<uint32_t> d_list_first, d_list_n, d_kq;
   DevBuf<uint64_t> d_out_keys;
   DevBuf<uint32_t> d_out_cnt;
-  DevBuf<uint32_t> d_lb;  // hit-ranked queries: histograms of the matches' lower weight bounds [n][NBINS], then their threshold words [n * QSTRIDE]
+  DevBuf<uint32_t> d_lb;  // hit-ranked queries: histograms of the matches' lower weight bounds [n][NBINS], their second levels [n][NBINS], then the threshold words [n * QSTRIDE]
   DevBuf<uint32_t> d_sel; // selection scratch: threshold bin | slices in use per query, then the survivors per slice
   // packed path: pruning histograms, candidate lists
   View<uint32_t> d_q_hist, d_q_cand_n, d_q_flags, d_q_tau_bin;
@@ -1226,11 +1226,12 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   sa.cand = b->d_cand.p;
   bool any_nearn = false;
   if (use_packed && any_prox && b->ctx->prox_prune) { // pruning in front of the hit pass (mrk_kprune.h, prox_bounds)
-    const size_t words = (size_t)n * (NBINS + mrk::QSTRIDE);
+    const size_t words = (size_t)n * (2 * NBINS + mrk::QSTRIDE);
     if ((rc = b->d_lb.reserve(words))) return rc;
     HIP_TRY(hipMemsetAsync(b->d_lb.p, 0, words * 4, st));
     sa.q_hist_lb = b->d_lb.p;
-    sa.q_tau_lb = b->d_lb.p + (size_t)n * NBINS;
+    sa.q_hist_lb2 = b->d_lb.p + (size_t)n * NBINS;
+    sa.q_tau_lb = b->d_lb.p + (size_t)n * 2 * NBINS;
   }
   if ((rc = bind_match_queues(b, mq_chunks, sa))) return rc;
   if (mq_chunks[0] || mq_chunks[1] || mq_chunks[2]) HIP_TRY(hipMemsetAsync(b->d_mq_count.p, 0, 3 * mrk::MQ_SHARDS * 4, st));

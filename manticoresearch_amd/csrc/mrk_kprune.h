@@ -95,6 +95,101 @@ __device__ __forceinline__ void hist_add_bins(uint32_t* __restrict__ gh, bool v,
   }
 }
 
+// ---- second level of the lower-bound histogram (round 3): the matches INSIDE the threshold bin, by exact weight and rowid ----
+// BM25 without document length is tie-heavy: thousands of matches share the very weight the K-th best has, and the sorter
+// breaks the tie by rowid (lower wins).  The first level only knows "K matches reach bin T"; the second level counts the
+// lower bounds that fall INTO bin T by (weight offset inside the bin, 2^rbits rowid slices, lower rowids in higher slots): once
+// K matches are known to sit above slot S, a match whose UPPER bound lies in bin T below slot S cannot enter the top K either.
+// The threshold bin moves (upwards only) while the kernels run, so every counter carries the bin it counts for in its upper
+// ten bits: adds for an older bin are dropped, the first add for a newer bin restarts the counter -- a counter never holds a
+// match that is not in the bin it names, and an undercount only lowers the threshold.
+constexpr uint32_t H2_CNT_BITS = 22, H2_CNT_MASK = (1u << H2_CNT_BITS) - 1u;
+
+__device__ __forceinline__ void hist2_add(uint32_t* __restrict__ gh2, bool v, uint32_t slot, uint32_t ver) {
+  const uint32_t lane = lane_id();
+  const uint32_t mine = v ? slot : 0xFFFFFFFFu;
+  uint64_t left = __ballot(v);
+  while (left) {
+    const uint32_t l = (uint32_t)__builtin_ctzll(left);
+    const uint32_t b = rdlane(mine, l);
+    const uint64_t same = __ballot(mine == b);
+    if (lane == l) {
+      const uint32_t cnt = (uint32_t)__popcll(same);
+      uint32_t old = __hip_atomic_load(gh2 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        const uint32_t over = old >> H2_CNT_BITS;
+        if (over > ver) break; // the threshold bin has moved on: this match is below it now
+        uint32_t c = (over == ver ? (old & H2_CNT_MASK) : 0u) + cnt;
+        if (c > H2_CNT_MASK) c = H2_CNT_MASK;
+        if (__hip_atomic_compare_exchange_strong(gh2 + b, &old, (ver << H2_CNT_BITS) | c, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+    }
+    left &= ~same;
+  }
+}
+
+// threshold_bin over the first level, plus the number of matches in the bins strictly above the one returned
+static __device__ uint32_t threshold_bin_above(const uint32_t* __restrict__ gh, uint32_t k, uint32_t& n_above) {
+  const uint32_t lane = lane_id();
+  uint32_t acc = 0;
+  n_above = 0;
+  for (int qd = NBINS / 256 - 1; qd >= 0; --qd) {
+    const uint32_t* p = gh + 256 * qd + 4 * lane;
+    const uint32_t g0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t g1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t g2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t g3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t sum = g0 + g1 + g2 + g3;
+    const uint32_t pre = wave_incl_scan(sum);
+    const uint32_t tot = rdlane(pre, 63);
+    if (acc + tot >= k) {
+      const uint32_t above = acc + tot - pre;
+      const uint64_t okl = __ballot(above + sum >= k);
+      const uint32_t L = 63u - (uint32_t)__builtin_clzll(okl | 1ull);
+      uint32_t run = above + g3, bi = 3, ab = above;
+      if (run < k) ab = run, run += g2, bi = 2;
+      if (run < k && bi == 2) ab = run, run += g1, bi = 1;
+      if (run < k && bi == 1) ab = run, bi = 0;
+      n_above = rdlane(ab, L);
+      return 256u * (uint32_t)qd + 4u * L + rdlane(bi, L);
+    }
+    acc += tot;
+  }
+  n_above = acc;
+  return 0u;
+}
+
+// threshold_bin over the second level: only the counters that name bin `ver` count
+static __device__ uint32_t threshold_slot(const uint32_t* __restrict__ gh2, uint32_t k, uint32_t ver) {
+  const uint32_t lane = lane_id();
+  uint32_t acc = 0;
+  if (!k) return (uint32_t)NBINS - 1u;
+  for (int qd = NBINS / 256 - 1; qd >= 0; --qd) {
+    const uint32_t* p = gh2 + 256 * qd + 4 * lane;
+    uint32_t g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t x = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g[i] = (x >> H2_CNT_BITS) == ver ? (x & H2_CNT_MASK) : 0u;
+    }
+    const uint32_t sum = g[0] + g[1] + g[2] + g[3];
+    const uint32_t pre = wave_incl_scan(sum);
+    const uint32_t tot = rdlane(pre, 63);
+    if (acc + tot >= k) {
+      const uint32_t above = acc + tot - pre;
+      const uint64_t okl = __ballot(above + sum >= k);
+      const uint32_t L = 63u - (uint32_t)__builtin_clzll(okl | 1ull);
+      uint32_t run = above + g[3], bi = 3;
+      if (run < k) run += g[2], bi = 2;
+      if (run < k && bi == 2) run += g[1], bi = 1;
+      if (run < k && bi == 1) bi = 0;
+      return 256u * (uint32_t)qd + 4u * L + rdlane(bi, L);
+    }
+    acc += tot;
+  }
+  return 0u;
+}
+
 // position of the n-th (0-based) set bit of a wave-uniform 64-bit mask, n per lane (n < popcount)
 __device__ __forceinline__ uint32_t nth_set_bit64(uint64_t m, uint32_t n) {
   uint32_t pos = 0, w = (uint32_t)m;

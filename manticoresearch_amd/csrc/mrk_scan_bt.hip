@@ -31,7 +31,7 @@
 #define MRK_BT_WAVES 4 // waves per SIMD the register allocation is made for
 #endif
 #ifndef MRK_BTEXP
-#define MRK_BTEXP 0 // ablations for profiling: 1 no match-queue write, 2 no scoring, 3 no match extraction, 4 no sparse keywords
+#define MRK_BTEXP 0 // ablations for profiling: 1 no match-queue write, 2 no scoring, 3 no match extraction, 4 no sparse keywords, 6 no lower-bound histogram, 7 bounds but no queue write
 #endif
 
 namespace mrk {
@@ -40,6 +40,7 @@ constexpr int BT_KW = MAX_PROX_TERMS; // keywords per query on this path
 constexpr int BT_CBUF = 128;          // candidates a wave collects before it publishes them
 constexpr int BT_QCAP = 128;          // match queue entries per wave (scored in batches of 64)
 constexpr int BT_WORDS = 64;          // words per window
+constexpr uint32_t BT_NOTES = 128;    // match notes a wave holds between the bit walk and the queue (uint16 each, in the abm words)
 constexpr int BT_SPAN = 4;            // windows per step: lane l holds 128 consecutive rowids = four bitmap words per keyword
 
 struct __align__(16) BtWaveLds {
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
   const bool prune_prox = PRUNE && need_hits && a.q_hist_lb && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && !(Q->tree_flags & TF_DUPES) &&
                           Q->n_wfilters == 0 && Q->bin_mode == BIN_WEIGHT;
   uint32_t* __restrict__ ghist_lb = prune_prox ? a.q_hist_lb + (uint64_t)oq * NBINS : nullptr;
-  uint32_t* __restrict__ gtau_lb = prune_prox ? a.q_tau_lb + (size_t)oq * QSTRIDE : nullptr;
+  uint32_t* __restrict__ ghist_lb2 = prune_prox ? a.q_hist_lb2 + (uint64_t)oq * NBINS : nullptr;
+  uint32_t* __restrict__ gtau_lb = prune_prox ? a.q_tau_lb + (size_t)oq * QSTRIDE : nullptr; // (threshold bin << 10) | threshold slot inside it
   const uint32_t bin_mode = Q->bin_mode, bin_shift = Q->bin_shift;
   const int32_t bin_lo = Q->bin_lo;
   const uint32_t cand_cap = Q->cand_cap;
@@ -172,7 +174,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
   uint32_t total = 0, tau_bin = 0, cn = 0, qn = 0;
   MqWriter mqw;
   // pruned hit-ranked matches: the survivors of a scoring round are compacted into the wave's pending chunk (LDS) until 64 are there
-  uint32_t tau_lb = 0, lb_rounds = 0, lb_added = 0, pend_n = 0;
+  uint32_t tau_lb = 0, tau2 = 0, lb_rounds = 0, lb_added = 0, pend_n = 0;
+  // second level of the lower-bound histogram: 10 bits = the weight's offset inside its bin (bin_shift bits) + rowid slices
+  const uint32_t l2_rbits = bin_shift < 10u ? 10u - bin_shift : 0u;
+  const uint32_t l2_rmax = a.seg.n_windows * 2048u - 1u; // >= every row of the segment
+  const uint32_t l2_rshift = (32u - (uint32_t)__builtin_clz(l2_rmax | 1u)) > l2_rbits ? (32u - (uint32_t)__builtin_clz(l2_rmax | 1u)) - l2_rbits : 0u;
   auto write_chunk = [&](const uint32_t* v, uint32_t n) { // one chunk of the HBM match queue from registers: lane l = entry l, n entries
     const MatchQueue& MQ = a.mq[0];
     const uint32_t c = mq_take(MQ, mqw);
@@ -302,31 +308,51 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
         write_chunk(vals, n);
         return;
       }
-      // bounds of the weight from what the doclists say; the lower bounds feed the query's histogram, the upper bound is tested
+      // bounds of the weight from what the doclists say; the lower bounds feed the query's histograms, the upper bound is tested
       uint32_t wlo, whi;
       prox_bounds(ranker, v0, a0, kf, BT_KW, s.fw, nw, index_weight, wlo, whi);
       // (only lower bounds that reach the current threshold can raise it: the others are never counted -- an undercounted
       // histogram only makes the threshold lower than it could be -- and once the threshold stands almost no round adds anything)
       const uint32_t blo = bin_of(BIN_WEIGHT, bin_lo, bin_shift, (int32_t)wlo, 0u);
+      const uint32_t bhi = bin_of(BIN_WEIGHT, bin_lo, bin_shift, (int32_t)whi, 0u);
+      // second level (mrk_kprune.h): inside the threshold bin, (weight offset in the bin, rowid slice) -- a bin in the middle of the
+      // range holds exactly the weights [bin_lo + (T << shift), + 2^shift), so the offset orders them exactly
+      const bool lvl2 = tau_lb > 0 && tau_lb < (uint32_t)NBINS - 1u && l2_rbits > 0;
+      const uint32_t rsl = (l2_rmax - row) >> l2_rshift; // (row <= l2_rmax; lower rowids in higher slices)
+      const uint32_t off_mask = (1u << bin_shift) - 1u;
+      const uint32_t slo = (((wlo - (uint32_t)bin_lo) & off_mask) << l2_rbits) | rsl;
+      const uint32_t shi = (((whi - (uint32_t)bin_lo) & off_mask) << l2_rbits) | rsl;
+#if MRK_BTEXP == 6
+      const bool counts = false, counts2 = false;
+#else
       const bool counts = valid && blo >= tau_lb;
-      lb_added += (uint32_t)__popcll(__ballot(counts));
+      const bool counts2 = valid && lvl2 && blo == tau_lb && slo >= tau2;
+#endif
+      lb_added += (uint32_t)__popcll(__ballot(counts)) + (uint32_t)__popcll(__ballot(counts2));
       hist_add_bins(ghist_lb, counts, blo);
-      if (lb_added >= 256u || (lb_rounds & 63u) == 0u) { // the wave added enough to matter / now and then: recompute
-        if (lb_added >= 256u) {
-          const uint32_t tb = threshold_bin(ghist_lb, K);
-          if (tb > tau_lb) {
-            tau_lb = tb;
-            if (lane == 0) atomicMax(gtau_lb, tb);
-          }
-          lb_added = 0;
+      if (lvl2) hist2_add(ghist_lb2, counts2, slo, tau_lb);
+      if (lb_added >= 256u) { // the wave added enough to matter: recompute
+        uint32_t n_above = 0;
+        const uint32_t tb = threshold_bin_above(ghist_lb, K, n_above);
+        bool moved = false;
+        if (tb > tau_lb) tau_lb = tb, tau2 = 0, moved = true;
+        if (tb == tau_lb && tau_lb > 0 && tau_lb < (uint32_t)NBINS - 1u && l2_rbits > 0 && n_above < K) {
+          const uint32_t t2 = threshold_slot(ghist_lb2, K - n_above, tau_lb);
+          if (t2 > tau2) tau2 = t2, moved = true;
         }
+        if (moved && lane == 0) atomicMax(gtau_lb, (tau_lb << 10) | tau2);
+        lb_added = 0;
       }
       if ((lb_rounds++ & 3u) == 0u) {
         const uint32_t gt = __hip_atomic_load(gtau_lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gt > tau_lb) tau_lb = gt;
+        if (gt > ((tau_lb << 10) | tau2)) tau_lb = gt >> 10, tau2 = gt & 1023u;
       }
-      const bool keep = valid && bin_of(BIN_WEIGHT, bin_lo, bin_shift, (int32_t)whi, 0u) >= tau_lb;
+      const bool keep = valid && (bhi > tau_lb || (bhi == tau_lb && (!(tau_lb > 0 && tau_lb < (uint32_t)NBINS - 1u && l2_rbits > 0) || shi >= tau2)));
       total += (valid && !keep) ? 1u : 0u; // a match all the same (CSphMatchQueue::PushT counts every push): rank_kernel counts the ones it sees
+#if MRK_BTEXP == 7
+      total += keep ? 1u : 0u;
+      return;
+#endif
       const uint64_t km = __ballot(keep);
       const uint32_t kcnt = (uint32_t)__popcll(km);
       if (!kcnt) return;
@@ -490,34 +516,55 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
         base[k + 1] += tot >> 16;
       }
     }
-    const uint32_t rowbase = lo + lane * 128u;
-    uint64_t bal;
-    while ((bal = __ballot((mlo | mhi) != 0)) != 0) {
-      const bool has = (mlo | mhi) != 0;
-      const bool up = mlo == 0; // the lane's next match is in its upper 64 rowids
-      const uint64_t cur = up ? mhi : mlo;
-      const uint32_t bit = has ? (uint32_t)__builtin_ctzll(cur) : 0u;
+    // The step's matches, in two moves (round 3).  (1) Every lane walks its 128 match bits and only NOTES where they are: one
+    // 16-bit (lane, bit) per match into a small ring in LDS -- the walk runs as many rounds as the busiest lane has matches, at
+    // ~ 1/4 of the lanes busy, so it has to be cheap.  (2) 64 notes at a time, one per lane and every lane busy, become queue
+    // entries: the noting lane's words come over by ds_bpermute, the match's rank in every keyword is the lane's first rank
+    // plus the popcount of the keyword's bits below the match.  (Both used to be one loop: ~ 80 instructions per round.)
+    uint16_t* __restrict__ note = (uint16_t*)L.abm; // (free again: the sparse keywords' words are in registers)
+    uint32_t th = 0, tn = 0;                        // ring of BT_NOTES notes: [th, th + tn)
+    for (;;) {
+      const uint64_t bal = __ballot((mlo | mhi) != 0);
+      if (bal) {
+        const bool has = (mlo | mhi) != 0;
+        const bool up = mlo == 0; // the lane's next match is in its upper 64 rowids
+        const uint64_t cur = up ? mhi : mlo;
+        const uint32_t bit = has ? (uint32_t)__builtin_ctzll(cur) : 0u;
+        if (has) note[(th + tn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))) & (BT_NOTES - 1u)] = (uint16_t)((lane << 7) | (up ? 64u : 0u) | bit);
+        tn += (uint32_t)__popcll(bal);
+        const uint64_t nx = cur & (cur - 1ull);
+        if (up)
+          mhi = nx;
+        else
+          mlo = nx;
+        if (tn < 64u) continue; // (< 64 notes before a round, <= 64 more in it: the ring holds them)
+      } else if (!tn)
+        break;
+      // notes [th, th + n) -> queue entries [qn, qn + n)
+      const uint32_t n = tn < 64u ? tn : 64u;
+      wave_lds_fence();
+      const bool valid = lane < n;
+      const uint32_t e = note[(th + lane) & (BT_NOTES - 1u)];
+      const uint32_t src = valid ? e >> 7 : lane, b7 = e & 127u, bit = e & 63u;
+      const bool up = (e & 64u) != 0;
       const uint64_t below = (1ull << bit) - 1ull;
-      const uint32_t pos = qn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-      if (has) {
-        uint32_t pm = 0;
+      const uint64_t msk_lo = up ? ~0ull : below, msk_hi = up ? below : 0ull; // the lane's rowids below the match
+      uint32_t pm = 0;
 #pragma unroll
-        for (int k = 0; k < BT_KW; ++k) {
-          if ((uint32_t)k < nterms) {
-            const uint64_t sel = up ? khi[k] : klo[k];
-            pm |= (uint32_t)((sel >> bit) & 1ull) << k;
-            L.q_rank[k][pos] = r0[k] + (up ? plo[k] : 0u) + (uint32_t)__popcll(sel & below);
-          }
+      for (int k = 0; k < BT_KW; ++k) {
+        if ((uint32_t)k < nterms) {
+          const uint64_t sl = (uint64_t)(uint32_t)__shfl((int)(uint32_t)klo[k], (int)src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(klo[k] >> 32), (int)src, 64) << 32);
+          const uint64_t sh = (uint64_t)(uint32_t)__shfl((int)(uint32_t)khi[k], (int)src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(khi[k] >> 32), (int)src, 64) << 32);
+          const uint32_t rb = (uint32_t)__shfl((int)r0[k], (int)src, 64);
+          pm |= (uint32_t)(((up ? sh : sl) >> bit) & 1ull) << k;
+          if (valid) L.q_rank[k][qn + lane] = rb + (uint32_t)__popcll(sl & msk_lo) + (uint32_t)__popcll(sh & msk_hi);
         }
-        L.q_row[pos] = rowbase + (up ? 64u : 0u) + bit;
-        L.q_pm[pos] = pm;
       }
-      qn += (uint32_t)__popcll(bal);
-      const uint64_t nx = cur & (cur - 1ull);
-      if (up)
-        mhi = nx;
-      else
-        mlo = nx;
+      if (valid) {
+        L.q_row[qn + lane] = lo + src * 128u + b7;
+        L.q_pm[qn + lane] = pm;
+      }
+      th += n, tn -= n, qn += n;
       if (qn >= 64u) {
 #if MRK_BTEXP != 2
         score(qn - 64u, 64u);
@@ -525,8 +572,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
         total += 64u;
 #endif
         qn -= 64u;
-        wave_lds_fence(); // the scored entries' slots may be rewritten
       }
+      wave_lds_fence(); // the scored entries' slots and the notes just read may be rewritten
     }
   }
   if (qn) score(0, qn);
