@@ -248,6 +248,11 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
     c->bm_target_items = (int)value;
     return MRK_OK;
   }
+  if (!strcmp(key, "bt_phrase")) {
+    if (value < 0 || value > 1) return mrk_fail(MRK_E_INVAL, "bt_phrase must be 0 or 1");
+    c->bt_phrase = (int)value;
+    return MRK_OK;
+  }
   if (!strcmp(key, "bt_cover_inv")) {
     if (value < 0 || value > (1 << 20)) return mrk_fail(MRK_E_INVAL, "bt_cover_inv must be 0 (off) .. 2^20");
     c->bt_cover_inv = (int)value;
@@ -893,9 +898,9 @@ static int queue_of(const DevQuery& P, bool fat) { return (P.tree_flags & mrk::T
 static uint64_t pass_max_matches(const DevQuery& P) {
   if (P.tree_flags & mrk::TF_BITMAP) return std::min<uint64_t>(P.t[0].docs, P.t[1].docs);
   if (P.tree_flags & mrk::TF_BTREE) {
-    uint64_t d = 0;
-    for (uint32_t k = 0; k < P.n_terms && k < (uint32_t)MRK_MAX_AND_TERMS; ++k) d += P.t[k].docs;
-    return d;
+    uint64_t d = 0, least = ~0ull;
+    for (uint32_t k = 0; k < P.n_terms && k < (uint32_t)MRK_MAX_AND_TERMS; ++k) d += P.t[k].docs, least = std::min<uint64_t>(least, P.t[k].docs);
+    return (P.tree_flags & mrk::TF_MULTIAND) && P.n_terms ? least : d; // (an AND of keywords holds no more docs than its rarest one)
   }
   return P.t[0].docs;
 }
@@ -1155,17 +1160,18 @@ static int mrk_batch_submit_impl(mrk_batch* b, mrk_segment* seg, const mrk_query
   // match queues: a pass hands over at most one entry per doc it can match, plus one partial chunk per wave of its items
   uint64_t mq_chunks[3] = {0, 0, 0};
   if (use_packed && any_prox) {
-    bool bt_feeds = false;
+    bool bt_feeds[3] = {false, false, false};
     auto account = [&](const DevQuery& P) {
       bool fat = false;
       if (!P.n_items || !pass_queues_matches(P, fat)) return;
       const bool bt = (P.tree_flags & mrk::TF_BTREE) != 0;
       mq_chunks[queue_of(P, fat)] += pass_max_matches(P) / 64 + (bt ? 0 : 4ull * (mrk::MQ_BATCH + 1) * P.n_items) + 1;
-      bt_feeds = bt_feeds || bt;
+      bt_feeds[queue_of(P, fat)] = bt_feeds[queue_of(P, fat)] || bt;
     };
     for (uint32_t i = 0; i < n; ++i) account(b->h_queries.p[i]);
     for (const DevQuery& P : extra) account(P);
-    if (bt_feeds) mq_chunks[0] += 4ull * (mrk::MQ_BATCH + 1) * n_items_kind[1]; // per wave one partial chunk + the unused rest of a reservation (its work items were only cut just now)
+    for (int i = 0; i < 2; ++i) // per wave one partial chunk + the unused rest of a reservation (its work items were only cut just now)
+      if (bt_feeds[i]) mq_chunks[i] += 4ull * (mrk::MQ_BATCH + 1) * n_items_kind[1];
     for (int i = 0; i < 3; ++i) mq_chunks[i] = std::min<uint64_t>(mq_chunks[i], (uint64_t)b->ctx->mq_max_chunks);
   }
   const size_t n_items_bm = items.size() - n_items_pk;

@@ -104,10 +104,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
   const uint32_t nw = Q->n_weights < 8u ? Q->n_weights : 8u;
   const uint32_t index_weight = Q->index_weight;
   const bool inline_hits = a.seg.inline_hits != 0;
-  const bool need_hits = (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY)
-                             ? nterms > 1
-                             : (ranker == MRK_RANK_WORDCOUNT || ranker == MRK_RANK_MATCHANY || ranker == MRK_RANK_FIELDMASK ||
-                                ranker == MRK_RANK_SPH04);
+  // a root PHRASE / PROXIMITY: the docs that hold all its words are CANDIDATES, the word state machine of the hit pass decides
+  // (queue 1, rank_kernel<1>; the planner sends such a query here when its words are common: mrk_plan.cpp)
+  const bool fat_q = (Q->tree_flags & TF_FAT) != 0;
+  const bool need_hits = fat_q || ((ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY)
+                                       ? nterms > 1
+                                       : (ranker == MRK_RANK_WORDCOUNT || ranker == MRK_RANK_MATCHANY || ranker == MRK_RANK_FIELDMASK ||
+                                          ranker == MRK_RANK_SPH04));
   BtWaveLds& L = s.w[wave];
   for (uint32_t j = 0; j < nterms; ++j) s.tfidf[j][tid] = term_tfidf(tid, Q->t[j].idf);
   {
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
     if (tid < 8) s.fw[tid] = tid < nw ? Q->weights[tid] : 0;
   }
   // prune in front of the hit pass (mrk_kprune.h, prox_bounds): proximity rankers over distinct keywords, nothing that needs the exact weight of every match
-  const bool prune_prox = PRUNE && need_hits && a.q_hist_lb && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && !(Q->tree_flags & TF_DUPES) &&
+  const bool prune_prox = PRUNE && need_hits && !fat_q && a.q_hist_lb && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && !(Q->tree_flags & TF_DUPES) &&
                           Q->n_wfilters == 0 && Q->bin_mode == BIN_WEIGHT;
   uint32_t* __restrict__ ghist_lb = prune_prox ? a.q_hist_lb + (uint64_t)oq * NBINS : nullptr;
   uint32_t* __restrict__ ghist_lb2 = prune_prox ? a.q_hist_lb2 + (uint64_t)oq * NBINS : nullptr;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
   const uint32_t l2_rmax = a.seg.n_windows * 2048u - 1u; // >= every row of the segment
   const uint32_t l2_rshift = (32u - (uint32_t)__builtin_clz(l2_rmax | 1u)) > l2_rbits ? (32u - (uint32_t)__builtin_clz(l2_rmax | 1u)) - l2_rbits : 0u;
   auto write_chunk = [&](const uint32_t* v, uint32_t n) { // one chunk of the HBM match queue from registers: lane l = entry l, n entries
-    const MatchQueue& MQ = a.mq[0];
+    const MatchQueue& MQ = a.mq[fat_q ? 1 : 0];
     const uint32_t c = mq_take(MQ, mqw);
     if (c != 0xFFFFFFFFu) {
       uint32_t* __restrict__ d = MQ.data + (uint64_t)c * (MQ_PLANES * 64) + lane;
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
       return;
 #endif
       uint32_t vals[MQ_PLANES];
-      vals[0] = row, vals[1] = __float_as_uint(v0), vals[2] = (f0 & 0xffu) | (a0 << 8);
+      vals[0] = row, vals[1] = __float_as_uint(v0), vals[2] = (f0 & 0xffu) | ((fat_q ? 0xffu : a0) << 8); // (a phrase's words all emit: scan_pk_kernel's non-tree instance says 0xff)
 #pragma unroll
       for (int t = 0; t < MAX_PROX_TERMS; ++t) vals[3 + t] = href[t];
       if (!prune_prox) {
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
     for (int i = 0; i < MQ_PLANES; ++i) part[i] = L.pend[i * 64 + lane];
     write_chunk(part, pend_n);
   }
-  if (need_hits) mq_close(a.mq[0], mqw, item.query);
+  if (need_hits) mq_close(a.mq[fat_q ? 1 : 0], mqw, item.query);
   if (cn) publish();
   {
     uint32_t t = total;

@@ -103,6 +103,45 @@ def test_three_term_mixes_proximity_bm25(orc, corpus):
     assert n_ok >= 30
 
 
+def test_proximity_pruning_under_ties(orc, corpus):
+    """The weight bounds in front of the hit pass (prox_bounds; two-level lower-bound histogram, mrk_kprune.h) where they
+    matter most: SPH_RANK_PROXIMITY has no BM25 part, so whole populations of matches share one weight and the sorter picks by
+    rowid.  Pruned == unpruned bit for bit (common keywords, millions of matches), and == the oracle where the CPU gets through."""
+    m, hi = corpus
+    rng = np.random.default_rng(16)
+    qs, sizes = [], []
+    for t in range(12):
+        lo = 0 if t % 2 == 0 else 2  # even: the common keywords (prune on == off); odd: mid-range ones (oracle too)
+        a, b, c = (int(x) for x in rng.choice(np.arange(lo, lo + 5), 3, replace=False))
+        ka, kb, kc = kw(m, a, 1), kw(m, b, 2), kw(m, c, 3)
+        root = (OR(m, ka, kb), m.XQNode.AND(OR(m, ka, kb), kc), m.XQNode.AND(ka, OR(m, kb, kc)), OR(m, ka, OR(m, kb, kc)))[t % 4]
+        qs.append(m.Query(root, ranker=m.SPH_RANK_PROXIMITY if t % 3 else m.SPH_RANK_PROXIMITY_BM25, max_matches=(1000, 20, 300)[t % 3],
+                          field_weights=(None, [3, 1, 2], [2, -1, 1], [1, 1, 1])[t % 4], index_weight=1 + (t % 5 == 0) * 2))
+        sizes.append(lo)
+    out = {}
+    for prune in (1, 0):
+        ctx = m.Context(0)
+        ctx.set("prox_prune", prune)
+        seg, batch = m.Segment(ctx, hi), m.Batch(ctx, len(qs))
+        try:
+            out[prune] = batch.search(seg, qs)
+        finally:
+            batch.close()
+            seg.close()
+            ctx.close()
+    oi = orc_index_of(orc, hi)
+    n_orc = 0
+    for q, lo, g, p in zip(qs, sizes, out[1], out[0]):
+        assert g.status == 0 and p.status == 0
+        assert g.total_found == p.total_found and (g.rowid == p.rowid).all() and (g.weight == p.weight).all()
+        check_order(g)
+        if lo == 2 and g.total_found < 1_500_000:
+            want = to_orc(orc, q).run(oi)
+            assert g.total_found == want.total_found and (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+            n_orc += 1
+    assert n_orc >= 3
+
+
 def test_phrase_mix_with_field_weights(orc, corpus):
     """BASELINE config 5 shapes: PHRASE (alone, with another keyword, in an OR) + field weights, default ranker."""
     from test_gpu_parity import PHRASE
