@@ -125,6 +125,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
     if (tid < 8) s.fw[tid] = tid < nw ? Q->weights[tid] : 0;
   }
   // prune in front of the hit pass (mrk_kprune.h, prox_bounds): proximity rankers over distinct keywords, nothing that needs the exact weight of every match
+  const bool ph_lone = fat_q && (Q->tree_flags & TF_FAT) == TF_PHRASE && Q->px_dist == 0 && inline_hits && nterms >= 2; // (see score())
   const bool prune_prox = PRUNE && need_hits && !fat_q && a.q_hist_lb && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && !(Q->tree_flags & TF_DUPES) &&
                           Q->n_wfilters == 0 && Q->bin_mode == BIN_WEIGHT;
   uint32_t* __restrict__ ghist_lb = prune_prox ? a.q_hist_lb + (uint64_t)oq * NBINS : nullptr;
@@ -307,10 +308,38 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
       vals[0] = row, vals[1] = __float_as_uint(v0), vals[2] = (f0 & 0xffu) | ((fat_q ? 0xffu : a0) << 8); // (a phrase's words all emit: scan_pk_kernel's non-tree instance says 0xff)
 #pragma unroll
       for (int t = 0; t < MAX_PROX_TERMS; ++t) vals[3 + t] = href[t];
-      if (!prune_prox) {
+      bool keep = valid;
+      if (ph_lone) {
+        // A plain PHRASE over candidates whose words all have ONE hit each (it sits in the doclist entry: pk_hit): the phrase
+        // occurs iff the hits share the field and lie exactly their query positions apart (FSMphrase_c, searchnode.cpp:3884-3953,
+        // with one hit per word) -- a candidate that fails is no match and never travels to the hit pass.  Candidates with a
+        // longer hit list, and the ones that pass (their weight is the hit pass's business), go on as before.
+        bool lone = valid;
+#pragma unroll
+        for (int k = 0; k < BT_KW; ++k)
+          if ((uint32_t)k < nterms) lone = lone && (href[k] >> 31) != 0;
+        uint32_t d0 = 0;
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < BT_KW; ++k) {
+          if ((uint32_t)k < nterms) {
+            const DevTerm& T = Q->t[k];
+            const uint32_t r = href[k] & 0x7FFFFFFFu;
+            const uint32_t hv = lone ? a.seg.pk_hit[(uint64_t)(T.blk_first + (r >> 7)) * DEVBLK + (r & 127u)] : 0u;
+            const uint32_t d = (hv & ~(1u << 23)) - T.qpos; // (field << 24 | position) - query position: equal <=> same field, in step
+            if (k == 0)
+              d0 = d;
+            else
+              same = same && d == d0;
+          }
+        }
+        keep = valid && !(lone && !same);
+      }
+      if (!prune_prox && !ph_lone) {
         write_chunk(vals, n);
         return;
       }
+      if (prune_prox) {
       // bounds of the weight from what the doclists say; the lower bounds feed the query's histograms, the upper bound is tested
       uint32_t wlo, whi;
       prox_bounds(ranker, v0, a0, kf, BT_KW, s.fw, nw, index_weight, wlo, whi);
@@ -350,8 +379,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
         const uint32_t gt = __hip_atomic_load(gtau_lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gt > ((tau_lb << 10) | tau2)) tau_lb = gt >> 10, tau2 = gt & 1023u;
       }
-      const bool keep = valid && (bhi > tau_lb || (bhi == tau_lb && (!(tau_lb > 0 && tau_lb < (uint32_t)NBINS - 1u && l2_rbits > 0) || shi >= tau2)));
+      keep = valid && (bhi > tau_lb || (bhi == tau_lb && (!(tau_lb > 0 && tau_lb < (uint32_t)NBINS - 1u && l2_rbits > 0) || shi >= tau2)));
       total += (valid && !keep) ? 1u : 0u; // a match all the same (CSphMatchQueue::PushT counts every push): rank_kernel counts the ones it sees
+      }
 #if MRK_BTEXP == 7
       total += keep ? 1u : 0u;
       return;
@@ -580,7 +610,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
     }
   }
   if (qn) score(0, qn);
-  if (PRUNE && pend_n) {
+  if (pend_n) {
     wave_lds_fence();
     uint32_t part[MQ_PLANES];
 #pragma unroll
