@@ -462,7 +462,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
   for (uint32_t wb = w0; wb < w1; wb += BT_SPAN) {
     // one step = BT_SPAN windows = 8192 rowids (a step used to be one window, one word per lane: the tree program, the prefix sums
     // and the loop around them cost the same per step whatever the lane holds, and at 14 matches per window they, not the matches,
-    // were the kernel).  (Requesting the NEXT step's words ahead of this one's work bought nothing: measured, 1.42 vs 1.39 ms.)
+    // were the kernel).  Requesting the NEXT step's words ahead of this one's work bought nothing, twice: into registers (1.42 vs
+    // 1.39 ms, 60 B of scratch) and by LDS DMA into landing rows of their own (global_load_lds_dwordx4; 53 KB of LDS = three
+    // workgroups per CU: config 3 4.85 -> 5.2 ms, config 5's two-word ANDs 12.9 -> 13.9 ms) -- the step is not what the waves wait for.
     uint4 nkw[BT_KW], ndw;
     load_step(wb, nkw, ndw);
     uint64_t klo[BT_KW], khi[BT_KW]; // rowids [0, 64) and [64, 128) of the lane, per keyword
