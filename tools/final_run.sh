@@ -7,9 +7,9 @@ OUT=$ROOT/gpurun_out
 cd $ROOT
 python -m pytest tests -x -q -m gpu > $OUT/fin_tests.log 2>&1
 python bench.py > $OUT/fin_bench.json 2> $OUT/fin_bench.err
-python bench.py --docs 10000000 --no-config3 > $OUT/fin_bench_10M.json 2> $OUT/fin_bench_10M.err
+python bench.py --docs 10000000 --no-config3 --no-config5 > $OUT/fin_bench_10M.json 2> $OUT/fin_bench_10M.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fin_prof -o f -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/fin_prof_bench.json 2> $OUT/fin_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fin_prof -o f -- python3 $ROOT/bench.py --no-cpu-baseline --no-config5 > $OUT/fin_prof_bench.json 2> $OUT/fin_prof.err
 cd $ROOT
 tail -2 $OUT/fin_tests.log
 python - <<PY
