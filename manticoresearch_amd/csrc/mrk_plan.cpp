@@ -1142,7 +1142,9 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
               !T.termpos && !T.notnear && !filtered && q.n_weight_filters == 0 && n <= MAX_PROX_TERMS && seg->total_docs < (1ull << 32) && T.nodes.size() <= 16;
     uint64_t cover_docs = 0;
     for (int k : cover) cover_docs += (uint64_t)T.kws[k].docs;
-    ok = ok && cover_docs * (uint64_t)seg->ctx->bt_cover_inv >= seg->total_docs;
+    // (a pure AND keeps the old bar of 1/32: below it the block walk behind a selective driver -- skiplist seeks, a probe per doc --
+    // beats streaming every keyword's bitmap; with 1/1024 the headline's selective x common stratum went from 0.36 to 0.54 ms)
+    ok = ok && cover_docs * (uint64_t)(pure_and ? std::min(seg->ctx->bt_cover_inv, 32) : seg->ctx->bt_cover_inv) >= seg->total_docs;
     int n_dense = 0;
     for (int k = 0; ok && k < n; ++k) {
       ok = (T.kws[k].queried32 & all_fields) == all_fields;
