@@ -236,7 +236,9 @@ int mrk_ctx_destroy(mrk_ctx* ctx);
    still goes through RCCL, default 0);
    "bt_cover_inv" (boolean trees whose candidate cover -- the keywords whose doc lists together hold every possible match --
    names >= 1/bt_cover_inv of the segment's docs are evaluated on doc-set bitmap words, 8192 rowids per step, instead of
-   block by block; default 1024, 0 = never; read at submit);
+   block by block; default 1024 -- a pure AND of keywords only from 1/32 --, 0 = never; read at submit);
+   "bt_phrase" (1 = a root PHRASE / PROXIMITY whose rarest word holds >= 1/bt_cover_inv of the docs takes its candidates -- the AND of
+   its words -- from the bitmap words too, default; 0 = block walk);
    "mq_max_chunks" (cap of a batch's match queue -- matched docs of hit-ranked queries on their way to the ranking kernel -- in
    chunks of 64 docs / 1792 bytes, default 2^20; queries that outgrow it are rerun one by one by mrk_batch_wait);
    "gen_lane_hits" / "gen_spill_mb" (the generic per-doc evaluator -- query shapes the specialised hit passes do not take: more
