@@ -155,6 +155,10 @@ def main() -> None:
     t_gen = time.time() - t_setup
 
     ctx = m.Context(local_rank)
+    # the main corpus is written WITHOUT field-end flags, so hits at one position reach the ranker in query-position order and the
+    # tighter of the two weight bounds in front of the hit pass is sound (mrk_kprune.h, prox_bounds; only config 3 uses a hit ranker here);
+    # config 5's corpus flags each keyword's own last hit -- not what the reference's indexer writes -- and runs with the bound by hits
+    ctx.set("prox_bound_keywords", 1)
     if args.item_bytes:
         ctx.set("item_bytes", args.item_bytes)
     ctx.set("path", args.path)
@@ -491,7 +495,8 @@ def main() -> None:
         out["config3"] = {"workload": f"{nq} queries/launch: a b c | (a|b) c | a (b|c) | a b -c, SPH_RANK_PROXIMITY_BM25, top-{K}",
                           "queries_per_s": round(reps * nq / dt3, 1), "scan_ms": round(st3["scan_ms"], 4),
                           "merge_ms": round(st3["merge_ms"], 4), "algo_MB": round(st3["algo_bytes"] / 1e6, 2),
-                          "ok": int(sum(r.status == 0 for r in res3)), "matches": int(sum(r.total_found for r in res3))}
+                          "ok": int(sum(r.status == 0 for r in res3)), "matches": int(sum(r.total_found for r in res3)),
+                          "weight_bound": "by keywords (prox_bound_keywords=1: this corpus holds no field-end flags)"}
         for bb in b3:
             bb.close()
     # HBM footprint of what this run holds: the materialised query terms only (the corpus' other ~10^6 terms were never generated)
@@ -572,6 +577,7 @@ def config5_leg(m, ctx, args, c, K):
     probs = [min(0.5, c / r) for r in ranks]
     hi5 = m.synth_index(args.config5_docs, probs, seed=CORPUS_SEED + 5, n_fields=4, end_markers=True, skiplist_block_size=args.skiplist_block)
     t_gen = time.time() - t0
+    ctx.set("prox_bound_keywords", 0)  # (read when a batch is planned: config 5 is the last leg that plans any)
     seg5 = m.Segment(ctx, hi5)
     gd = hi5.dict["docs"].astype(np.int64)
     qs = config5_queries(m, strata, nq5, K, args.config5_docs, gd, fw)
@@ -594,7 +600,8 @@ def config5_leg(m, ctx, args, c, K):
            "queries_per_s": round(reps * nq5 / dt, 1), "ms_per_launch": round(dt / reps * 1e3, 3), "scan_ms": round(st["scan_ms"], 4),
            "select_ms": round(st["merge_ms"], 4), "doclist_MB": round(st["algo_bytes"] / 1e6, 2), "ok": int(sum(r.status == 0 for r in res)),
            "declined": int(sum(r.status != 0 for r in res)), "matches": int(sum(r.total_found for r in res)),
-           "device_bytes": int(seg5.device_bytes), "postings": int(gd.sum()), "setup_s": {"generate": round(t_gen, 1), "total": round(time.time() - t0, 1)}}
+           "device_bytes": int(seg5.device_bytes), "postings": int(gd.sum()), "setup_s": {"generate": round(t_gen, 1), "total": round(time.time() - t0, 1)},
+           "weight_bound": "by hits (prox_bound_keywords=0: this corpus flags each keyword's own last hit of a field)"}
     for bb in bs:
         bb.close()
     seg5.close()

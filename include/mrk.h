@@ -232,6 +232,10 @@ int mrk_ctx_destroy(mrk_ctx* ctx);
    batches that feed the hit pass; default 7 -- small items are the fast ones); "pk_min_items" (a batch with fewer block-scan work items
    has its block ranges cut finer, default 2048);
    "prox_prune" (1 = proximity rankers: matches whose weight upper bound cannot reach the top K skip the hit pass, default);
+   "prox_bound_keywords" (0 = that bound takes a proximity run to be as long as the field's hits allow: always sound, default;
+   1 = as long as the number of keywords in the field -- tighter, and sound where hits of different keywords at ONE position reach
+   the ranker in query-position order: indexes whose field-end flag belongs to the position, which is what the reference's indexer
+   writes (sphinx.cpp:22424-22430), or that carry no field-end flags; the caller's statement about the context's indexes, read at submit);
    "exchange_part" (1 = mrk_shard_exchange partitions the merge by query, default), "exchange_self_rccl" (1 = a one-rank exchange
    still goes through RCCL, default 0);
    "bt_cover_inv" (boolean trees whose candidate cover -- the keywords whose doc lists together hold every possible match --

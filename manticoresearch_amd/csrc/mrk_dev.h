@@ -199,6 +199,7 @@ constexpr uint32_t TF_PHRASE_LEAF = 8; // one PHRASE below other operators: ph_m
 constexpr uint32_t TF_PHRASE = 2;   // the whole query is one PHRASE: ph_atoms[] = atom positions in phrase order
 constexpr uint32_t TF_FAT = TF_PHRASE | TF_PHRASE_LEAF | TF_TERMPOS | TF_ORDER | TF_NOTNEAR; // final ranking needs the full hit pass (rank_kernel<true>)
 constexpr uint32_t TF_GEN = 1024;   // answered by the generic per-doc evaluator (mrk_keval.h): matches go to queue 2 with one reference per keyword
+constexpr uint32_t TF_LCS_BY_KEYWORDS = 4096; // the weight bounds may take "one hit per keyword" for a proximity run's length (ctx key prox_bound_keywords; mrk_kprune.h, prox_bounds)
 constexpr uint32_t TF_GEN_NEARN = 2048; // ... whose root is a NEAR over three and more operands: its folded hits' query position needs the probe launch
 constexpr int PHRASE_STATES = 8;    // live FSMphrase_c states per doc (>= phrase span + 1)
 constexpr int TREE_STACK = 4;       // evaluation stack depth of the tree program

@@ -248,6 +248,11 @@ extern "C" int mrk_ctx_set(mrk_ctx* c, const char* key, int64_t value) {
     c->bm_target_items = (int)value;
     return MRK_OK;
   }
+  if (!strcmp(key, "prox_bound_keywords")) {
+    if (value < 0 || value > 1) return mrk_fail(MRK_E_INVAL, "prox_bound_keywords must be 0 or 1");
+    c->prox_bound_keywords = (int)value;
+    return MRK_OK;
+  }
   if (!strcmp(key, "bt_phrase")) {
     if (value < 0 || value > 1) return mrk_fail(MRK_E_INVAL, "bt_phrase must be 0 or 1");
     c->bt_phrase = (int)value;

@@ -41,6 +41,7 @@ struct mrk_ctx {
   int exchange_self_rccl = 0;     // one rank: still send the rows to itself through RCCL (rehearsal of the collective path)
   int item_order = 7;             // work items of different queries interleaved (piece-major): 1 = block scan, 2 = bitmap AND, 4 = bitmap trees; 0 = query-major
   int bt_target_items = 6144;     // ... and the tree kernel over bitmap words
+  int prox_bound_keywords = 0;    // 1: equal positions of different keywords sort by query position in this context's indexes (see mrk.h) -- the tighter weight bound is sound
   int bt_phrase = 1;              // root PHRASE / PROXIMITY of common words: the AND of the words runs on bitmap words too (0 = block walk)
   int bt_cover_inv = 1024;        // trees whose candidate cover holds >= 1/bt_cover_inv of the docs run on bitmap words (0 = never; 32 until the step grew to 8192 rowids: config 3 5.4 -> 4.8 ms)
   int gen_lane_hits = 256;        // generic evaluator: hits (16 B) of per-lane list memory, GEN_GRID * 256 lanes

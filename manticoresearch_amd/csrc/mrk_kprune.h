@@ -209,20 +209,36 @@ __device__ __forceinline__ uint32_t nth_set_bit64(uint64_t m, uint32_t n) {
 
 // Bounds of a match's weight under the proximity rankers BEFORE its hits are read (round 3).  RankerState_Proximity_fn
 // (sphinxsearch.cpp:1320-1438) adds 1000 x sum_f LCS[f] x w[f] to the BM25 part; LCS[f] is the longest run of hits of
-// field f whose query positions advance with their positions.  Without repeated keywords such a run holds every keyword at
-// most once, and a single hit already makes a run of one: with cnt_f = the number of hit-emitting keywords that have field f
-// in their (queried) field mask -- both known from the doclists --, 1 <= LCS[f] <= cnt_f wherever cnt_f > 0.  The scan keeps a
-// histogram of the LOWER bounds: K docs whose lower bound reaches bin T prove that the K-th best weight reaches it, and a doc
-// whose UPPER bound stays below T cannot enter the top K -- it is counted (total_found) and never travels to the hit pass.
-__device__ __forceinline__ void prox_bounds(uint32_t ranker, float acc, uint32_t emit, const uint32_t* kf, int nk, const int32_t* fw, uint32_t nw,
-                                            uint32_t index_weight, uint32_t& wlo, uint32_t& whi) {
+// field f whose (position - query position) stays the same.  A single hit already makes a run of one, and every hit adds at
+// most one to a run, so 1 <= LCS[f] <= h_f wherever the field has a hit at all, h_f = the hits the emitting keywords can have
+// in field f.  The doclists say, per keyword, its hit count tf and the fields F it occurs in -- each of those holds at least one
+// of its hits, so at most tf - |F| + 1 of them lie in any one field: h_f = sum over the emitting keywords with f in F of
+// (tf - |F| + 1).
+// A tighter end holds where hits at one (field, position) reach the ranker in query-position order: the run's position groups then
+// have strictly increasing query positions (p' - qmin' = p - qmax with p' > p), so a run holds every keyword at most once and
+// LCS[f] <= the number of emitting keywords with f in F.  The merges of AND / OR / MAYBE / ANDNOT order by (Hitpos_t, query position)
+// (IsHitLess, searchnode.cpp:2611) and Hitpos_t carries the field-END flag: the order is by query position iff that flag belongs to the
+// POSITION -- the reference's indexer marks every hit of a field's tail position (sphinx.cpp:22424-22430) -- or no hit carries one.
+// A writer that flags each keyword's own last hit (the synthetic corpora with end_markers do) breaks it: 't2@2, t0@2|END, t2@3' runs
+// to three with two keywords (found by a soak of the fuzz test with a fresh seed, MRK_FUZZ_SEED=777, after the second level below
+// began to cut INSIDE the threshold bin; until then the tight end was the only one).  So the tight end is the caller's statement
+// about the index (ctx key prox_bound_keywords -> TF_LCS_BY_KEYWORDS); the default is the bound by hits.
+// The scan keeps a histogram of the LOWER bounds: K docs whose lower bound reaches bin T prove that the K-th best weight
+// reaches it, and a doc whose UPPER bound stays below T cannot enter the top K -- it is counted (total_found) and never
+// travels to the hit pass.
+__device__ __forceinline__ void prox_bounds(uint32_t ranker, float acc, uint32_t emit, const uint32_t* kf, const uint32_t* ktf, int nk, const int32_t* fw, uint32_t nw,
+                                            uint32_t index_weight, bool by_keywords, uint32_t& wlo, uint32_t& whi) {
   int lo = 0, hi = 0;
+  int room[MAX_PROX_TERMS]; // hits of keyword k that one field's run can take at most
+#pragma unroll
+  for (int k = 0; k < MAX_PROX_TERMS; ++k) room[k] = k < nk && ((emit >> k) & 1u) ? (by_keywords ? 1 : (int)ktf[k] - (int)__popc(kf[k]) + 1) : 0;
   for (uint32_t f = 0; f < nw; ++f) {
-    int cnt = 0;
-    for (int k = 0; k < nk; ++k) cnt += (int)(((emit >> k) & 1u) & ((kf[k] >> f) & 1u));
-    const int w = fw[f], one = cnt ? 1 : 0;
-    lo += w >= 0 ? w * one : w * cnt;
-    hi += w >= 0 ? w * cnt : w * one;
+    int h = 0;
+#pragma unroll
+    for (int k = 0; k < MAX_PROX_TERMS; ++k) h += ((kf[k] >> f) & 1u) ? room[k] : 0;
+    const int w = fw[f], one = h > 0 ? 1 : 0;
+    lo += w >= 0 ? w * one : w * h;
+    hi += w >= 0 ? w * h : w * one;
   }
   const int32_t bm = (int32_t)((acc + 0.5f) * 1000.0f);
   if (ranker == MRK_RANK_PROXIMITY_BM25)

@@ -1158,7 +1158,7 @@ int mrk::plan_query(const mrk_segment* seg, const mrk_query& q, int64_t item_byt
     if (ok && n_dense > 0) {
       dq.n_terms = (uint32_t)n;
       for (int i = 0; i < n; ++i) fill_term(seg, T.kws[i], dq.t[i]);
-      dq.tree_flags = (pure_and ? TF_MULTIAND : 0) | (got_dupes ? TF_DUPES : 0) | TF_BTREE;
+      dq.tree_flags = (pure_and ? TF_MULTIAND : 0) | (got_dupes ? TF_DUPES : 0) | TF_BTREE | (seg->ctx->prox_bound_keywords ? TF_LCS_BY_KEYWORDS : 0);
       dq.n_nodes = (uint32_t)T.nodes.size();
       for (size_t i = 0; i < T.nodes.size(); ++i) {
         const PlanNode& pn = T.nodes[i];

@@ -31,7 +31,7 @@
 #define MRK_BT_WAVES 4 // waves per SIMD the register allocation is made for
 #endif
 #ifndef MRK_BTEXP
-#define MRK_BTEXP 0 // ablations for profiling: 1 no match-queue write, 2 no scoring, 3 no match extraction, 4 no sparse keywords, 6 no lower-bound histogram, 7 bounds but no queue write
+#define MRK_BTEXP 0 // ablations for profiling: 1 no match-queue write, 2 no scoring, 3 no match extraction, 4 no sparse keywords, 6 no lower-bound histogram, 7 bounds but no queue write, 8 no second level of the lower-bound histogram
 #endif
 
 namespace mrk {
@@ -180,7 +180,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
   // pruned hit-ranked matches: the survivors of a scoring round are compacted into the wave's pending chunk (LDS) until 64 are there
   uint32_t tau_lb = 0, tau2 = 0, lb_rounds = 0, lb_added = 0, pend_n = 0;
   // second level of the lower-bound histogram: 10 bits = the weight's offset inside its bin (bin_shift bits) + rowid slices
+#if MRK_BTEXP == 8 // (ablation: first level only)
+  const uint32_t l2_rbits = 0u;
+#else
   const uint32_t l2_rbits = bin_shift < 10u ? 10u - bin_shift : 0u;
+#endif
   const uint32_t l2_rmax = a.seg.n_windows * 2048u - 1u; // >= every row of the segment
   const uint32_t l2_rshift = (32u - (uint32_t)__builtin_clz(l2_rmax | 1u)) > l2_rbits ? (32u - (uint32_t)__builtin_clz(l2_rmax | 1u)) - l2_rbits : 0u;
   auto write_chunk = [&](const uint32_t* v, uint32_t n) { // one chunk of the HBM match queue from registers: lane l = entry l, n entries
@@ -242,10 +246,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
     const uint32_t e = from + (valid ? lane : 0u);
     const uint32_t row = L.q_row[e], pm = valid ? L.q_pm[e] : 0u;
     float kv[BT_KW];
-    uint32_t kf[BT_KW], href[BT_KW];
+    uint32_t kf[BT_KW], ktf[BT_KW], href[BT_KW];
 #pragma unroll
     for (int k = 0; k < BT_KW; ++k) {
-      kv[k] = 0.0f, kf[k] = 0, href[k] = 0;
+      kv[k] = 0.0f, kf[k] = 0, ktf[k] = 0, href[k] = 0;
       if ((uint32_t)k < nterms) {
         const DevTerm& T = Q->t[k];
         const bool pres = ((pm >> k) & 1u) != 0;
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
         if (pres) {
           kf[k] = (wd >> (16u + sh)) & 0xffu & T.queried32; // (all fields queried: the doc's own field bits)
           kv[k] = tf == 255u ? term_tfidf(exc_tf(a.seg, T, row), T.idf) : s.tfidf[k][tf];
+          ktf[k] = tf == 255u ? 0xFFFFu : tf; // (a saturated count: "many" is all the weight bounds need to know)
           href[k] = ((inline_hits && tf == 1u) ? 0x80000000u : 0u) | r;
         }
       }
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
       if (prune_prox) {
       // bounds of the weight from what the doclists say; the lower bounds feed the query's histograms, the upper bound is tested
       uint32_t wlo, whi;
-      prox_bounds(ranker, v0, a0, kf, BT_KW, s.fw, nw, index_weight, wlo, whi);
+      prox_bounds(ranker, v0, a0, kf, ktf, BT_KW, s.fw, nw, index_weight, (Q->tree_flags & TF_LCS_BY_KEYWORDS) != 0, wlo, whi);
       // (only lower bounds that reach the current threshold can raise it: the others are never counted -- an undercounted
       // histogram only makes the threshold lower than it could be -- and once the threshold stands almost no round adds anything)
       const uint32_t blo = bin_of(BIN_WEIGHT, bin_lo, bin_shift, (int32_t)wlo, 0u);
@@ -381,6 +386,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
       }
       keep = valid && (bhi > tau_lb || (bhi == tau_lb && (!(tau_lb > 0 && tau_lb < (uint32_t)NBINS - 1u && l2_rbits > 0) || shi >= tau2)));
       total += (valid && !keep) ? 1u : 0u; // a match all the same (CSphMatchQueue::PushT counts every push): rank_kernel counts the ones it sees
+#ifdef MRK_BT_DEBUG_ROW
+      if (valid && row == MRK_BT_DEBUG_ROW)
+        printf("bt debug: q %u row %u keep %d wlo %u whi %u blo %u bhi %u T %u tau2 %u slo %u shi %u shift %u lo %d rbits %u rshift %u acc %f emit %x kf %x %x %x %x pm %x K %u\n", oq, row, (int)keep, wlo, whi, blo, bhi,
+               tau_lb, tau2, slo, shi, bin_shift, bin_lo, l2_rbits, l2_rshift, v0, a0, kf[0], kf[1], kf[2], kf[3], pm, K);
+#endif
       }
 #if MRK_BTEXP == 7
       total += keep ? 1u : 0u;

@@ -1069,6 +1069,43 @@ def test_generic_evaluator_vs_oracle(orc, dev):
     assert n_checked >= 150
 
 
+def test_proximity_bounds_with_shared_positions(orc, dev):
+    """Two keywords may share a position (exact forms next to lemmas, blended parts): a proximity run then carries on through the
+    shared position and LCS exceeds the number of keywords.  The weight bounds in front of the hit pass (prox_bounds) must allow
+    for it -- a bound of "one per keyword" once dropped such a doc from the top K (MRK_FUZZ_SEED=777, trial 22 of the fuzz below).
+    Corpus: four positions per field, so positions collide all the time; OR / AND-OR shapes over dense keywords, small and large
+    K, field weights: device == oracle."""
+    m, ctx, batch = dev
+    if ctx_path(ctx) != 0:
+        pytest.skip("pruning in front of the hit pass: packed path only")
+    rng = np.random.default_rng(777022)
+    n_docs = 30000
+    probs = [0.7, 0.7, 0.5, 0.3]
+    W, R, H = synth_postings(rng, n_docs, probs, n_fields=3, max_pos=4, end_markers=True)
+    hi = m.index_from_hits(W, R, H, n_terms=len(probs) + 1, total_docs=n_docs, skiplist_block_size=128, hit_format=1, n_fields=3)
+    seg = m.Segment(ctx, hi)
+    oi = orc_index_of(orc, hi)
+    qs = []
+    for k_ in (1, 10, 100, 1000):
+        for fw in (None, [7, 8, 8], [1, 5, -2]):
+            a, b, c = kw(m, 0, 1), kw(m, 1, 2), kw(m, 2, 3)
+            for root in (QUORUM(m, 1, a, b), OR(m, a, b), m.XQNode.AND(OR(m, a, b), c), OR(m, a, OR(m, b, c)), MAYBE(m, a, b)):
+                qs.append(m.Query(root, ranker=m.SPH_RANK_PROXIMITY_BM25 if k_ != 10 else m.SPH_RANK_PROXIMITY, max_matches=k_, field_weights=fw))
+    try:
+        n_ok = 0
+        for i in range(0, len(qs), 24):
+            part = qs[i:i + 24]
+            for q, g in zip(part, batch.search(seg, part)):
+                assert g.status == 0
+                want = to_orc(orc, q).run(oi)
+                assert g.total_found == want.total_found
+                assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all(), (q.max_matches, q.field_weights, q.ranker)
+                n_ok += 1
+        assert n_ok == len(qs)
+    finally:
+        seg.close()
+
+
 # ------------------------------------------------------------------ many tiny corpora: boundaries of blocks / windows
 def test_fuzz_tiny_corpora_all_shapes(orc, dev):
     """Corpora of 1 .. 5000 docs (below / around one 128-doc block and one 2048-rowid window), every query shape the
@@ -1076,6 +1113,9 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
     m, ctx, batch = dev
     import os
     rng = np.random.default_rng(int(os.environ.get("MRK_FUZZ_SEED", 424242)))
+    tuned = [kv.split("=") for kv in os.environ.get("MRK_FUZZ_CTX", "").split(",") if kv]  # e.g. prox_prune=0,bt_phrase=0: localise a mismatch
+    for k_, v_ in tuned:
+        ctx.set(k_, int(v_))
     packed = ctx_path(ctx) == 0
     n_checked = 0
     for trial in range(int(os.environ.get("MRK_FUZZ_TRIALS", 28))):  # MRK_FUZZ_TRIALS=500 for a long soak
@@ -1157,13 +1197,21 @@ def test_fuzz_tiny_corpora_all_shapes(orc, dev):
             seg.set_dead_rows(dead)
             oi.dead_rows = dead
         try:
-            for q, g in zip(qs, batch.search(seg, qs)):
+            for qi_, (q, g) in enumerate(zip(qs, batch.search(seg, qs))):
                 if g.status == -2:
                     continue
                 want = to_orc(orc, q).run(oi)
+                what = (trial, n_docs, qi_, q.ranker, q.max_matches, q.field_weights, base, block, fmt)
                 assert g.status == 0
-                assert g.total_found == want.total_found, (trial, n_docs, g.total_found, want.total_found)
-                assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all(), (trial, n_docs)
+                if os.environ.get("MRK_FUZZ_CTX") is not None and not ((g.rowid == want.rowid).all() and (g.weight == want.weight).all()):
+                    def tree(nd):
+                        return ("t%d@%d" % (nd.word.term_id, nd.word.atom_pos)) if nd.word is not None else (nd.op, nd.opt, [tree(c) for c in nd.children])
+                    bad = [(i_, int(a), int(b), int(c), int(d)) for i_, (a, b, c, d) in enumerate(zip(g.rowid, g.weight, want.rowid, want.weight)) if a != c or b != d]
+                    print("MISMATCH", what, tree(q.root), "n", len(g.rowid), len(want.rowid), "total", g.total_found, "docs", [int(x) for x in hi.dict["docs"]],
+                          "first", bad[:6], "last", bad[-3:], "dead" if oi.dead_rows is not None else "", flush=True)
+                assert g.total_found == want.total_found, what + (g.total_found, want.total_found)
+                assert (g.rowid == want.rowid).all() and (g.weight == want.weight).all(), what + (
+                    [(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(g.rowid, g.weight, want.rowid, want.weight) if a != c or b != d][:4],)
                 n_checked += 1
         finally:
             seg.close()

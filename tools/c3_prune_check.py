@@ -25,6 +25,7 @@ gd = hi.dict["docs"].astype(np.int64)
 out = []
 for prune in (1, 0):
     ctx = m.Context(0)
+    ctx.set("prox_bound_keywords", 1)  # the bench corpus carries no field-end flags: see bench.py
     ctx.set("prox_prune", prune)
     seg = m.Segment(ctx, hi)
     qs = bench.config3_queries(m, strata, args.queries, 1000, args.docs, gd)

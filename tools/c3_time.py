@@ -28,6 +28,7 @@ probs = [min(0.5, c / r) for r in ranks]
 t0 = time.time()
 hi = m.synth_index(args.docs, probs, seed=bench.CORPUS_SEED)
 ctx = m.Context(0)
+ctx.set("prox_bound_keywords", 1)  # the bench corpus carries no field-end flags: see bench.py
 for kv in args.set:
     k, v = kv.split("=")
     ctx.set(k, int(v))
