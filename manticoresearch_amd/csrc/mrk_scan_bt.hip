@@ -126,7 +126,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
   }
   // prune in front of the hit pass (mrk_kprune.h, prox_bounds): proximity rankers over distinct keywords, nothing that needs the exact weight of every match
   const bool ph_lone = fat_q && (Q->tree_flags & TF_FAT) == TF_PHRASE && Q->px_dist == 0 && inline_hits && nterms >= 2; // (see score())
-  const bool prune_prox = PRUNE && need_hits && !fat_q && a.q_hist_lb && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && !(Q->tree_flags & TF_DUPES) &&
+  // the bounds are 32-bit like the weights: a run of up to 4 x 255 hits times the field weights, x 1000, x index_weight must fit (absurd
+  // weights: no pruning -- the weights themselves wrap there as the reference's int does)
+  uint64_t wabs = 0;
+  for (uint32_t f = 0; f < nw; ++f) wabs += (uint64_t)(Q->weights[f] < 0 ? -(int64_t)Q->weights[f] : (int64_t)Q->weights[f]);
+  const bool bounds_fit = (wabs * 1020ull * 1000ull + 1000ull) * (uint64_t)index_weight < (1ull << 32);
+  const bool prune_prox = PRUNE && need_hits && !fat_q && bounds_fit && a.q_hist_lb && (ranker == MRK_RANK_PROXIMITY_BM25 || ranker == MRK_RANK_PROXIMITY) && !(Q->tree_flags & TF_DUPES) &&
                           Q->n_wfilters == 0 && Q->bin_mode == BIN_WEIGHT;
   uint32_t* __restrict__ ghist_lb = prune_prox ? a.q_hist_lb + (uint64_t)oq * NBINS : nullptr;
   uint32_t* __restrict__ ghist_lb2 = prune_prox ? a.q_hist_lb2 + (uint64_t)oq * NBINS : nullptr;
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRK_BT_WAVES
         if (pres) {
           kf[k] = (wd >> (16u + sh)) & 0xffu & T.queried32; // (all fields queried: the doc's own field bits)
           kv[k] = tf == 255u ? term_tfidf(exc_tf(a.seg, T, row), T.idf) : s.tfidf[k][tf];
-          ktf[k] = tf == 255u ? 0xFFFFu : tf; // (a saturated count: "many" is all the weight bounds need to know)
+          ktf[k] = tf; // (255 = "255 or more": a run is counted in a byte, RankState::lcs, so 255 already bounds it)
           href[k] = ((inline_hits && tf == 1u) ? 0x80000000u : 0u) | r;
         }
       }
