@@ -142,6 +142,48 @@ def test_proximity_pruning_under_ties(orc, corpus):
     assert n_orc >= 3
 
 
+def test_proximity_bound_by_keywords_on_a_corpus_without_end_flags(orc):
+    """ctx key prox_bound_keywords = 1: the tighter weight bound in front of the hit pass (a proximity run holds every keyword at most
+    once).  It is sound where hits of different keywords at one position reach the ranker in query-position order -- here: a corpus
+    WITHOUT field-end flags and only 16 positions per field, so keywords share positions in most docs.  Device (pruned, tight bound) ==
+    device (unpruned) == oracle."""
+    import manticoresearch_amd as m
+
+    probs = [0.3, 0.12, 0.06, 0.031, 0.012, 0.004]
+    hi = m.synth_index(3_000_000, probs, seed=20261005, n_fields=2, max_pos=16, end_markers=False)
+    rng = np.random.default_rng(26)
+    qs = []
+    for t in range(16):
+        a, b, c = (int(x) for x in rng.choice(np.arange(0 if t % 4 == 0 else 1, 5), 3, replace=False))
+        ka, kb, kc = kw(m, a, 1), kw(m, b, 2), kw(m, c, 3)
+        root = (OR(m, ka, kb), m.XQNode.AND(OR(m, ka, kb), kc), m.XQNode.AND(ka, OR(m, kb, kc)), OR(m, ka, OR(m, kb, kc)))[t % 4]
+        qs.append(m.Query(root, ranker=m.SPH_RANK_PROXIMITY_BM25 if t % 3 else m.SPH_RANK_PROXIMITY, max_matches=(1000, 50, 300)[t % 3],
+                          field_weights=(None, [3, 1], [2, -1], [1, 1])[t % 4]))
+    out = {}
+    for prune in (1, 0):
+        ctx = m.Context(0)
+        ctx.set("prox_prune", prune)
+        ctx.set("prox_bound_keywords", 1)
+        seg, batch = m.Segment(ctx, hi), m.Batch(ctx, len(qs))
+        try:
+            out[prune] = batch.search(seg, qs)
+        finally:
+            batch.close()
+            seg.close()
+            ctx.close()
+    oi = orc_index_of(orc, hi)
+    n_orc = 0
+    for q, g, p in zip(qs, out[1], out[0]):
+        assert g.status == 0 and p.status == 0
+        assert g.total_found == p.total_found and (g.rowid == p.rowid).all() and (g.weight == p.weight).all()
+        check_order(g)
+        if g.total_found < 600_000:
+            want = to_orc(orc, q).run(oi)
+            assert g.total_found == want.total_found and (g.rowid == want.rowid).all() and (g.weight == want.weight).all()
+            n_orc += 1
+    assert n_orc >= 6
+
+
 def test_phrase_mix_with_field_weights(orc, corpus):
     """BASELINE config 5 shapes: PHRASE (alone, with another keyword, in an OR) + field weights, default ranker."""
     from test_gpu_parity import PHRASE
