@@ -155,9 +155,9 @@ def main() -> None:
     t_gen = time.time() - t_setup
 
     ctx = m.Context(local_rank)
-    # the main corpus is written WITHOUT field-end flags, so hits at one position reach the ranker in query-position order and the
-    # tighter of the two weight bounds in front of the hit pass is sound (mrk_kprune.h, prox_bounds; only config 3 uses a hit ranker here);
-    # config 5's corpus flags each keyword's own last hit -- not what the reference's indexer writes -- and runs with the bound by hits
+    # the main corpus is written WITHOUT field-end flags, config 5's with the flag on the hit at a field's last position whatever the
+    # word (what the reference's indexer writes): in both, hits at one position reach the ranker in query-position order and the tighter of
+    # the two weight bounds in front of the hit pass is sound (mrk_kprune.h, prox_bounds)
     ctx.set("prox_bound_keywords", 1)
     if args.item_bytes:
         ctx.set("item_bytes", args.item_bytes)
@@ -575,9 +575,10 @@ def config5_leg(m, ctx, args, c, K):
     nq5, fw = 1024, (10, 5, 2, 1)
     ranks, strata = make_queries(c, 342)
     probs = [min(0.5, c / r) for r in ranks]
-    hi5 = m.synth_index(args.config5_docs, probs, seed=CORPUS_SEED + 5, n_fields=4, end_markers=True, skiplist_block_size=args.skiplist_block)
+    hi5 = m.synth_index(args.config5_docs, probs, seed=CORPUS_SEED + 5, n_fields=4, end_markers=2, skiplist_block_size=args.skiplist_block)
     t_gen = time.time() - t0
-    ctx.set("prox_bound_keywords", 0)  # (read when a batch is planned: config 5 is the last leg that plans any)
+    # (config 5's corpus carries field-end flags the way the reference's indexer writes them -- on the hit at a field's last position,
+    # whatever the word: end_markers=2 -- so the statement made for the main corpus holds here too)
     seg5 = m.Segment(ctx, hi5)
     gd = hi5.dict["docs"].astype(np.int64)
     qs = config5_queries(m, strata, nq5, K, args.config5_docs, gd, fw)
@@ -601,7 +602,7 @@ def config5_leg(m, ctx, args, c, K):
            "select_ms": round(st["merge_ms"], 4), "doclist_MB": round(st["algo_bytes"] / 1e6, 2), "ok": int(sum(r.status == 0 for r in res)),
            "declined": int(sum(r.status != 0 for r in res)), "matches": int(sum(r.total_found for r in res)),
            "device_bytes": int(seg5.device_bytes), "postings": int(gd.sum()), "setup_s": {"generate": round(t_gen, 1), "total": round(time.time() - t0, 1)},
-           "weight_bound": "by hits (prox_bound_keywords=0: this corpus flags each keyword's own last hit of a field)"}
+           "weight_bound": "by keywords (prox_bound_keywords=1: this corpus flags the hit at a field's last position, as the reference's indexer does)"}
     for bb in bs:
         bb.close()
     seg5.close()

@@ -431,7 +431,8 @@ typedef struct {
   uint32_t max_pos;         /* positions uniform in [1, max_pos] */
   uint32_t skiplist_block_size;
   uint32_t hit_format;
-  uint32_t end_markers;     /* set the field-end bit on a doc's last hit per field */
+  uint32_t end_markers;     /* field-end bits: 0 none; 1 on each word's own last hit per field (two words at one position may differ in it);
+                               2 on the hit at the field's last POSITION in that doc, whatever the word -- what the reference's indexer writes */
   uint32_t n_threads;       /* 0 = hardware concurrency */
 } mrk_synth_params;
 

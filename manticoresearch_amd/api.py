@@ -201,7 +201,7 @@ def index_from_hits(wordid: np.ndarray, rowid: np.ndarray, hitpos: np.ndarray, n
 
 def synth_index(n_docs: int, term_prob: Sequence[float], seed: int = 0x5EED0001, shard: int = 0, n_fields: int = 2,
                 title_frac: float = 0.1, max_pos: int = 1024, skiplist_block_size: int = 128,
-                hit_format: int = SPH_HIT_FORMAT_INLINE, end_markers: bool = False, n_threads: int = 0,
+                hit_format: int = SPH_HIT_FORMAT_INLINE, end_markers: int = False, n_threads: int = 0,
                 rowid_base: Optional[int] = None) -> HostIndex:
     """Deterministic synthetic postings for the given per-term document probabilities.
 

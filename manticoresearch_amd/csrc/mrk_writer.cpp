@@ -324,8 +324,8 @@ extern "C" int mrk_index_from_hits(const uint64_t* wordid, const uint32_t* rowid
 // those rows -- "sharded result == unsharded result" is testable.  Inside a chunk term t occurs in a doc with
 // probability term_prob[t] (geometric gaps; restarting them at a chunk border leaves the per-doc Bernoulli law
 // untouched), tf = 1 + min(254, Geometric(1/2)), every hit falls into field 0 with probability title_frac (else one
-// of the other fields) at a uniform position in [1, max_pos]; duplicate positions collapse like the reference writer
-// collapses them.  A chunk the shard covers only partly is drawn whole and the rows outside the shard are dropped.
+// of the other fields) at a uniform position in [1, max_pos] (end_markers = 2: in [1, the field's length in that doc]); duplicate
+// positions collapse like the reference writer collapses them.  A chunk the shard covers only partly is drawn whole and the rows outside the shard are dropped.
 constexpr uint64_t SYNTH_CHUNK = 65536;
 
 extern "C" int mrk_synth_generate(const mrk_synth_params* p, mrk_host_index** out) {
@@ -369,8 +369,13 @@ extern "C" int mrk_synth_generate(const mrk_synth_params* p, mrk_host_index** ou
           const uint64_t a = splitmix64(s);
           uint32_t f = 0;
           if (p->n_fields > 1 && a >= title_thr) f = 1 + (uint32_t)((a >> 20) % (p->n_fields - 1));
-          const uint32_t pos = 1 + (uint32_t)((a & 0xFFFFF) * (uint64_t)p->max_pos >> 20);
-          tmp[n++] = (f << 24) | pos;
+          uint32_t len = p->max_pos;
+          if (p->end_markers == 2) { // the field's length in this doc: a function of (seed, rowid, field) only -- every word sees the same one
+            uint64_t hs = p->seed ^ (0xA24BAED4963EE407ull * (cbase + row + 1)) ^ (0x9E6C63D0676A9A99ull * (f + 1));
+            len = 1 + (uint32_t)(splitmix64(hs) % p->max_pos);
+          }
+          const uint32_t pos = 1 + (uint32_t)((a & 0xFFFFF) * (uint64_t)len >> 20);
+          tmp[n++] = (f << 24) | pos | ((p->end_markers == 2 && pos == len) ? 1u << 23 : 0u);
         }
         const uint64_t grow = cbase + row;
         ++row;
@@ -382,7 +387,10 @@ extern "C" int mrk_synth_generate(const mrk_synth_params* p, mrk_host_index** ou
             std::sort(tmp, tmp + n);
           n = (uint32_t)(std::unique(tmp, tmp + n) - tmp);
         }
-        if (p->end_markers) // mark each field's last hit of this word in this doc
+        // end_markers = 1: each field's last hit of THIS WORD in this doc carries the flag (a stress for the hit merges: two words at one
+        // position may differ in it); 2: the hit at the field's last POSITION does, whatever the word -- what the reference's indexer
+        // writes (sphinx.cpp:22424-22430), set above with the position
+        if (p->end_markers == 1)
           for (uint32_t i = 0; i < n; ++i)
             if (i + 1 == n || (tmp[i + 1] >> 24) != (tmp[i] >> 24)) tmp[i] |= 1u << 23;
         w.rowid.push_back((uint32_t)(grow - g0));

@@ -142,15 +142,17 @@ def test_proximity_pruning_under_ties(orc, corpus):
     assert n_orc >= 3
 
 
-def test_proximity_bound_by_keywords_on_a_corpus_without_end_flags(orc):
+@pytest.mark.parametrize("end_markers", [0, 2])
+def test_proximity_bound_by_keywords_where_positions_own_the_end_flag(orc, end_markers):
     """ctx key prox_bound_keywords = 1: the tighter weight bound in front of the hit pass (a proximity run holds every keyword at most
-    once).  It is sound where hits of different keywords at one position reach the ranker in query-position order -- here: a corpus
-    WITHOUT field-end flags and only 16 positions per field, so keywords share positions in most docs.  Device (pruned, tight bound) ==
-    device (unpruned) == oracle."""
+    once).  It is sound where hits of different keywords at one position reach the ranker in query-position order -- a corpus WITHOUT
+    field-end flags (0), or with the flag on the hit at the field's last POSITION whatever the word (2: what the reference's indexer
+    writes).  Only 16 positions per field, so keywords share positions -- the last one included -- in most docs.  Device (pruned, tight
+    bound) == device (unpruned) == oracle."""
     import manticoresearch_amd as m
 
     probs = [0.3, 0.12, 0.06, 0.031, 0.012, 0.004]
-    hi = m.synth_index(3_000_000, probs, seed=20261005, n_fields=2, max_pos=16, end_markers=False)
+    hi = m.synth_index(3_000_000, probs, seed=20261005, n_fields=2, max_pos=16, end_markers=end_markers)
     rng = np.random.default_rng(26)
     qs = []
     for t in range(16):

@@ -25,8 +25,9 @@ c = bench.zipf_c()
 ranks, strata = bench.make_queries(c, 342)
 probs = [min(0.5, c / r) for r in ranks]
 t0 = time.time()
-hi = m.synth_index(args.docs, probs, seed=bench.CORPUS_SEED + 5, n_fields=4, end_markers=True)
+hi = m.synth_index(args.docs, probs, seed=bench.CORPUS_SEED + 5, n_fields=4, end_markers=2)  # as bench.py: field-end flags owned by positions
 ctx = m.Context(0)
+ctx.set("prox_bound_keywords", 1)  # (sound on this corpus: see bench.py)
 for kv in args.set:
     ctx.set(kv.split("=")[0], int(kv.split("=")[1]))
 seg = m.Segment(ctx, hi)
