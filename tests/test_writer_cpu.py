@@ -76,6 +76,40 @@ def test_synth_index_decodes_with_oracle_reader(orc):
     assert bytes(hi.spd) == bytes(hi2.spd) and bytes(hi.spp) == bytes(hi2.spp)
 
 
+def test_synth_end_markers_owned_by_positions(orc):
+    """mrk_synth_params::end_markers = 2: the field-end flag sits on the hit at the field's LAST POSITION in that doc, whatever the word --
+    every word at that position carries it, no hit lies beyond it (what the reference's indexer writes, sphinx.cpp:22424-22430; the
+    tighter weight bound of the device path rests on it: csrc/mrk_kprune.h).  end_markers = 1 flags each word's own last hit instead."""
+    import manticoresearch_amd as m
+    probs = [0.8, 0.7, 0.6, 0.5]
+    n_docs = 4000
+
+    def collect(mode):
+        hi = m.synth_index(n_docs, probs, seed=77, n_fields=3, max_pos=6, hit_format=0, end_markers=mode, n_threads=2)
+        oi = orc.Index(hi.spd, hi.spp, hi.spe, hi.dict.view(orc.DICT_DTYPE), hi.total_docs, hi.skiplist_block_size, 0, 3)
+        seen = {}  # (rowid, field) -> {pos: set of flags}
+        for t in range(len(probs)):
+            rowid, fields, hits, hp = oi.decode_doclist(t)
+            for r, h in zip(rowid, hp):
+                for x in oi.decode_hits(h):
+                    seen.setdefault((int(r), x >> 24), {}).setdefault(x & 0x7FFFFF, set()).add((x >> 23) & 1)
+        return seen
+
+    seen = collect(2)
+    n_flagged = n_shared = 0
+    for poss in seen.values():
+        top = max(poss)
+        for pos, flags in poss.items():
+            assert len(flags) == 1, "two words at one position differ in the end flag"
+            if 1 in flags:
+                assert pos == top, "a hit lies beyond the flagged position"
+                n_flagged += 1
+            n_shared += 1
+    assert n_flagged > 1000 and n_shared > 10000
+    # (mode 1 does flag per word: at crowded positions some position must carry both values)
+    assert any(len(flags) == 2 for poss in collect(1).values() for flags in poss.values())
+
+
 def test_index_from_hits_checks_its_arguments():
     """Unsorted hits, word ids outside 1..n_terms, a zero skiplist block size or an unknown hit format come back as MRK_E_INVAL."""
     import manticoresearch_amd as m
