@@ -11,6 +11,7 @@ from test_gpu_parity import ANDNOT, OR, kw, orc_index_of, to_orc
 pytestmark = pytest.mark.gpu
 
 N_DOCS = int(os.environ.get("MRK_SCALE_DOCS", 10_000_000))
+SEED_OFF = int(os.environ.get("MRK_SCALE_SEED", 0))  # added to every query generator's seed: a soak draws other queries over the same corpora
 # document probabilities: four common keywords, two in between, four selective ones
 PROBS = [0.3, 0.12, 0.06, 0.031, 0.012, 0.004, 0.0011, 0.0004, 0.00013, 0.00005]
 
@@ -49,7 +50,7 @@ def check_order(r):
 
 def test_two_term_and_paths_agree(orc, corpus):
     m, hi = corpus
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + SEED_OFF)
     qs = []
     for a in range(len(PROBS)):
         for b in range(len(PROBS)):
@@ -78,7 +79,7 @@ def test_two_term_and_paths_agree(orc, corpus):
 def test_three_term_mixes_proximity_bm25(orc, corpus):
     """BASELINE config 3: a b c, (a|b) c, a (b|c), a b -c under SPH_RANK_PROXIMITY_BM25 (hitlist decode)."""
     m, hi = corpus
-    rng = np.random.default_rng(6)
+    rng = np.random.default_rng(6 + SEED_OFF)
     qs = []
     for _ in range(10):
         a, b, c = (int(x) for x in rng.choice(np.arange(2, len(PROBS)), 3, replace=False))
@@ -108,7 +109,7 @@ def test_proximity_pruning_under_ties(orc, corpus):
     matter most: SPH_RANK_PROXIMITY has no BM25 part, so whole populations of matches share one weight and the sorter picks by
     rowid.  Pruned == unpruned bit for bit (common keywords, millions of matches), and == the oracle where the CPU gets through."""
     m, hi = corpus
-    rng = np.random.default_rng(16)
+    rng = np.random.default_rng(16 + SEED_OFF)
     qs, sizes = [], []
     for t in range(12):
         lo = 0 if t % 2 == 0 else 2  # even: the common keywords (prune on == off); odd: mid-range ones (oracle too)
@@ -153,7 +154,7 @@ def test_proximity_bound_by_keywords_where_positions_own_the_end_flag(orc, end_m
 
     probs = [0.3, 0.12, 0.06, 0.031, 0.012, 0.004]
     hi = m.synth_index(3_000_000, probs, seed=20261005, n_fields=2, max_pos=16, end_markers=end_markers)
-    rng = np.random.default_rng(26)
+    rng = np.random.default_rng(26 + SEED_OFF)
     qs = []
     for t in range(16):
         a, b, c = (int(x) for x in rng.choice(np.arange(0 if t % 4 == 0 else 1, 5), 3, replace=False))
@@ -190,7 +191,7 @@ def test_phrase_mix_with_field_weights(orc, corpus):
     """BASELINE config 5 shapes: PHRASE (alone, with another keyword, in an OR) + field weights, default ranker."""
     from test_gpu_parity import PHRASE
     m, hi = corpus
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + SEED_OFF)
     qs = []
     for _ in range(12):
         a, b, c, d = (int(x) for x in rng.choice(np.arange(0, 8), 4, replace=False))
@@ -216,7 +217,7 @@ def test_generic_evaluator_shapes_at_scale(orc, corpus):
     passes): five common keywords under the hit rankers, a 5-word proximity, NEAR over phrases, BEFORE over groups, NOTNEAR, SENTENCE with
     a keyword standing in for the boundary word, NEAR over four operands at the root (probe launch) -- each against the oracle."""
     m, hi = corpus
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(8 + SEED_OFF)
     X = m.XQNode
     qs = []
     for _ in range(4):
