@@ -634,6 +634,9 @@ enum { EN_TERM, EN_MULTIAND, EN_AND, EN_OR, EN_MAYBE, EN_ANDNOT, EN_PHRASE, EN_Q
 typedef struct {
   qword qw;
   uint32_t queried32;
+  uint32_t queried_hi[7]; /* m_dQueriedFields dwords 1..7 (indexes with more than 32 fields) */
+  int wide_index;         /* ISphQwordSetup::m_bHasWideFields: the index has more than 32 fields */
+  int has_wide;           /* m_bHasWideFields of the node: wide index AND some queried field >= 32 (searchnode.cpp:1837-1841, 2717-2725) */
   float idf;
   int atom_pos;
   int nodepos;
@@ -724,12 +727,37 @@ static int en_docs_count(const enode* e) { /* GetDocsCount, searchnode.cpp:194, 
   return e->kind == EN_TERM && !e->tp_kind ? e->t.qw.docs : INT_MAX;
 }
 
-/* FitsFields, searchnode.cpp:2727-2747 / 1925-1929 (32-field path) */
-static inline int fits_fields(const mnode* n) { return (n->qw.fields32 & n->queried32) != 0; }
+/* ISphQword::CollectHitMask (sphinxsearch.cpp:50-58): the doclist entry carries the low dword of the doc's field mask only
+   (Assign32, sphinx.cpp:516-535); the other dwords come from the doc's hits */
+static void collect_hit_mask(qword* q, uint32_t mask[8]) {
+  memset(mask, 0, 8 * sizeof(uint32_t));
+  mask[0] = q->fields32;
+  qw_seek_hitlist(q, q->hitlist_pos);
+  for (;;) {
+    const uint32_t h = qw_next_hit(q);
+    if (h == ORC_EMPTY_HIT) break;
+    const uint32_t f = ORC_HIT_FIELD(h);
+    mask[f >> 5] |= 1u << (f & 31u);
+  }
+}
 
-static inline int queried_test(uint32_t queried32, uint32_t field) {
-  if (field < 32) return (queried32 >> field) & 1u;
-  return queried32 == 0xFFFFFFFFu; /* >32 fields: only the unrestricted mask is restated */
+/* FitsFields, searchnode.cpp:2727-2747 / 1925-1939: fields 0-31 from the doclist mask; a node that queries a field >= 32 of a wide
+   index collects the doc's whole mask from its hits first */
+static inline int fits_fields(mnode* n) {
+  if (!n->has_wide) return (n->qw.fields32 & n->queried32) != 0;
+  uint32_t m[8];
+  collect_hit_mask(&n->qw, m);
+  if (m[0] & n->queried32) return 1;
+  for (int i = 0; i < 7; i++)
+    if (m[i + 1] & n->queried_hi[i]) return 1;
+  return 0;
+}
+
+/* m_dQueriedFields.Test ( HITMAN::GetField ( hit ) ) */
+static inline int queried_test(const mnode* n, uint32_t field) {
+  if (field < 32) return (n->queried32 >> field) & 1u;
+  if (n->wide_index) return (n->queried_hi[(field >> 5) - 1] >> (field & 31u)) & 1u;
+  return n->queried32 == 0xFFFFFFFFu; /* (a hit in a field the schema does not have: only the unrestricted mask lets it through) */
 }
 
 static inline float term_tfidf(uint32_t hits, float idf) {
@@ -747,7 +775,7 @@ static void term_raw_hits(enode* e, hitvec* out) {
   for (;;) {
     uint32_t h = qw_next_hit(&n->qw);
     if (h == ORC_EMPTY_HIT) break;
-    if (!queried_test(n->queried32, ORC_HIT_FIELD(h))) continue;
+    if (!queried_test(n, ORC_HIT_FIELD(h))) continue;
     hit_t t;
     t.rowid = e->rowid;
     t.hitpos = h;
@@ -914,9 +942,9 @@ static void mand_hits(enode* e, hitvec* out) {
     }
     if (best < 0) break;
     mnode* n = &e->m[best];
-    uint32_t fmask = n->queried32;
-    if (phase == 1) fmask = e->m[best == tl ? 0 : 1].queried32;
-    if (!e->test_fields || queried_test(fmask, ORC_HIT_FIELD(cur[best]))) {
+    const mnode* fnode = n;
+    if (phase == 1) fnode = &e->m[best == tl ? 0 : 1];
+    if (!e->test_fields || queried_test(fnode, ORC_HIT_FIELD(cur[best]))) {
       hit_t t;
       t.rowid = e->rowid;
       t.hitpos = cur[best];
@@ -1817,6 +1845,12 @@ static enode* en_new(build_ctx* bc, int kind) {
 static void mnode_init(build_ctx* bc, mnode* n, const orc_node* qn, int nodepos) {
   qw_setup(&n->qw, bc->idx, qn->term_id, &bc->skips);
   n->queried32 = qn->field_mask;
+  n->wide_index = bc->idx->n_fields > 32;
+  n->has_wide = 0;
+  for (int i = 0; i < 7; i++) {
+    n->queried_hi[i] = n->wide_index ? qn->field_mask_hi[i] : 0u;
+    if (n->queried_hi[i]) n->has_wide = 1;
+  }
   n->idf = 0.0f;
   n->atom_pos = qn->atom_pos;
   n->nodepos = nodepos;
@@ -1873,6 +1907,7 @@ static enode* build_phrase(build_ctx* bc, const orc_node* qn) {
     const orc_node* c = &bc->q->nodes[bc->q->children[qn->first_child + i]];
     orc_node w = *c;
     w.field_mask = qn->field_mask & c->field_mask; /* words inherit the phrase node's field spec */
+    for (int d = 0; d < 7; d++) w.field_mask_hi[d] = qn->field_mask_hi[d] & c->field_mask_hi[d];
     if (w.term_pos) {
       bc->error = 1;
       fail("position modifiers on the words of a phrase are not restated in the oracle");
@@ -1966,6 +2001,7 @@ static enode* build_node(build_ctx* bc, int ni) {
         }
         orc_node w = *c;
         w.field_mask = qn->field_mask & c->field_mask; /* Create ( word, pNode, .. ): the quorum node's field spec */
+        for (int d = 0; d < 7; d++) w.field_mask_hi[d] = qn->field_mask_hi[d] & c->field_mask_hi[d];
         terms[i] = build_term(bc, &w);
         key[i] = en_docs_count(terms[i]);
         pos[i] = i;
@@ -2065,7 +2101,10 @@ static enode* build_node(build_ctx* bc, int ni) {
           mnode_init(bc, &tmp[i], c, i);
           key[i] = tmp[i].qw.docs;
           pos[i] = i;
-          if (c->field_mask != 0xFFFFFFFFu) test_fields = 1;
+          if (c->field_mask != 0xFFFFFFFFu) test_fields = 1; /* TEST_FIELDS = !m_dFieldMask.TestAll ( true ) */
+          if (bc->idx->n_fields > 32)
+            for (int d = 0; d < 7; d++)
+              if (c->field_mask_hi[d] != 0xFFFFFFFFu) test_fields = 1;
         }
         sph_isort_idx(pos, k, key); /* m_dNodes.Sort ( SelectivitySorter_t ) :2791 */
         e->m = (mnode*)calloc((size_t)k, sizeof(mnode));
@@ -2176,6 +2215,7 @@ static enode* build_node(build_ctx* bc, int ni) {
           orc_node w;
           memset(&w, 0, sizeof w);
           w.op = ORC_OP_TERM, w.term_id = qn->term_id, w.field_mask = qn->field_mask, w.boost = 1.0f;
+          memcpy(w.field_mask_hi, qn->field_mask_hi, sizeof w.field_mask_hi);
           cur->dot = build_term(bc, &w);
         }
       }
@@ -2644,7 +2684,7 @@ int orc_search(const orc_index* idx, const orc_query* q, orc_result* res) {
   res->total_found = 0;
   res->fetched_docs = res->fetched_hits = res->skips = 0;
   if (q->max_matches <= 0) return fail("max_matches must be > 0");
-  if (idx->n_fields > 32) return fail("oracle restates the <=32-field path only");
+  if (idx->n_fields > ORC_MAX_FIELDS) return fail("more fields than SPH_MAX_FIELDS");
 
   int ranker = q->ranker;
   const orc_node* rootq = &q->nodes[q->root];

@@ -139,6 +139,8 @@ typedef struct {
   int not_weighted;
   int term_pos;        /* ORC_TERMPOS_*: XQKeyword_t::m_bFieldStart / m_bFieldEnd, XQLimitSpec_t::m_iFieldMaxPos */
   int field_max_pos;   /* m_iFieldMaxPos for ORC_TERMPOS_LIMIT */
+  uint32_t field_mask_hi[7]; /* m_dFieldMask dwords 1..7: fields 32..255 (FieldMask_t, sphinx.h:830-900); read only for indexes with
+                                more than 32 fields -- "any field" there = all ones in every dword */
 } orc_node;
 
 /* TermPosFilter_e (searchnode.cpp:875-878, 1145-1146) */

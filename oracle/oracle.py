@@ -52,7 +52,7 @@ class _Index(C.Structure):
 class _Node(C.Structure):
     _fields_ = [("op", C.c_int), ("n_children", C.c_int), ("first_child", C.c_int), ("term_id", C.c_int32),
                 ("atom_pos", C.c_int), ("field_mask", C.c_uint32), ("boost", C.c_float), ("opt", C.c_int),
-                ("not_weighted", C.c_int), ("term_pos", C.c_int), ("field_max_pos", C.c_int)]
+                ("not_weighted", C.c_int), ("term_pos", C.c_int), ("field_max_pos", C.c_int), ("field_mask_hi", C.c_uint32 * 7)]
 
 
 class _Filter(C.Structure):
@@ -283,7 +283,10 @@ class FlatQuery:
             cn = self.nodes[i]
             cn.op, cn.n_children, cn.first_child = n.op, len(n._kids), len(kids)  # type: ignore[attr-defined]
             kids.extend(n._kids)  # type: ignore[attr-defined]
-            cn.term_id, cn.atom_pos, cn.field_mask, cn.boost = n.term_id, n.atom_pos, n.field_mask, n.boost
+            cn.term_id, cn.atom_pos, cn.field_mask, cn.boost = n.term_id, n.atom_pos, n.field_mask & 0xFFFFFFFF, n.boost
+            # fields 32..255 (indexes with more than 32 fields): ALL_FIELDS = any field; else the mask's bits above 32
+            for d in range(7):
+                cn.field_mask_hi[d] = 0xFFFFFFFF if n.field_mask == ALL_FIELDS else (n.field_mask >> (32 * (d + 1))) & 0xFFFFFFFF
             cn.opt = n.opt
             cn.term_pos, cn.field_max_pos = n.term_pos, n.field_max_pos
         self.children = (C.c_int * max(1, len(kids)))(*kids)

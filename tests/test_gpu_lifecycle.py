@@ -58,3 +58,25 @@ def test_batcher_from_python_threads():
     st = bt.stats()
     assert st["queries"] == len(qs) and st["launches"] <= len(qs)
     ctx.close()
+
+
+def test_more_than_32_fields_is_declined_at_load():
+    """The device path covers <= 32 fields (the doclist entry's field mask is one dword; beyond it the mask comes from the hits:
+    ISphQword::CollectHitMask, restated in the oracle and pinned by test/test_183's rows -- tests/test_oracle_wide_fields.py).
+    A 40-field index is refused when the segment is created, loudly, and the context stays usable."""
+    import manticoresearch_amd as m
+    from manticoresearch_amd import _lib
+
+    W = np.array([1, 1, 2], np.uint64)
+    R = np.array([0, 1, 1], np.uint32)
+    H = np.array([(36 << 24) | 1, (3 << 24) | 1, (36 << 24) | 2], np.uint32)
+    hi = m.index_from_hits(W, R, H, n_terms=2, total_docs=2, n_fields=40)
+    ctx = m.Context(0)
+    try:
+        with pytest.raises(_lib.MrkError) as e:
+            m.Segment(ctx, hi)
+        assert e.value.code == _lib.MRK_E_UNSUPPORTED and "fields" in str(e.value)
+        ok = m.Segment(ctx, m.synth_index(1000, [0.5], seed=3))
+        ok.close()
+    finally:
+        ctx.close()
